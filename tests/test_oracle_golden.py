@@ -1,0 +1,230 @@
+"""Pins the CPU oracle (oracle/) to vectors produced by the reference itself (tests/golden/)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import butd as ob
+from oracle import ciderd as oc
+from synth import feats_from_seed, masks_from_seed, probe_indices
+
+TOL = 1e-4   # BASELINE.json north_star: "CIDEr reward and XE loss within 1e-4 fp32"
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def sd_of(g, prefix="sd."):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+@pytest.fixture(scope="module", params=["butd_dec_tiny", "butd_dec_odd"])
+def dec(request, golden_dir):
+    g = load(golden_dir, request.param)
+    return g, ob.to_params(sd_of(g)), torch.from_numpy(g["feats"])
+
+
+def test_step(dec):
+    g, p, feats = dec
+    st = tuple(torch.from_numpy(g["step_" + k]) for k in ("h1", "c1", "h2", "c2"))
+    logits, alpha, (h1, c1, h2, c2) = ob.step(feats, feats.mean(1), torch.from_numpy(g["step_it"]), st, p)
+    for got, key in ((h1, "nh1"), (c1, "nc1"), (h2, "nh2"), (c2, "nc2"), (alpha, "alpha"), (logits, "logits")):
+        np.testing.assert_allclose(got.numpy(), g["step_" + key], atol=2e-5, rtol=1e-5)
+
+
+def test_greedy_token_exact(dec):
+    g, p, feats = dec
+    ids, alphas, logits = ob.greedy(feats, p, 20)
+    assert np.array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(alphas.numpy(), g["greedy_alphas"], atol=1e-5)
+    np.testing.assert_allclose(logits.numpy(), g["greedy_logits"], atol=1e-4)
+
+
+def beam_regime_params(p, g, regime):
+    """The four <end>-logit regimes of the beam goldens (tests/golden/make_goldens.py, G-beam)."""
+    q = {k: v.clone() for k, v in p.items()}
+    if regime == "early":
+        q["predict.bias"][2] = 4.0
+    elif regime == "never":
+        q["predict.bias"][2] = -1e4
+    elif regime == "track":
+        tok = int(g["beam_track_tok"])
+        q["predict.weight_v"][2] = q["predict.weight_v"][tok]
+        q["predict.weight_g"][2] = q["predict.weight_g"][tok]
+        q["predict.bias"][2] = q["predict.bias"][tok] - 0.2
+    return q
+
+
+BEAM_CASES = [(r, k, i) for r in ("nat", "early", "never", "track") for k in (1, 3, 5) for i in range(3)]
+
+
+def test_beam_token_exact(dec):
+    g, p, feats = dec
+    mid_sentence_end = 0
+    for regime, k, img in BEAM_CASES:
+        q = beam_regime_params(p, g, regime)
+        want = g["beam_%s_k%d_i%d" % (regime, k, img)]
+        got = ob.beam_search(feats[img:img + 1], q, k).numpy()
+        assert got.dtype == np.float32 and got.shape == want.shape, (regime, k, img)
+        assert np.array_equal(got, want), (regime, k, img)
+        if regime == "never":
+            assert want.shape[1] == 51 and 2 not in want
+        if want[0, -1] == 2 and want.shape[1] > 3:
+            mid_sentence_end += 1
+    assert mid_sentence_end >= 1      # the shrinking-k / best-complete path is exercised
+
+
+def test_xe_forward_loss_grads(dec):
+    g, _, feats = dec
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    B, R, D, H, E, A, V = g["dims"]
+    lengths = g["xe_lengths"].tolist()
+    att = np.unpackbits(g["xe_att_mask"], axis=-1)[..., :A]
+    logits = ob.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p,
+                           g["xe_emb_mask"], att, g["xe_out_mask"])
+    np.testing.assert_allclose(logits.detach().numpy(), g["xe_packed_logits"], atol=1e-4)
+    order = ob.packed_order(lengths)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in order])
+    assert np.array_equal(tgt.numpy(), g["xe_packed_targets"])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["xe_loss"])) < TOL
+    assert abs(ob.label_smoothing_loss(logits.detach(), tgt, 0.0).item() - float(g["xe_loss_s0"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["xe_grad." + k], atol=2e-5, rtol=1e-4, err_msg=k)
+
+
+def test_sample_rl_and_reinforce_grads(dec):
+    g, _, feats = dec
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    B, R, D, H, E, A, V = g["dims"]
+    with torch.no_grad():
+        p["predict.bias"][2] = float(g["rl_end_bias"])
+    att = np.unpackbits(g["rl_att_mask"], axis=-1)[..., :A]
+    seq, lp, logits = ob.sample_rl(feats, p, g["rl_u"], g["rl_emb_mask"], att, g["rl_out_mask"], 20)
+    assert np.array_equal(seq.numpy(), g["rl_seq"])
+    np.testing.assert_allclose(lp.detach().numpy(), g["rl_logprobs"], atol=1e-5)
+    assert logits.shape[1] == int(g["rl_steps_run"])
+    loss = ob.reward_criterion(lp, seq, torch.from_numpy(g["rl_reward"]))
+    assert abs(loss.item() - float(g["rl_loss"])) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["rl_grad." + k], atol=2e-6, rtol=1e-4, err_msg=k)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def cider_fx(golden_dir):
+    return json.load(open(os.path.join(golden_dir, "ciderd_cases.json")))
+
+
+@pytest.mark.parametrize("which", ["cases", "abstract"])
+def test_ciderd_bit_exact(cider_fx, which):
+    fx = cider_fx if which == "cases" else cider_fx["abstract"]
+    docfreq = oc.DocFreq.from_json(fx["df"])
+    gts = fx["gts"]
+    hyps = [r["caption"][0] for r in fx["res"]]
+    refs = [gts[str(r["image_id"])] for r in fx["res"]]
+    got = oc.ciderd_scores(hyps, refs, docfreq)
+    assert np.array_equal(got, np.array(fx["scores"])), np.abs(got - np.array(fx["scores"])).max()
+    assert float(np.mean(got)) == fx["score"]
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def eng(golden_dir):
+    g = load(golden_dir, "butd_engine_tiny")
+    fx = json.load(open(os.path.join(golden_dir, "butd_engine_tiny.json")))
+    return g, fx
+
+
+def check_pinned(g, prefix, params, slack=0.0):
+    """slack = sum of learning rates applied so far.  d(loss)/d(atten.affine.bias) is identically zero
+    (softmax is shift-invariant, BUTD_Model.py:59-60), so what the reference feeds Adam for it is rounding
+    noise ~1e-9 that Adam's g/(sqrt(v)+eps) amplifies to anything within +-lr per step: that one scalar is
+    only comparable to within `slack`."""
+    for k, v in params.items():
+        a = v.detach().numpy()
+        base = "%sdecoder.%s/" % (prefix, k)
+        if k == "atten.affine.bias":
+            np.testing.assert_allclose(a, g[base + "full"], atol=slack * 1.01 + 1e-7, rtol=0, err_msg=k)
+        elif base + "full" in g:
+            np.testing.assert_allclose(a, g[base + "full"], atol=3e-6, rtol=0, err_msg=k)
+        else:
+            f = a.reshape(-1)
+            np.testing.assert_allclose(f[probe_indices(f.size)], g[base + "sample"], atol=3e-6, rtol=0, err_msg=k)
+            assert abs(f.astype(np.float64).sum() - float(g[base + "sum"])) < 1e-5 * max(1.0, np.sqrt(f.size))
+            assert abs((f.astype(np.float64) ** 2).sum() - float(g[base + "sumsq"])) < 1e-6 * f.size
+
+
+def test_reward_end_to_end(eng):
+    g, fx = eng
+    ix2word = dict(enumerate(fx["vocab"]))
+    docfreq = oc.DocFreq.from_json(fx["df"])
+    B = g["r1_gen"].shape[0]
+    gts = {int(k): v for k, v in fx["r1_gts"].items()}
+    r = oc.self_critical_reward(g["r1_gen"], g["r1_greedy"], gts, list(range(B)), ix2word, docfreq)
+    assert r.dtype == np.float32 and np.array_equal(r, g["r1_reward"])
+    assert oc.sampled_sentence(g["r1_gen"][0], ix2word) == "<pad>"
+    assert oc.greedy_sentence(g["r1_greedy"][0], ix2word) == ""
+
+
+def test_eval_json_and_beam(eng):
+    g, fx = eng
+    B, R, D, H, E, A, V = g["dims"]
+    p = ob.to_params(sd_of(g, "sd0."))
+    feats = torch.from_numpy(feats_from_seed(int(g["eval_feats_seed"]), B, R, D))
+    ids, _, _ = ob.greedy(feats, p, 20)
+    assert np.array_equal(ids.numpy(), g["eval_greedy_ids"])
+    ix2word = dict(enumerate(fx["vocab"]))
+    assert oc.captions_json(ids.numpy(), g["eval_img_ids"], ix2word) == fx["eval_greedy_json"]
+    for i in range(B):
+        s = ob.beam_search(feats[i:i + 1], p, 3).numpy()
+        assert np.array_equal(s.ravel(), g["eval_beam3_seq_%d" % i])
+        assert oc.captions_json(s, g["eval_img_ids"][i:i + 1], ix2word)[0] == fx["eval_beam3_json"][i]
+
+
+def test_engine_xe_then_scst_steps(eng):
+    """Engine.training_epoch x2 then SCST_training_epoch x2 (Engine.py:169-188, 251-272) restated."""
+    g, fx = eng
+    B, R, D, H, E, A, V = g["dims"]
+    p = ob.to_params(sd_of(g, "sd0."), requires_grad=True)
+    ix2word = dict(enumerate(fx["vocab"]))
+    docfreq = oc.DocFreq.from_json(fx["df"])
+    opt = ob.Adam(p, 4e-4)
+    for s in range(2):
+        pre = "xe%d_" % s
+        feats = torch.from_numpy(feats_from_seed(int(g[pre + "feats_seed"]), B, R, D))
+        caps = torch.from_numpy(g[pre + "captions"])
+        lengths = [int(l) - 1 for l in g[pre + "lengths"]]
+        em, am, om, _ = masks_from_seed(int(g[pre + "mask_seed"]), max(lengths), B, R, E, A, H)
+        logits = ob.forward_xe(feats, caps, lengths, p, em, am, om)
+        tgt = torch.tensor([int(caps[b, t + 1]) for b, t in ob.packed_order(lengths)])
+        loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+        assert abs(loss.item() - float(g[pre + "loss"])) < TOL
+        grads = dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()))))
+        opt.step(grads, 0.1)
+        check_pinned(g, pre + "sd.", p, slack=4e-4 * (s + 1))
+    opt = ob.Adam(p, 2e-5)
+    for s in range(2):
+        pre = "rl%d_" % s
+        feats = torch.from_numpy(feats_from_seed(int(g[pre + "feats_seed"]), B, R, D))
+        em, am, om, u = masks_from_seed(int(g[pre + "mask_seed"]), 20, B, R, E, A, H)
+        with torch.no_grad():
+            gre, _, _ = ob.greedy(feats, p, 20)
+        assert np.array_equal(gre.numpy(), g[pre + "greedy_ids"])
+        seq, lp, _ = ob.sample_rl(feats, p, u, em, am, om, 20)
+        assert np.array_equal(seq.numpy(), g[pre + "seq"])
+        np.testing.assert_allclose(lp.detach().numpy(), g[pre + "logprobs"], atol=TOL)
+        img_ids = [int(i) for i in g[pre + "img_ids"]]
+        gts = {int(k): v for k, v in fx[pre + "gts"].items()}
+        rew = oc.self_critical_reward(seq.numpy(), gre.numpy(), gts, img_ids, ix2word, docfreq)
+        assert np.array_equal(rew, g[pre + "reward"])
+        loss = ob.reward_criterion(lp, seq, torch.from_numpy(rew))
+        assert abs(loss.item() - float(g[pre + "loss"])) < TOL
+        grads = dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()))))
+        opt.step(grads, 0.25)
+        check_pinned(g, pre + "sd.", p, slack=8e-4 + 2e-5 * (s + 1))
