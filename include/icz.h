@@ -1,0 +1,170 @@
+/* libicz -- C ABI of the MI355X-native caption-decoding hot path (BUTD / SCST).
+ *
+ * The reference (zyj0021200/simpleImageCaptionZoo) is pure Python on PyTorch and has no FFI of its own; its
+ * extension point for this path is the duck-typed Captioner nn.Module that Engine calls
+ * (Engine.py:179-182, 258-262, 284-286) plus the loss / reward helpers in Utils.py.  Each entry point below
+ * names the reference function it replaces.  INTEGRATION.md shows the ctypes binding a maintainer adds.
+ *
+ * Conventions: every pointer is a DEVICE pointer unless the name ends in _host; tensors are dense row-major
+ * fp32 unless stated; ids are int64 (torch.LongTensor); `stream` is a hipStream_t passed as void* (0 = null
+ * stream).  Calls are asynchronous on `stream`; nothing synchronises the device unless documented.  The
+ * library never frees caller memory.  Return value: ICZ_OK (0) or a negative icz_status; icz_last_error()
+ * gives the text (thread-local).  A handle is not thread-safe; distinct handles are independent.
+ */
+#ifndef ICZ_H_
+#define ICZ_H_
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum {
+    ICZ_OK = 0,
+    ICZ_ERR_INVALID = -1,   /* bad argument / shape / alignment */
+    ICZ_ERR_HIP = -2,       /* a HIP runtime call failed        */
+    ICZ_ERR_STATE = -3,     /* call order violated (e.g. backward before sample) */
+    ICZ_ERR_NOMEM = -4
+} icz_status;
+
+const char* icz_last_error(void);
+/* library version and the gfx target it was built for ("gfx950") */
+const char* icz_version(void);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * BUTD top-down attention decoder (Models/BUTD_Model.py:64-318, DecoderRNN + SoftAttention)
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct icz_butd icz_butd_t;
+
+typedef struct {
+    int32_t R;        /* regions per image (36 bottom-up boxes, 49 for the 7x7 spatial grid) */
+    int32_t D;        /* region feature size (2048)                                          */
+    int32_t H;        /* LSTM hidden size (Configs/Models/BUTDDetection.json: 1024)          */
+    int32_t E;        /* embedding size                                                      */
+    int32_t A;        /* attention size                                                      */
+    int32_t V;        /* vocabulary size                                                     */
+    int32_t max_rows; /* capacity in decoder rows: batch for greedy/sample/XE, images*beam for beam search */
+    int32_t max_len;  /* capacity in time steps kept for backward (>= max_len of sample / XE length)        */
+} icz_butd_dims;
+
+/* Parameter block in the reference's state_dict layout (keys "decoder.<name>", BUTD_Model.py:75-84;
+ * weight_norm'd Linear layers are the old-style (weight_g, weight_v) pairs).  The same struct type carries
+ * gradients (one buffer per parameter, same shapes). */
+typedef struct {
+    float* embed_weight;                          /* embed.0.weight          [V, E]            */
+    float *td_w_ih, *td_w_hh, *td_b_ih, *td_b_hh; /* TD_atten.*              [4H, H+D+E] [4H, H] [4H] [4H] */
+    float *lm_w_ih, *lm_w_hh, *lm_b_ih, *lm_b_hh; /* language_model.*        [4H, D+H]   [4H, H] [4H] [4H] */
+    float *enc_att_v, *enc_att_g, *enc_att_b;     /* atten.enc_att.weight_v [A, D], weight_g [A,1], bias [A] */
+    float *dec_att_v, *dec_att_g, *dec_att_b;     /* atten.dec_att.*        [A, H], [A,1], [A]               */
+    float *affine_v, *affine_g, *affine_b;        /* atten.affine.*         [1, A], [1,1], [1]               */
+    float *predict_v, *predict_g, *predict_b;     /* predict.*              [V, H], [V,1], [V]               */
+} icz_butd_params;
+
+int icz_butd_create(const icz_butd_dims* dims, icz_butd_t** out);
+int icz_butd_destroy(icz_butd_t* h);
+/* Bind the (caller-owned, device-resident) parameters; pointers must stay valid while the handle is used. */
+int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
+/* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */
+int icz_butd_refresh_weights(icz_butd_t* h, void* stream);
+
+/* DecoderRNN.sample (BUTD_Model.py:153-189): greedy decode.
+ * feats [B,R,D]; ids_out [B,max_len] int64; alphas_out [B,max_len,R] or NULL. */
+int icz_butd_greedy(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out,
+                    float* alphas_out, void* stream);
+
+/* Randomness for the training-mode paths.  Either explicit arrays (parity tests; layouts below) or, for any
+ * NULL pointer, an in-kernel counter-based generator (Philox4x32-10) keyed by `seed` -- reproduced
+ * bit-for-bit by the matching backward call, so nothing is stored. */
+typedef struct {
+    uint64_t seed;
+    const float* uniforms;     /* [T, B]        one draw per row per step (multinomial), in [0,1) */
+    const uint8_t* emb_mask;   /* [T, B, E]     keep-masks (1 = keep) of nn.Dropout(0.5) on the embedding, */
+    const uint8_t* att_mask;   /* [T, B, R, A]  on relu(enc_ctx + dec_ctx) in SoftAttention,               */
+    const uint8_t* out_mask;   /* [T, B, H]     and on h2 before `predict`                                 */
+} icz_rng;
+
+/* DecoderRNN.sample_rl (BUTD_Model.py:191-234), training mode (dropout active).
+ * seq_out [B,max_len] int64 (0 at and after a sampled <end>), logprobs_out [B,max_len].  Activations needed by
+ * icz_butd_sample_backward are kept inside the handle until the next sample/XE call. */
+int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
+                    int64_t* seq_out, float* logprobs_out, void* stream);
+
+/* RewardCriterion.forward + loss.backward() for the rollout kept by the last icz_butd_sample
+ * (Utils.py:295-317, Engine.py:266-270).  reward [B,max_len]; grads receives d loss / d parameter (overwritten,
+ * not accumulated); loss_out (1 float, device) receives the loss.
+ * Data-parallel use: pass mask_sum_global > 0 to normalise by the all-rank sum of the mask instead of the
+ * local one; mask_sum_out (1 float, device, may be NULL) always receives the local mask sum. */
+int icz_butd_sample_backward(icz_butd_t* h, const float* reward, const icz_butd_params* grads, float* loss_out,
+                             float* mask_sum_out, float mask_sum_global, void* stream);
+/* local sum of the REINFORCE mask of the last rollout (1 float, device) without running backward */
+int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream);
+
+/* DecoderRNN.forward + LabelSmoothingLoss + backward (BUTD_Model.py:97-151, Utils.py:268-286,
+ * Engine.py:178-186).  captions [B,L] int64, rows sorted by length descending; lengths_host[b] = len-1 as in
+ * Engine.py:178 (host array).  packed_logits_out [sum(lengths), V] in pack_padded_sequence order or NULL.
+ * n_tokens_global > 0 replaces the local token count as the loss normaliser (data-parallel). */
+int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L,
+                        const int32_t* lengths_host, const icz_rng* rng, int32_t train,
+                        float* packed_logits_out, void* stream);
+int icz_butd_xe_backward(icz_butd_t* h, float smoothing, const icz_butd_params* grads, float* loss_out,
+                         float n_tokens_global, void* stream);
+
+/* DecoderRNN.beam_search_sample (BUTD_Model.py:236-318) for n_img images at once (the reference runs one image
+ * per call, Utils.py:72-73).  feats [n_img,R,D]; seqs_out [n_img, max_steps+1] float32 incl. the leading <sta>
+ * and, if finished, the trailing <end>; lens_out [n_img] int32 = valid length of each row. */
+int icz_butd_beam_search(icz_butd_t* h, const float* feats, int32_t n_img, int32_t beam, int32_t max_steps,
+                         float* seqs_out, int32_t* lens_out, void* stream);
+
+/* One decoder step from an explicit state (BUTD_Model.py:172-182) -- exposed for the per-kernel parity tests.
+ * it [B] int64; state tensors [B,H] are updated in place; ctx_out [B,D], alpha_out [B,R], logits_out [B,V]. */
+int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* it, float* h1, float* c1,
+                  float* h2, float* c2, float* ctx_out, float* alpha_out, float* logits_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Optimiser step: clip_gradient (Utils.py:241-250, value clamp) + torch.optim.Adam(betas=(0.9,0.999),
+ * eps=1e-8, weight_decay=0) (Utils.py:219-220) fused, one call per parameter tensor.
+ * ---------------------------------------------------------------------------------------------------------- */
+int icz_adam_clamp_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                        float lr, float clip, int32_t step, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * CIDEr-D reward (Utils.py:319-367 get_self_critical_reward -> ciderD.py:30-55 -> ciderD_scorer.py:127-206)
+ * The document-frequency table and the cooked references are built once on the host by the Python side
+ * (they depend on strings) and uploaded as flat arrays; scoring runs on the device in float64.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct icz_ciderd icz_ciderd_t;
+
+/* df table: open-addressing hash of n-grams of token ids.  keys [cap,4] int32 (unused slots -1-filled, n-gram
+ * right-padded with -1), idf [cap] float64 = log(ref_len) - log(max(1, df)); cap is a power of two.
+ * default_idf = log(ref_len) (n-gram absent from the table).  penalty [64] float64: exp(-d^2/(2 sigma^2)) for
+ * |delta| = 0..63 computed on the host exactly as the reference does. */
+int icz_ciderd_create(const int32_t* df_keys, const double* df_idf, int64_t cap, double default_idf,
+                      const double* penalty, icz_ciderd_t** out);
+int icz_ciderd_destroy(icz_ciderd_t* h);
+
+/* Cooked references of a batch, CSR over images -> refs -> n-gram entries:
+ *   img_ref_ptr [B+1]; ref_ent_ptr [n_refs+1]; ent_key [n_ent,4] int32; ent_order [n_ent] int32 (1..4);
+ *   ent_w [n_ent] float64 tf-idf weight; ref_norm [n_refs,4] float64; ref_len [n_refs] int32 (bigram count).
+ * gen [B,T] int64 = sampled ids (sample_rl semantics), greedy [B,T] int64.  reward_out [B,T] float32 =
+ * (CIDEr-D(sample) - CIDEr-D(greedy)) broadcast over T.  scores_out [2B] float64 or NULL. */
+int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
+                      const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
+                      const int32_t* ent_order, const double* ent_w, const double* ref_norm,
+                      const int32_t* ref_len, float* reward_out, double* scores_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
+ * Building blocks exported for tests and benchmarks
+ * ---------------------------------------------------------------------------------------------------------- */
+/* C[M,N] = X[M,K] W[N,K]^T (+ bias[N]) on the fp32 MFMA; layout 0 = NT (y = x W^T), 1 = NN (C = X[M,K] W[K,N]),
+ * 2 = TN (C = X[K,M]^T W[K,N]).  nsplit = 0 lets the library choose (then icz_gemm_workspace_floats(M,N) floats
+ * of workspace suffice); an explicit nsplit needs nsplit*M*N floats. */
+int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias,
+                 float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,
+                 size_t workspace_floats, void* stream);
+size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* ICZ_H_ */

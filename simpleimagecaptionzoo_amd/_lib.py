@@ -1,0 +1,99 @@
+"""ctypes binding of libicz.so (the C ABI declared in include/icz.h).
+
+The HIP library is the product: there is no CPU or eager-PyTorch fallback.  Loading fails loudly if the
+shared object is missing (build it with `python -c "import __graft_entry__ as g; g.build()"` or
+`make -C simpleimagecaptionzoo_amd/csrc`).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libicz.so")
+
+
+class IczError(RuntimeError):
+    pass
+
+
+class ButdDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("R", "D", "H", "E", "A", "V", "max_rows", "max_len")]
+
+
+BUTD_PARAM_FIELDS = (
+    "embed_weight",
+    "td_w_ih", "td_w_hh", "td_b_ih", "td_b_hh",
+    "lm_w_ih", "lm_w_hh", "lm_b_ih", "lm_b_hh",
+    "enc_att_v", "enc_att_g", "enc_att_b",
+    "dec_att_v", "dec_att_g", "dec_att_b",
+    "affine_v", "affine_g", "affine_b",
+    "predict_v", "predict_g", "predict_b",
+)
+# reference state_dict key (without the "decoder." prefix) of each field, Models/BUTD_Model.py:75-84
+BUTD_PARAM_KEYS = (
+    "embed.0.weight",
+    "TD_atten.weight_ih", "TD_atten.weight_hh", "TD_atten.bias_ih", "TD_atten.bias_hh",
+    "language_model.weight_ih", "language_model.weight_hh", "language_model.bias_ih", "language_model.bias_hh",
+    "atten.enc_att.weight_v", "atten.enc_att.weight_g", "atten.enc_att.bias",
+    "atten.dec_att.weight_v", "atten.dec_att.weight_g", "atten.dec_att.bias",
+    "atten.affine.weight_v", "atten.affine.weight_g", "atten.affine.bias",
+    "predict.weight_v", "predict.weight_g", "predict.bias",
+)
+
+
+class ButdParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in BUTD_PARAM_FIELDS]
+
+
+class Rng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("uniforms", C.c_void_p), ("emb_mask", C.c_void_p),
+                ("att_mask", C.c_void_p), ("out_mask", C.c_void_p)]
+
+
+_lib = None
+
+
+def lib():
+    """Load libicz.so once; raise IczError (never fall back) if it is missing or lacks a symbol."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise IczError("libicz.so not found at %s -- the HIP extension is required (no fallback); run "
+                       "__graft_entry__.build()" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+    sig = {
+        "icz_last_error": (C.c_char_p, []),
+        "icz_version": (C.c_char_p, []),
+        "icz_butd_create": (C.c_int, [C.POINTER(ButdDims), C.POINTER(vp)]),
+        "icz_butd_destroy": (C.c_int, [vp]),
+        "icz_butd_bind_params": (C.c_int, [vp, C.POINTER(ButdParams)]),
+        "icz_butd_refresh_weights": (C.c_int, [vp, vp]),
+        "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
+        "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
+        "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),
+    }
+    for name, (res, args) in sig.items():
+        try:
+            fn = getattr(L, name)
+        except AttributeError as e:
+            raise IczError("libicz.so lacks symbol %s (stale build?)" % name) from e
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+def check(status):
+    if status != 0:
+        raise IczError("libicz status %d: %s" % (status, lib().icz_last_error().decode()))
+
+
+def ptr(t):
+    """Device pointer of a torch tensor (None -> NULL)."""
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def stream_ptr():
+    import torch
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)

@@ -1,0 +1,101 @@
+"""Host-side owner of one libicz BUTD decoder handle (thin: shapes, pointers, stream)."""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import BUTD_PARAM_FIELDS, BUTD_PARAM_KEYS, ButdDims, ButdParams, check, lib, ptr, stream_ptr
+
+
+class ButdHandle:
+    """Wraps icz_butd_* for a fixed architecture (R, D, H, E, A, V) and row / step capacity."""
+
+    def __init__(self, R, D, H, E, A, V, max_rows, max_len=20, device="cuda:0"):
+        self.R, self.D, self.H, self.E, self.A, self.V = R, D, H, E, A, V
+        self.max_rows, self.max_len = max_rows, max_len
+        self.device = torch.device(device)
+        self._h = C.c_void_p()
+        self._params = None
+        dims = ButdDims(R, D, H, E, A, V, max_rows, max_len)
+        with torch.cuda.device(self.device):
+            check(lib().icz_butd_create(C.byref(dims), C.byref(self._h)))
+
+    def close(self):
+        if self._h:
+            lib().icz_butd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- parameters ---------------------------------------------------------------------------
+    def bind(self, tensors):
+        """tensors: {reference state_dict key without 'decoder.': fp32 CUDA tensor}.  The tensors are used in
+        place (no copy) and must stay alive; call refresh() after every update."""
+        st = ButdParams()
+        keep = []
+        for field, key in zip(BUTD_PARAM_FIELDS, BUTD_PARAM_KEYS):
+            t = tensors[key]
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise _lib.IczError("parameter %s must be a contiguous fp32 CUDA tensor" % key)
+            setattr(st, field, t.data_ptr())
+            keep.append(t)
+        self._params = keep
+        check(lib().icz_butd_bind_params(self._h, C.byref(st)))
+        self.refresh()
+
+    def refresh(self):
+        check(lib().icz_butd_refresh_weights(self._h, stream_ptr()))
+
+    # ---- decode -------------------------------------------------------------------------------
+    def _check_feats(self, feats):
+        if feats.dtype != torch.float32 or not feats.is_cuda:
+            raise _lib.IczError("feats must be an fp32 CUDA tensor")
+        if feats.dim() != 3 or feats.shape[1] != self.R or feats.shape[2] != self.D:
+            raise _lib.IczError("feats must be (B,%d,%d), got %s" % (self.R, self.D, tuple(feats.shape)))
+        return feats.contiguous()
+
+    def greedy(self, feats, max_len=20, want_alphas=False):
+        """DecoderRNN.sample (Models/BUTD_Model.py:153-189) -> ids (B,max_len) int64 [, alphas (B,max_len,R)]."""
+        feats = self._check_feats(feats)
+        B = feats.shape[0]
+        ids = torch.empty(B, max_len, dtype=torch.int64, device=feats.device)
+        alphas = torch.empty(B, max_len, self.R, dtype=torch.float32, device=feats.device) if want_alphas else None
+        check(lib().icz_butd_greedy(self._h, ptr(feats), B, max_len, ptr(ids), ptr(alphas), stream_ptr()))
+        return (ids, alphas) if want_alphas else ids
+
+    def step(self, feats, it, h1, c1, h2, c2):
+        """One decoder step from an explicit state (BUTD_Model.py:172-182); state tensors are updated in place.
+        Returns (ctx, alpha, logits)."""
+        feats = self._check_feats(feats)
+        B = feats.shape[0]
+        dev = feats.device
+        ctx = torch.empty(B, self.D, device=dev)
+        alpha = torch.empty(B, self.R, device=dev)
+        logits = torch.empty(B, self.V, device=dev)
+        check(lib().icz_butd_step(self._h, ptr(feats), B, ptr(it), ptr(h1), ptr(c1), ptr(h2), ptr(c2), ptr(ctx),
+                                  ptr(alpha), ptr(logits), stream_ptr()))
+        return ctx, alpha, logits
+
+
+def gemm(layout, X, W, bias=None, nsplit=0):
+    """Test/bench entry for icz_gemm_f32.  layout 'nt': X[M,K] W[N,K]; 'nn': X[M,K] W[K,N]; 'tn': X[K,M] W[K,N]."""
+    code = {"nt": 0, "nn": 1, "tn": 2}[layout]
+    if layout == "nt":
+        M, K = X.shape
+        N = W.shape[0]
+    elif layout == "nn":
+        M, K = X.shape
+        N = W.shape[1]
+    else:
+        K, M = X.shape
+        N = W.shape[1]
+    out = torch.empty(M, N, device=X.device, dtype=torch.float32)
+    ws = torch.empty(max(lib().icz_gemm_workspace_floats(M, N), max(nsplit, 1) * M * N), device=X.device,
+                     dtype=torch.float32)
+    check(lib().icz_gemm_f32(code, ptr(X), X.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), N, M, N, K,
+                             nsplit, ptr(ws), ws.numel(), stream_ptr()))
+    return out

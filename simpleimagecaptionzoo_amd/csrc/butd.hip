@@ -1,0 +1,327 @@
+// BUTD decoder: handle, launch sequences and C ABI (include/icz.h).  gfx950 only.
+#include <stdarg.h>
+
+#include <vector>
+
+#include "butd_impl.h"
+
+namespace icz {
+
+static thread_local char g_err[1024] = "";
+void set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+
+// ------------------------------------------------------------------------------------------------
+int Butd::alloc(void** p, size_t bytes) {
+    ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
+    allocs.push_back(*p);
+    return ICZ_OK;
+}
+
+int Butd::init(const icz_butd_dims& d) {
+    dims = d;
+    ICZ_REQUIRE(d.R > 0 && d.R <= 64, "butd: R=%d must be in 1..64 (36 boxes / 49 grid cells)", d.R);
+    ICZ_REQUIRE(d.D % 4 == 0 && d.H % 4 == 0 && d.E % 4 == 0 && d.A % 4 == 0, "butd: D,H,E,A must be multiples of 4");
+    ICZ_REQUIRE(d.V > 3 && d.max_rows > 0 && d.max_len > 0, "butd: bad V/max_rows/max_len");
+    const size_t rows = d.max_rows, H = d.H, D = d.D, E = d.E, A = d.A, V = d.V, R = d.R;
+    ICZ_TRY(alloc((void**)&w_enc, sizeof(float) * A * D));
+    ICZ_TRY(alloc((void**)&w_dec, sizeof(float) * A * H));
+    ICZ_TRY(alloc((void**)&w_aff, sizeof(float) * A));
+    ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * V * H));
+    ICZ_TRY(alloc((void**)&n_enc, sizeof(float) * A));
+    ICZ_TRY(alloc((void**)&n_dec, sizeof(float) * A));
+    ICZ_TRY(alloc((void**)&n_aff, sizeof(float) * 4));
+    ICZ_TRY(alloc((void**)&n_pred, sizeof(float) * V));
+    ICZ_TRY(alloc((void**)&mean, sizeof(float) * rows * D));
+    ICZ_TRY(alloc((void**)&premean, sizeof(float) * rows * 4 * H));
+    ICZ_TRY(alloc((void**)&enc_ctx, sizeof(float) * rows * R * A));
+    for (int i = 0; i < 2; ++i) {
+        ICZ_TRY(alloc((void**)&h1[i], sizeof(float) * rows * H));
+        ICZ_TRY(alloc((void**)&c1[i], sizeof(float) * rows * H));
+        ICZ_TRY(alloc((void**)&h2[i], sizeof(float) * rows * H));
+        ICZ_TRY(alloc((void**)&c2[i], sizeof(float) * rows * H));
+    }
+    ICZ_TRY(alloc((void**)&emb, sizeof(float) * rows * E));
+    ICZ_TRY(alloc((void**)&ctx, sizeof(float) * rows * D));
+    ICZ_TRY(alloc((void**)&scores, sizeof(float) * rows * R));
+    ICZ_TRY(alloc((void**)&alpha, sizeof(float) * rows * R));
+    ICZ_TRY(alloc((void**)&h2drop, sizeof(float) * rows * H));
+    ICZ_TRY(alloc((void**)&logits, sizeof(float) * rows * V));
+    ICZ_TRY(alloc((void**)&it, sizeof(int64_t) * rows));
+    size_t nmax = 4 * H;
+    if (A > nmax) nmax = A;
+    if (V > nmax) nmax = V;
+    ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
+    return ICZ_OK;
+}
+
+Butd::~Butd() {
+    for (void* p : allocs) (void)hipFree(p);
+}
+
+// ------------------------------------------------------------------------------------------------
+int Butd::refresh(hipStream_t st) {
+    ICZ_REQUIRE(bound, "butd: parameters not bound");
+    const int A = dims.A, D = dims.D, H = dims.H, V = dims.V;
+    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, P.enc_att_v, P.enc_att_g, w_enc, n_enc, A, D);
+    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, P.dec_att_v, P.dec_att_g, w_dec, n_dec, A, H);
+    hipLaunchKernelGGL(weight_norm_kernel, dim3(1), dim3(256), 0, st, P.affine_v, P.affine_g, w_aff, n_aff, 1, A);
+    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, P.predict_v, P.predict_g, w_pred, n_pred, V, H);
+    ICZ_CHECK_HIP(hipGetLastError());
+    fresh = true;
+    return ICZ_OK;
+}
+
+// generic "y = x W^T" with automatic split-K into the workspace; returns the split used (1 = direct into out)
+int Butd::gemm_nt(GemmArgs& g, int* nsplit_out, hipStream_t st) {
+    g.nsplit = gemm_pick_split(g, TARGET_WGS);
+    if (g.nsplit > 1) {
+        ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "butd: workspace too small for %dx%dx%d slabs", g.nsplit, g.M, g.N);
+        g.out = ws;
+        g.bias = nullptr;
+    }
+    *nsplit_out = g.nsplit;
+    return gemm_f32(GEMM_NT, g, st);
+}
+
+// Once per batch of images (K0 in SURVEY.md 2.3): mean features, the time-invariant part of the TD-LSTM gates
+// (mean . W_ih[:, H:H+D]^T) and enc_att(feats) -- the reference recomputes the latter every step (:57).
+int Butd::prologue(const float* feats, int n_img, hipStream_t st) {
+    const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A;
+    ICZ_REQUIRE(fresh, "butd: call icz_butd_refresh_weights after binding/updating parameters");
+    ICZ_REQUIRE(n_img > 0 && n_img <= dims.max_rows, "butd: %d images exceed capacity %d", n_img, dims.max_rows);
+    hipLaunchKernelGGL(mean_feats_kernel, dim3(cdiv(D, 1024), n_img), dim3(256), 0, st, feats, mean, R, D);
+    {   // premean = mean . W_ih[:, H:H+D]^T   [n_img, 4H]
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {mean, P.td_w_ih + H, D, H + D + E, D, nullptr};
+        g.M = n_img; g.N = 4 * H; g.out = premean; g.ldo = 4 * H;
+        int ns;
+        ICZ_TRY(gemm_nt(g, &ns, st));
+        if (ns > 1) {
+            size_t MN = (size_t)n_img * 4 * H;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, 4 * H, (const float*)nullptr, premean);
+        }
+    }
+    {   // enc_ctx = feats . w_enc^T + b_enc   [n_img*R, A]
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {feats, w_enc, D, D, D, nullptr};
+        g.M = n_img * R; g.N = A; g.out = enc_ctx; g.ldo = A; g.bias = P.enc_att_b;
+        int ns;
+        const float* bias = g.bias;
+        ICZ_TRY(gemm_nt(g, &ns, st));
+        if (ns > 1) {
+            size_t MN = (size_t)n_img * R * A;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, A, bias, enc_ctx);
+        }
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// One decoder step (:172-182) for `rows` decoder rows.  State is read from s.*_in and written to s.*_out.
+int Butd::step(const StepIO& s, hipStream_t st) {
+    const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A, V = dims.V;
+    const int rows = s.rows;
+    DropCfg off = {0, nullptr, 0, 0, 0};
+    // embedding -> relu -> dropout
+    hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb_out ? s.emb_out : emb, rows, E, s.drop_emb);
+    const float* embp = s.emb_out ? s.emb_out : emb;
+    int ns;
+    {   // TD-attention LSTM: [h2, mean, emb] W_ih^T + h1 W_hh^T  (mean part hoisted into premean)
+        GemmArgs g = {};
+        g.nseg = 3;
+        g.seg[0] = {s.h2_in, P.td_w_ih, H, H + D + E, H, nullptr};
+        g.seg[1] = {embp, P.td_w_ih + H + D, E, H + D + E, E, nullptr};
+        g.seg[2] = {s.h1_in, P.td_w_hh, H, H, H, nullptr};
+        g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
+        g.nsplit = gemm_pick_split(g, TARGET_WGS);
+        if (g.nsplit == 1) g.nsplit = 1;
+        ns = g.nsplit;
+        ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_floats && (size_t)rows * 4 * H <= ws_floats, "butd: workspace too small");
+        if (ns == 1) { g.out = ws; }
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
+        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, a, off);
+    }
+    {   // attention
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {s.h1_out, w_dec, H, H, H, nullptr};
+        g.M = rows; g.N = A; g.out = ws; g.ldo = A;
+        g.nsplit = gemm_pick_split(g, TARGET_WGS);
+        ns = g.nsplit;
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        const int parts = rows >= 128 ? 1 : (rows >= 32 ? 4 : 8);
+        AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A};
+        hipLaunchKernelGGL(att_scores_kernel, dim3(rows, parts), dim3(256), sizeof(float) * A, st, a, s.drop_att);
+        hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 1024)), dim3(256), 0, st, s.feats, s.img_of_row, scores,
+                           s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D);
+    }
+    const float* ctxp = s.ctx_out ? s.ctx_out : ctx;
+    {   // language LSTM: [ctx, h1] W_ih^T + h2 W_hh^T
+        GemmArgs g = {};
+        g.nseg = 3;
+        g.seg[0] = {ctxp, P.lm_w_ih, D, D + H, D, nullptr};
+        g.seg[1] = {s.h1_out, P.lm_w_ih + D, H, D + H, H, nullptr};
+        g.seg[2] = {s.h2_in, P.lm_w_hh, H, H, H, nullptr};
+        g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
+        g.nsplit = gemm_pick_split(g, TARGET_WGS);
+        ns = g.nsplit;
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
+                           s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
+        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, a, s.drop_out);
+    }
+    {   // predict: logits = drop(h2) w_pred^T + b   (K = H is short: no split-K, bias fused)
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {s.h2drop_out ? s.h2drop_out : h2drop, w_pred, H, H, H, nullptr};
+        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = V; g.bias = P.predict_b;
+        g.nsplit = 1;
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int Butd::zero_state(int rows, int which, hipStream_t st) {
+    const size_t n = sizeof(float) * rows * dims.H;
+    ICZ_CHECK_HIP(hipMemsetAsync(h1[which], 0, n, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(c1[which], 0, n, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(h2[which], 0, n, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(c2[which], 0, n, st));
+    return ICZ_OK;
+}
+
+int Butd::greedy(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && max_len > 0, "butd greedy: bad arguments");
+    ICZ_TRY(prologue(feats, B, st));
+    ICZ_TRY(zero_state(B, 0, st));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
+    int cur = 0;
+    for (int t = 0; t < max_len; ++t) {
+        StepIO s = {};
+        s.rows = B; s.feats = feats; s.it = it;
+        s.h1_in = h1[cur]; s.c1_in = c1[cur]; s.h2_in = h2[cur]; s.c2_in = c2[cur];
+        s.h1_out = h1[cur ^ 1]; s.c1_out = c1[cur ^ 1]; s.h2_out = h2[cur ^ 1]; s.c2_out = c2[cur ^ 1];
+        if (alphas_out) { s.alpha_out2 = alphas_out + (size_t)t * dims.R; s.alpha2_stride = max_len * dims.R; }
+        ICZ_TRY(step(s, st));
+        hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, st, logits, dims.V, it, ids_out, max_len, t);
+        cur ^= 1;
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // namespace icz
+
+// ================================================================================================
+using namespace icz;
+
+extern "C" {
+
+const char* icz_last_error(void) { return icz::g_err; }
+const char* icz_version(void) { return "libicz 0.1 (gfx950)"; }
+
+int icz_butd_create(const icz_butd_dims* dims, icz_butd_t** out) {
+    ICZ_REQUIRE(dims && out, "icz_butd_create: null argument");
+    Butd* b = new Butd();
+    int s = b->init(*dims);
+    if (s != ICZ_OK) { delete b; return s; }
+    *out = reinterpret_cast<icz_butd_t*>(b);
+    return ICZ_OK;
+}
+
+int icz_butd_destroy(icz_butd_t* h) {
+    delete reinterpret_cast<Butd*>(h);
+    return ICZ_OK;
+}
+
+int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* p) {
+    ICZ_REQUIRE(h && p, "icz_butd_bind_params: null argument");
+    const float* const* q = reinterpret_cast<const float* const*>(p);
+    for (size_t i = 0; i < sizeof(icz_butd_params) / sizeof(float*); ++i) {
+        ICZ_REQUIRE(q[i] != nullptr, "icz_butd_bind_params: parameter pointer %zu is null", i);
+        ICZ_REQUIRE(((uintptr_t)q[i] & 15) == 0 || i == 16 || i == 17, "icz_butd_bind_params: parameter %zu not 16-byte aligned", i);
+    }
+    Butd* b = reinterpret_cast<Butd*>(h);
+    b->P = *p;
+    b->bound = true;
+    b->fresh = false;
+    return ICZ_OK;
+}
+
+int icz_butd_refresh_weights(icz_butd_t* h, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->refresh((hipStream_t)stream);
+}
+
+int icz_butd_greedy(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out,
+                    float* alphas_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->greedy(feats, B, max_len, ids_out, alphas_out, (hipStream_t)stream);
+}
+
+int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* it, float* h1, float* c1,
+                  float* h2, float* c2, float* ctx_out, float* alpha_out, float* logits_out, void* stream) {
+    ICZ_REQUIRE(h && feats && it && h1 && c1 && h2 && c2 && logits_out, "icz_butd_step: null argument");
+    Butd* b = reinterpret_cast<Butd*>(h);
+    hipStream_t st = (hipStream_t)stream;
+    ICZ_REQUIRE(B > 0 && B <= b->dims.max_rows, "icz_butd_step: B out of range");
+    ICZ_TRY(b->prologue(feats, B, st));
+    StepIO s = {};
+    s.rows = B; s.feats = feats; s.it = it;
+    s.h1_in = h1; s.c1_in = c1; s.h2_in = h2; s.c2_in = c2;
+    // in-place update is safe: every consumer of *_in has been launched before the kernel that overwrites it
+    // only if input/output buffers differ, so run into the handle's buffers and copy back.
+    s.h1_out = b->h1[0]; s.c1_out = b->c1[0]; s.h2_out = b->h2[0]; s.c2_out = b->c2[0];
+    s.ctx_out = ctx_out; s.alpha_out = alpha_out; s.logits_out = logits_out;
+    ICZ_TRY(b->step(s, st));
+    const size_t n = sizeof(float) * B * b->dims.H;
+    ICZ_CHECK_HIP(hipMemcpyAsync(h1, b->h1[0], n, hipMemcpyDeviceToDevice, st));
+    ICZ_CHECK_HIP(hipMemcpyAsync(c1, b->c1[0], n, hipMemcpyDeviceToDevice, st));
+    ICZ_CHECK_HIP(hipMemcpyAsync(h2, b->h2[0], n, hipMemcpyDeviceToDevice, st));
+    ICZ_CHECK_HIP(hipMemcpyAsync(c2, b->c2[0], n, hipMemcpyDeviceToDevice, st));
+    return ICZ_OK;
+}
+
+size_t icz_gemm_workspace_floats(int32_t M, int32_t N) { return (size_t)Butd::TARGET_WGS * 4096 * 2 + (size_t)M * N; }
+
+int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias,
+                 float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,
+                 size_t workspace_floats, void* stream) {
+    ICZ_REQUIRE(layout >= 0 && layout <= 2, "icz_gemm_f32: layout %d", layout);
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {X, W, ldx, ldw, K, nullptr};
+    g.M = M; g.N = N; g.out = C; g.ldo = ldc; g.bias = bias;
+    g.nsplit = nsplit > 0 ? nsplit : gemm_pick_split(g, Butd::TARGET_WGS);
+    {   // normalise a caller-chosen split so that no split is empty
+        int tot = cdiv(K, GEMM_BK);
+        if (g.nsplit > tot) g.nsplit = tot;
+        g.nsplit = cdiv(tot, cdiv(tot, g.nsplit));
+    }
+    hipStream_t st = (hipStream_t)stream;
+    if (g.nsplit > 1) {
+        ICZ_REQUIRE(workspace, "icz_gemm_f32: split-K needs a workspace");
+        ICZ_REQUIRE(gemm_slab_floats(M, N, g.nsplit) <= workspace_floats, "icz_gemm_f32: workspace of %zu floats too small for %d slabs of %dx%d", workspace_floats, g.nsplit, M, N);
+        ICZ_REQUIRE(ldc == N, "icz_gemm_f32: split-K path needs ldc == N");
+        g.out = workspace; g.bias = nullptr;
+        ICZ_TRY(gemm_f32((GemmLayout)layout, g, st));
+        size_t MN = (size_t)M * N;
+        ICZ_REQUIRE(MN % 4 == 0, "icz_gemm_f32: M*N must be a multiple of 4 for the split-K reduce");
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, workspace, g.nsplit, MN, N, bias, C);
+        ICZ_CHECK_HIP(hipGetLastError());
+        return ICZ_OK;
+    }
+    return gemm_f32((GemmLayout)layout, g, st);
+}
+
+}  // extern "C"

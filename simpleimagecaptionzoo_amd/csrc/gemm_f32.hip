@@ -1,0 +1,412 @@
+// fp32 MFMA GEMMs (see gemm_f32.h for the tiling rationale).  gfx950 only.
+#include "gemm_f32.h"
+
+namespace icz {
+
+// ------------------------------------------------------------------------------------------------
+// chunk bookkeeping: the K dimension is the concatenation of the segments, cut into 64-deep chunks
+// (a segment's last chunk may be partial; loads beyond K are zero-filled).
+struct ChunkPos { int seg; int k0; };
+
+__device__ __forceinline__ ChunkPos locate_chunk(const GemmArgs& a, int chunk) {
+    ChunkPos p; p.seg = 0; p.k0 = 0;
+    int c = chunk;
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s) {
+        if (s < a.nseg) {
+            int n = (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+            if (c < n || s == a.nseg - 1) { p.seg = s; p.k0 = c * GEMM_BK; return p; }
+            c -= n;
+        }
+    }
+    return p;
+}
+
+static int total_chunks(const GemmArgs& a) {
+    int t = 0;
+    for (int s = 0; s < a.nseg; ++s) t += cdiv(a.seg[s].K, GEMM_BK);
+    return t;
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p, bool ok) {
+    f32x4 z = {0.f, 0.f, 0.f, 0.f};
+    return ok ? *reinterpret_cast<const f32x4*>(p) : z;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT: C = X W^T.  A chunk through LDS (shared by the 4 waves), W fragments straight to registers.
+// Lane (i = lane&15, q = lane>>4).  MFMA operand maps (16x16x4 f32): A[i][k=q], B[k=q][j=i];
+// one float4 along k per lane feeds 4 MFMAs (component c <-> k = 16s + 4q + c, same on both operands).
+template <int MT>
+__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * GEMM_LDS_STRIDE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * (MT * 16), z = blockIdx.z;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    {
+        int tot = 0;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG; ++s)
+            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        if (c_end > tot) c_end = tot;
+    }
+    const int ncol = n0 + wave * 16 + li;          // this lane's W row (= output column)
+    const bool ncol_ok = ncol < a.N;
+
+    f32x4 acc[MT];
+#pragma unroll
+    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    constexpr int XL = (MT * 16 * 16 + 255) / 256;   // float4 staging loads per thread per chunk
+    f32x4 xr[XL];
+    f32x4 wcur[4], wnxt[4];
+
+    auto load_chunk = [&](int chunk, f32x4 (&w)[4]) {
+        ChunkPos p = locate_chunk(a, chunk);
+        const GemmSeg& sg = a.seg[p.seg];
+        // W fragments: row ncol, k = k0 + 16s + 4q
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int k = p.k0 + 16 * s + 4 * lq;
+            w[s] = ld4(sg.B + (size_t)ncol * sg.ldb + k, ncol_ok && k < sg.K);
+        }
+        // A staging: idx -> (row, c4)
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx >> 4, c4 = idx & 15;
+            int m = m0 + row, k = p.k0 + 4 * c4;
+            bool ok = (row < MT * 16) && (m < a.M) && (k < sg.K);
+            const float* src;
+            if (sg.gather) {
+                int64_t g = ok ? sg.gather[m] : 0;
+                src = sg.A + (size_t)g * sg.lda + k;
+            } else {
+                src = sg.A + (size_t)m * sg.lda + k;
+            }
+            f32x4 v = ld4(src, ok);
+            if (sg.gather) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+            }
+            xr[j] = v;
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx >> 4, c4 = idx & 15;
+            if (row < MT * 16)
+                *reinterpret_cast<f32x4*>(&lds[buf][row * GEMM_LDS_STRIDE + 4 * c4]) = xr[j];
+        }
+    };
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin, wcur);
+        store_stage(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            const bool more = (c + 1 < c_end);
+            if (more) load_chunk(c + 1, wnxt);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                f32x4 af[MT];
+#pragma unroll
+                for (int t = 0; t < MT; ++t)
+                    af[t] = *reinterpret_cast<const f32x4*>(
+                        &lds[buf][(t * 16 + li) * GEMM_LDS_STRIDE + 16 * s + 4 * lq]);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+#pragma unroll
+                    for (int t = 0; t < MT; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], wcur[s][e], acc[t], 0, 0, 0);
+                }
+            }
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) wcur[s] = wnxt[s];
+        }
+    }
+
+    // epilogue: acc[t][r] <-> row m0 + 16t + 4q + r, column ncol
+    if (ncol_ok) {
+        if (a.nsplit == 1) {
+            const float b = a.bias ? a.bias[ncol] : 0.f;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = m0 + 16 * t + 4 * lq + r;
+                    if (m < a.M) {
+                        float* o = a.out + (size_t)m * a.ldo + ncol;
+                        float v = acc[t][r] + b;
+                        *o = a.accumulate ? (*o + v) : v;
+                    }
+                }
+        } else {
+            float* slab = a.out + (size_t)z * a.M * a.N;
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) {
+                    int m = m0 + 16 * t + 4 * lq + r;
+                    if (m < a.M) slab[(size_t)m * a.N + ncol] = acc[t][r];
+                }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// NN: C = dY W   (A(m,k) = dY[m*lda+k], B(k,n) = W[k*ldb+n]).
+// Mirror image of NT: the B chunk (64 k x 64 n, shared by the 4 waves) goes through LDS, each wave owns 16
+// rows and all 64 columns; A fragments straight to registers.  Column tiles are interleaved: a lane's
+// float4 along n at [k][4i..4i+3] supplies column 4i+j to column tile j, so one ds_read_b128 feeds 4 MFMAs.
+__global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float lds[2][GEMM_BK * GEMM_BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM, z = blockIdx.z;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    {
+        int tot = 0;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG; ++s)
+            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        if (c_end > tot) c_end = tot;
+    }
+    const int mrow = m0 + wave * 16 + li;
+    const bool mrow_ok = mrow < a.M;
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    f32x4 br[4];
+    f32x4 acur[4], anxt[4];
+
+    auto load_chunk = [&](int chunk, f32x4 (&av)[4]) {
+        ChunkPos p = locate_chunk(a, chunk);
+        const GemmSeg& sg = a.seg[p.seg];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int k = p.k0 + 16 * s + 4 * lq;
+            av[s] = ld4(sg.A + (size_t)mrow * sg.lda + k, mrow_ok && k < sg.K);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx >> 4, c4 = idx & 15;
+            int k = p.k0 + row, n = n0 + 4 * c4;
+            br[j] = ld4(sg.B + (size_t)k * sg.ldb + n, (k < sg.K) && (n < a.N));
+        }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int idx = tid + 256 * j;
+            int row = idx >> 4, c4 = idx & 15;
+            *reinterpret_cast<f32x4*>(&lds[buf][row * GEMM_BN + 4 * c4]) = br[j];
+        }
+    };
+
+    if (c_begin < c_end) {
+        load_chunk(c_begin, acur);
+        store_stage(0);
+        __syncthreads();
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            const bool more = (c + 1 < c_end);
+            if (more) load_chunk(c + 1, anxt);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    // MFMA k index q <-> k = 16s + 4q + e (A side: component e of the lane's float4)
+                    f32x4 bf = *reinterpret_cast<const f32x4*>(&lds[buf][(16 * s + 4 * lq + e) * GEMM_BN + 4 * li]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t)
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s][e], bf[t], acc[t], 0, 0, 0);
+                }
+            }
+            if (more) store_stage(buf ^ 1);
+            __syncthreads();
+#pragma unroll
+            for (int s = 0; s < 4; ++s) acur[s] = anxt[s];
+        }
+    }
+    // epilogue: acc[t][r] <-> row m0 + 16*wave + 4q + r, column n0 + 4*i + t
+    float* base = (a.nsplit == 1) ? a.out : a.out + (size_t)z * a.M * a.N;
+    const int ldo = (a.nsplit == 1) ? a.ldo : a.N;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        int m = m0 + wave * 16 + 4 * lq + r;
+        int n = n0 + 4 * li;
+        if (m < a.M && n < a.N) {
+            float* o = base + (size_t)m * ldo + n;
+            f32x4 v = {acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
+            if (a.nsplit == 1 && a.bias) {
+                v[0] += a.bias[n]; v[1] += a.bias[n + 1]; v[2] += a.bias[n + 2]; v[3] += a.bias[n + 3];
+            }
+            if (a.nsplit == 1 && a.accumulate) {
+                f32x4 old = *reinterpret_cast<f32x4*>(o);
+                v += old;
+            }
+            *reinterpret_cast<f32x4*>(o) = v;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// TN: C = dY^T X  (A(m,k) = dY[k*lda+m], B(k,n) = X[k*ldb+n]); the reduction index k runs over rows of
+// both operands (batch x time), so both are contiguous along their output index.  No LDS staging: each wave
+// takes a quarter of the chunk's k range and the whole 64 x 64 tile (16 accumulators); a lane's float4 along
+// m (resp. n) at row k supplies row 4i+j to row tile j (resp. column 4i+j to column tile j): 2 loads feed
+// 16 MFMAs.  The four waves' partial tiles are summed through LDS at the end.
+__global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
+    __shared__ __attribute__((aligned(16))) float red[3][64 * 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM, z = blockIdx.z;
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    {
+        int tot = 0;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG; ++s)
+            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        if (c_end > tot) c_end = tot;
+    }
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int mcol = m0 + 4 * li, ncol = n0 + 4 * li;
+    const bool m_ok = mcol < a.M, n_ok = ncol < a.N;
+
+    for (int c = c_begin; c < c_end; ++c) {
+        ChunkPos p = locate_chunk(a, c);
+        const GemmSeg& sg = a.seg[p.seg];
+        // wave w handles k = k0 + 16w + 4s' + q   (s' = 0..3)
+        f32x4 av[4], bv[4];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            int k = p.k0 + 16 * wave + 4 * s + lq;
+            bool kok = k < sg.K;
+            av[s] = ld4(sg.A + (size_t)k * sg.lda + mcol, kok && m_ok);
+            bv[s] = ld4(sg.B + (size_t)k * sg.ldb + ncol, kok && n_ok);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[s][u], acc[t][u], 0, 0, 0);
+    }
+    // acc[t][u][r] <-> row m0 + 4*(4q + r) + t, column n0 + 4*i + u.  Tile-local (row, col) in [0,64)^2.
+    // waves 1..3 park their tiles in LDS, wave 0 sums in fixed order (bitwise reproducible).
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 4 * (4 * lq + r) + t;
+                f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+                *reinterpret_cast<f32x4*>(&red[wave - 1][row * 64 + 4 * li]) = v;
+            }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        float* base = (a.nsplit == 1) ? a.out : a.out + (size_t)z * a.M * a.N;
+        const int ldo = (a.nsplit == 1) ? a.ldo : a.N;
+#pragma unroll
+        for (int t = 0; t < 4; ++t)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+                int row = 4 * (4 * lq + r) + t;
+                f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+#pragma unroll
+                for (int w = 0; w < 3; ++w) v += *reinterpret_cast<const f32x4*>(&red[w][row * 64 + 4 * li]);
+                int m = m0 + row, n = n0 + 4 * li;
+                if (m < a.M && n < a.N) {
+                    float* o = base + (size_t)m * ldo + n;
+                    if (a.nsplit == 1 && a.accumulate) v += *reinterpret_cast<f32x4*>(o);
+                    *reinterpret_cast<f32x4*>(o) = v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N : 0; }
+
+int gemm_pick_split(const GemmArgs& a, int target_wgs) {
+    int tiles = cdiv(a.N, GEMM_BN) * cdiv(a.M, GEMM_BM);
+    int tot = total_chunks(a);
+    int s = target_wgs / (tiles > 0 ? tiles : 1);
+    if (s < 1) s = 1;
+    if (s > tot) s = tot;
+    if (s > 32) s = 32;
+    // make every split non-empty
+    int cps = cdiv(tot, s);
+    return cdiv(tot, cps);
+}
+
+static int check_args(GemmLayout layout, const GemmArgs& a) {
+    ICZ_REQUIRE(a.nseg >= 1 && a.nseg <= GEMM_MAX_SEG, "gemm: nseg %d out of range", a.nseg);
+    ICZ_REQUIRE(a.M > 0 && a.N > 0 && a.out, "gemm: bad M/N/out");
+    ICZ_REQUIRE(a.nsplit >= 1, "gemm: nsplit %d", a.nsplit);
+    ICZ_REQUIRE(a.nsplit == 1 || (!a.bias && !a.accumulate), "gemm: bias/accumulate need nsplit == 1");
+    for (int s = 0; s < a.nseg; ++s) {
+        const GemmSeg& g = a.seg[s];
+        ICZ_REQUIRE(g.A && g.B && g.K > 0, "gemm: segment %d null operand or K<=0", s);
+        ICZ_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: segment %d operands must be 16-byte aligned", s);
+        ICZ_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: segment %d leading dims must be multiples of 4 (lda %d ldb %d)", s, g.lda, g.ldb);
+        if (layout == GEMM_NT) {
+            ICZ_REQUIRE(g.K % 4 == 0, "gemm NT: segment %d K=%d must be a multiple of 4", s, g.K);
+        } else if (layout == GEMM_NN) {
+            ICZ_REQUIRE(g.K % 4 == 0 && a.N % 4 == 0, "gemm NN: K and N must be multiples of 4 (K %d N %d)", g.K, a.N);
+            ICZ_REQUIRE(!g.gather, "gemm NN: gather unsupported");
+        } else {
+            ICZ_REQUIRE(a.M % 4 == 0 && a.N % 4 == 0, "gemm TN: M and N must be multiples of 4 (M %d N %d)", a.M, a.N);
+            ICZ_REQUIRE(!g.gather, "gemm TN: gather unsupported");
+        }
+    }
+    if (layout != GEMM_NT && a.nsplit == 1) {
+        ICZ_REQUIRE(a.ldo % 4 == 0 && ((uintptr_t)a.out & 15) == 0, "gemm: output must be float4-aligned");
+    }
+    return ICZ_OK;
+}
+
+int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    ICZ_TRY(check_args(layout, a));
+    int tot = total_chunks(a);
+    a.chunks_per_split = cdiv(tot, a.nsplit);
+    ICZ_REQUIRE(cdiv(tot, a.chunks_per_split) == a.nsplit, "gemm: nsplit %d leaves empty splits (chunks %d)", a.nsplit, tot);
+    dim3 block(256);
+    if (layout == GEMM_NT) {
+        int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
+        dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, mt * 16), a.nsplit);
+        if (mt == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, stream, a);
+        else if (mt == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, block, 0, stream, a);
+    } else if (layout == GEMM_NN) {
+        dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
+        hipLaunchKernelGGL(gemm_nn_kernel, grid, block, 0, stream, a);
+    } else {
+        dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
+        hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, a);
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // namespace icz

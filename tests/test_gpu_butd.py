@@ -1,0 +1,89 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle and the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import butd as ob  # noqa: E402
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def sd_of(g, prefix="sd."):
+    return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
+
+
+def make_handle(g, sd=None, max_rows=None, max_len=20):
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    sd = sd if sd is not None else sd_of(g)
+    sd = ob.strip_prefix(sd)
+    params = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device="cuda") for k, v in sd.items()}
+    h = ButdHandle(R, D, H, E, A, V, max_rows or max(B, 8), max_len)
+    h.bind(params)
+    return h, params
+
+
+@pytest.mark.parametrize("layout,M,N,K", [
+    ("nt", 64, 4096, 1024), ("nt", 5, 53, 96), ("nt", 64, 10102, 1024), ("nt", 130, 256, 2048),
+    ("nt", 16, 128, 48), ("nt", 33, 70, 16),
+    ("nn", 64, 1024, 4096), ("nn", 5, 96, 53 * 4), ("nn", 100, 64, 10104), ("nn", 20, 2048, 4096),
+    ("tn", 4096, 1024, 1280), ("tn", 64, 52, 100), ("tn", 128, 2048, 37), ("tn", 1024, 10104, 64),
+])
+@pytest.mark.parametrize("nsplit", [0, 1, 3])
+def test_gemm_against_float64(layout, M, N, K, nsplit):
+    from simpleimagecaptionzoo_amd.butd import gemm
+    rng = np.random.RandomState(M * 7 + N * 3 + K)
+    if layout == "nt":
+        X, W = rng.randn(M, K), rng.randn(N, K)
+        want = X @ W.T
+    elif layout == "nn":
+        X, W = rng.randn(M, K), rng.randn(K, N)
+        want = X @ W
+    else:
+        X, W = rng.randn(K, M), rng.randn(K, N)
+        want = X.T @ W
+    bias = rng.randn(N) if (N % 4 == 0 or nsplit == 1) and layout != "tn" else None
+    if nsplit == 3 and (K + 63) // 64 < 3:
+        pytest.skip("fewer K chunks than splits")
+    if nsplit != 1 and (M * N) % 4:
+        pytest.skip("split-K reduce needs M*N % 4 == 0")
+    Xd = torch.tensor(X, dtype=torch.float32, device="cuda")
+    Wd = torch.tensor(W, dtype=torch.float32, device="cuda")
+    bd = None if bias is None else torch.tensor(bias, dtype=torch.float32, device="cuda")
+    got = gemm(layout, Xd, Wd, bd, nsplit).cpu().numpy().astype(np.float64)
+    if bias is not None:
+        want = want + bias
+    # fp32 accumulation error bound ~ K * eps * |x||w|
+    tol = 4e-7 * np.sqrt(K) * 6 + 1e-6
+    assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), np.abs(got - want).max()
+
+
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+def test_step_matches_reference(golden_dir, name):
+    g = load(golden_dir, name)
+    h, _ = make_handle(g)
+    feats = torch.tensor(g["feats"], device="cuda")
+    st = [torch.tensor(g["step_" + k], device="cuda") for k in ("h1", "c1", "h2", "c2")]
+    it = torch.tensor(g["step_it"], device="cuda")
+    ctx, alpha, logits = h.step(feats, it, *st)
+    torch.cuda.synchronize()
+    for got, key in ((st[0], "nh1"), (st[1], "nc1"), (st[2], "nh2"), (st[3], "nc2"), (ctx, "ctx"), (alpha, "alpha"),
+                     (logits, "logits")):
+        np.testing.assert_allclose(got.cpu().numpy(), g["step_" + key], atol=1e-4, rtol=1e-4, err_msg=key)
+
+
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+def test_greedy_token_exact(golden_dir, name):
+    g = load(golden_dir, name)
+    h, _ = make_handle(g)
+    feats = torch.tensor(g["feats"], device="cuda")
+    ids, alphas = h.greedy(feats, 20, want_alphas=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(alphas.cpu().numpy(), g["greedy_alphas"], atol=1e-4)
