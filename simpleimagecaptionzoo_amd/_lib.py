@@ -71,6 +71,12 @@ def lib():
         "icz_butd_refresh_weights": (C.c_int, [vp, vp]),
         "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "icz_butd_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(Rng), vp, vp, vp]),
+        "icz_butd_sample_backward": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp, vp, f32, vp]),
+        "icz_butd_sample_mask_sum": (C.c_int, [vp, vp, vp]),
+        "icz_butd_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
+        "icz_butd_xe_backward": (C.c_int, [vp, f32, C.POINTER(ButdParams), vp, f32, vp]),
+        "icz_adam_clamp_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, i32, vp]),
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
         "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),
     }

@@ -4,7 +4,7 @@ import ctypes as C
 import torch
 
 from . import _lib
-from ._lib import BUTD_PARAM_FIELDS, BUTD_PARAM_KEYS, ButdDims, ButdParams, check, lib, ptr, stream_ptr
+from ._lib import BUTD_PARAM_FIELDS, BUTD_PARAM_KEYS, ButdDims, ButdParams, Rng, check, lib, ptr, stream_ptr
 
 
 class ButdHandle:
@@ -67,6 +67,70 @@ class ButdHandle:
         check(lib().icz_butd_greedy(self._h, ptr(feats), B, max_len, ptr(ids), ptr(alphas), stream_ptr()))
         return (ids, alphas) if want_alphas else ids
 
+    def _grad_struct(self, grads):
+        st = ButdParams()
+        for field, key in zip(BUTD_PARAM_FIELDS, BUTD_PARAM_KEYS):
+            t = grads[key]
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise _lib.IczError("gradient buffer %s must be a contiguous fp32 CUDA tensor" % key)
+            setattr(st, field, t.data_ptr())
+        return st
+
+    def new_grads(self):
+        """Zeroed gradient buffers, one per bound parameter (same keys / shapes)."""
+        return {k: torch.zeros_like(t) for k, t in zip(BUTD_PARAM_KEYS, self._params)}
+
+    def sample(self, feats, max_len=20, rng=None):
+        """DecoderRNN.sample_rl (BUTD_Model.py:191-234), dropout on -> (seq int64 (B,T), logprobs (B,T))."""
+        feats = self._check_feats(feats)
+        B = feats.shape[0]
+        rng = rng or make_rng(0)
+        seq = torch.zeros(B, max_len, dtype=torch.int64, device=feats.device)
+        lp = torch.zeros(B, max_len, dtype=torch.float32, device=feats.device)
+        check(lib().icz_butd_sample(self._h, ptr(feats), B, max_len, C.byref(rng), ptr(seq), ptr(lp), stream_ptr()))
+        self._live = (feats, rng, seq, lp)
+        return seq, lp
+
+    def sample_mask_sum(self):
+        out = torch.zeros(1, device=self.device)
+        check(lib().icz_butd_sample_mask_sum(self._h, ptr(out), stream_ptr()))
+        return out
+
+    def sample_backward(self, reward, grads, mask_sum_global=0.0):
+        """RewardCriterion + backward (Utils.py:295-317) for the last sample(); fills `grads`; returns
+        (loss, local mask sum) as 1-element device tensors."""
+        reward = reward.to(device=self.device, dtype=torch.float32).contiguous()
+        loss = torch.zeros(1, device=self.device)
+        msum = torch.zeros(1, device=self.device)
+        gs = self._grad_struct(grads)
+        check(lib().icz_butd_sample_backward(self._h, ptr(reward), C.byref(gs), ptr(loss), ptr(msum),
+                                             float(mask_sum_global), stream_ptr()))
+        return loss, msum
+
+    def xe_forward(self, feats, captions, lengths, rng=None, train=True, want_logits=False):
+        """DecoderRNN.forward (BUTD_Model.py:97-151).  lengths = caption lengths minus one (Engine.py:178),
+        sorted descending.  Returns packed logits (sum(lengths), V) if want_logits."""
+        feats = self._check_feats(feats)
+        B, L = captions.shape
+        captions = captions.to(device=feats.device, dtype=torch.int64).contiguous()
+        lens = (C.c_int32 * B)(*[int(x) for x in lengths])
+        out = torch.empty(sum(int(x) for x in lengths), self.V, device=feats.device) if want_logits else None
+        if train and rng is None:
+            rng = make_rng(0)
+        check(lib().icz_butd_xe_forward(self._h, ptr(feats), ptr(captions), B, L, lens,
+                                        C.byref(rng) if rng is not None else None, 1 if train else 0, ptr(out),
+                                        stream_ptr()))
+        self._live = (feats, rng, captions)
+        return out
+
+    def xe_backward(self, grads, smoothing=0.1, n_tokens_global=0.0):
+        """LabelSmoothingLoss + backward (Utils.py:268-286) for the last xe_forward(); returns the loss."""
+        loss = torch.zeros(1, device=self.device)
+        gs = self._grad_struct(grads)
+        check(lib().icz_butd_xe_backward(self._h, float(smoothing), C.byref(gs), ptr(loss), float(n_tokens_global),
+                                         stream_ptr()))
+        return loss
+
     def step(self, feats, it, h1, c1, h2, c2):
         """One decoder step from an explicit state (BUTD_Model.py:172-182); state tensors are updated in place.
         Returns (ctx, alpha, logits)."""
@@ -79,6 +143,22 @@ class ButdHandle:
         check(lib().icz_butd_step(self._h, ptr(feats), B, ptr(it), ptr(h1), ptr(c1), ptr(h2), ptr(c2), ptr(ctx),
                                   ptr(alpha), ptr(logits), stream_ptr()))
         return ctx, alpha, logits
+
+
+def make_rng(seed=0, uniforms=None, emb_mask=None, att_mask=None, out_mask=None):
+    """icz_rng: explicit arrays (uint8 keep-masks / fp32 uniforms on the device) or Philox from `seed` for None."""
+    r = Rng()
+    r.seed = int(seed) & 0xFFFFFFFFFFFFFFFF
+    keep = []
+    for name, t, dt in (("uniforms", uniforms, torch.float32), ("emb_mask", emb_mask, torch.uint8),
+                        ("att_mask", att_mask, torch.uint8), ("out_mask", out_mask, torch.uint8)):
+        if t is not None:
+            if t.dtype != dt or not t.is_cuda or not t.is_contiguous():
+                raise _lib.IczError("%s must be a contiguous %s CUDA tensor" % (name, dt))
+            setattr(r, name, t.data_ptr())
+            keep.append(t)
+    r._keep = keep
+    return r
 
 
 def gemm(layout, X, W, bias=None, nsplit=0):

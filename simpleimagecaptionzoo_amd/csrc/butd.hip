@@ -31,7 +31,9 @@ int Butd::init(const icz_butd_dims& d) {
     ICZ_TRY(alloc((void**)&w_enc, sizeof(float) * A * D));
     ICZ_TRY(alloc((void**)&w_dec, sizeof(float) * A * H));
     ICZ_TRY(alloc((void**)&w_aff, sizeof(float) * A));
-    ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * V * H));
+    const size_t Vp = (V + 3) & ~(size_t)3;     // padded rows stay zero: the dgrad GEMM reads K = Vp rows
+    ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * Vp * H));
+    ICZ_CHECK_HIP(hipMemset(w_pred, 0, sizeof(float) * Vp * H));
     ICZ_TRY(alloc((void**)&n_enc, sizeof(float) * A));
     ICZ_TRY(alloc((void**)&n_dec, sizeof(float) * A));
     ICZ_TRY(alloc((void**)&n_aff, sizeof(float) * 4));
@@ -183,7 +185,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {s.h2drop_out ? s.h2drop_out : h2drop, w_pred, H, H, H, nullptr};
-        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = V; g.bias = P.predict_b;
+        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : V; g.bias = P.predict_b;
         g.nsplit = 1;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     }

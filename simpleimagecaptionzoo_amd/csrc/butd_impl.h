@@ -24,11 +24,29 @@ struct StepIO {
     float* ctx_out;                  // [rows,D]
     float* h2drop_out;               // [rows,H]
     float* logits_out;               // [rows,V]
+    int logits_ld;                   // row stride of logits_out (0 = V)
     DropCfg drop_emb, drop_att, drop_out;
+};
+
+// Activations kept by a training-mode forward (slot t = time step, slot stride = B rows) and backward scratch.
+struct TrainBuf {
+    int B = 0, T = 0;
+    int64_t* tok = nullptr;                                   // [(T+1), B] input token of each step
+    float *emb = nullptr, *h1 = nullptr, *c1 = nullptr, *h2 = nullptr, *c2 = nullptr;   // states: [(T+1), B, H], slot 0 = zeros
+    float *gtd = nullptr, *glm = nullptr, *dec = nullptr, *alpha = nullptr, *ctx = nullptr, *h2d = nullptr, *logit = nullptr;
+    int32_t* draw = nullptr; float* lse = nullptr;
+    uint8_t* unf = nullptr; int* nunf = nullptr; float *coef = nullptr, *loss_rows = nullptr;
+    float *dGtd = nullptr, *dGlm = nullptr, *dDec = nullptr, *dEmb = nullptr, *dH2d = nullptr, *dEnc = nullptr;
+    float *dwaff = nullptr, *ddec_part = nullptr, *dalpha = nullptr, *dGsum = nullptr;
+    float *dc1[2] = {nullptr, nullptr}, *dc2[2] = {nullptr, nullptr};
+    float* X[4] = {nullptr, nullptr, nullptr, nullptr}; size_t xfloats = 0;
+    float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;
+    int* scalars_i = nullptr; int scalars_i_cap = 0;
 };
 
 struct Butd {
     static constexpr int TARGET_WGS = 512;   // ~2 workgroups per CU on 256 CUs
+    static constexpr int ATT_PARTS = 4;
     icz_butd_dims dims;
     icz_butd_params P;
     bool bound = false, fresh = false;
@@ -55,6 +73,28 @@ struct Butd {
     int step(const StepIO& s, hipStream_t st);
     int zero_state(int rows, int which, hipStream_t st);
     int greedy(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
+
+    // training paths (butd_train.hip)
+    TrainBuf tb;
+    icz_rng rng = {};
+    int mode = 0;                 // 0 none, 1 sample rollout stored, 2 XE forward stored
+    int cur_B = 0, cur_T = 0, cur_L = 0, n_tokens = 0;
+    bool cur_train = false;
+    const float* cur_feats = nullptr;
+    const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr; const int64_t* cur_captions = nullptr;
+    std::vector<int> rows_t;
+    int ensure_train(int B, int T);
+    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st);
+    int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_mask_sum(float* out, hipStream_t st);
+    int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,
+                        float mask_sum_global, hipStream_t st);
+    int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_rng* r,
+                   int train, float* packed_out, hipStream_t st);
+    int xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
+    int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
+    int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);
+    int bptt(const icz_butd_params& G, hipStream_t st);
 };
 
 }  // namespace icz

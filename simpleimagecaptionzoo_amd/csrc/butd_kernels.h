@@ -5,6 +5,7 @@
 #include "rng.h"
 
 namespace icz {
+namespace {   // internal linkage: this header is included by several translation units
 
 // ---------------------------------------------------------------------------------------------------------
 // weight_norm (old style, dim 0): w[r,:] = v[r,:] * g[r] / ||v[r,:]||   (:43-45, :84).  One wave per row.
@@ -265,4 +266,490 @@ __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     if (i < n) p[i] = v;
 }
 
+}  // namespace
+}  // namespace icz
+
+// =========================================================================================================
+// Training-mode kernels: multinomial epilogue, REINFORCE / XE loss gradients, BPTT pointwise parts.
+// =========================================================================================================
+namespace icz {
+namespace {   // internal linkage: this header is included by several translation units
+
+// block-wide helpers (256 threads)
+__device__ __forceinline__ float block_max_256(float v, float* sm) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum_256(float v, float* sm) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = (sm[0] + sm[1]) + (sm[2] + sm[3]);
+    __syncthreads();
+    return r;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// sample_rl epilogue (:221-233): logp = log_softmax(logits); draw ~ multinomial(exp(logp)) by inverse CDF
+// (smallest i with cumsum(p)[i] > u * sum(p), float64 -- the contract shared with the oracle); store logp[draw];
+// unfinished &= (draw != <end>); it = draw * unfinished.  A row block = one workgroup; each thread owns a
+// contiguous slice of the vocabulary so the global "first index above target" is the minimum over threads.
+// Steps after every row has finished are left zero, as the reference's early break does (:233).
+struct SampleSelArgs {
+    const float* logits; int V; int ldl;
+    const float* uniforms;        // [rows] for this step or null (Philox)
+    uint64_t seed; int t; int T;
+    uint8_t* unfinished;          // [rows] in/out
+    int* n_unfinished;            // [T] counters (zeroed before the rollout)
+    int64_t* seq_out; float* logp_out;   // [rows, T]
+    int64_t* it_next;             // [rows]
+    int32_t* draw_out;            // [rows] raw draw (for backward)
+    float* lse_out;               // [rows] max + log(sum exp) (for backward)
+};
+__global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
+    __shared__ float smf[4];
+    __shared__ double smd[256];
+    __shared__ int smi[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const bool dead = (a.t > 0) && (a.n_unfinished[a.t - 1] == 0);
+    if (dead) {
+        if (tid == 0) {
+            a.seq_out[(size_t)row * a.T + a.t] = 0;
+            a.logp_out[(size_t)row * a.T + a.t] = 0.f;
+            a.it_next[row] = 0;
+            a.draw_out[row] = -1;
+            a.lse_out[row] = 0.f;
+        }
+        return;
+    }
+    const float* l = a.logits + (size_t)row * a.ldl;
+    float mx = -INFINITY;
+    for (int v = tid; v < a.V; v += 256) mx = fmaxf(mx, l[v]);
+    mx = block_max_256(mx, smf);
+    float se = 0.f;
+    for (int v = tid; v < a.V; v += 256) se += expf(l[v] - mx);
+    se = block_sum_256(se, smf);
+    const float lse = logf(se);
+    // contiguous slice per thread
+    const int per = (a.V + 255) / 256;
+    const int v0 = tid * per, v1 = min(a.V, v0 + per);
+    double loc = 0.0;
+    for (int v = v0; v < v1; ++v) loc += (double)expf((l[v] - mx) - lse);
+    smd[tid] = loc;
+    __syncthreads();
+    // exclusive prefix by a single wave-free serial pass per thread is O(256^2); do a Hillis-Steele scan instead
+    for (int o = 1; o < 256; o <<= 1) {
+        double x = (tid >= o) ? smd[tid - o] : 0.0;
+        __syncthreads();
+        smd[tid] += x;
+        __syncthreads();
+    }
+    const double total = smd[255];
+    const double prefix = smd[tid] - loc;
+    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(a.seed, (uint32_t)a.t, (uint64_t)row);
+    const double target = (double)u * total;
+    int cand = 0x7fffffff;
+    {
+        double run = prefix;
+        for (int v = v0; v < v1; ++v) {
+            run += (double)expf((l[v] - mx) - lse);
+            if (run > target) { cand = v; break; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if ((tid & 63) == 0) smi[tid >> 6] = cand;
+    __syncthreads();
+    if (tid == 0) {
+        int d = min(min(smi[0], smi[1]), min(smi[2], smi[3]));
+        if (d > a.V - 1) d = a.V - 1;
+        const float lp = (l[d] - mx) - lse;
+        bool unf = a.unfinished[row] != 0;
+        unf = unf && (d != 2);
+        a.unfinished[row] = unf ? 1 : 0;
+        const int64_t itv = unf ? (int64_t)d : 0;
+        a.seq_out[(size_t)row * a.T + a.t] = itv;
+        a.logp_out[(size_t)row * a.T + a.t] = lp;
+        a.it_next[row] = itv;
+        a.draw_out[row] = d;
+        a.lse_out[row] = mx + lse;
+        if (unf) atomicAdd(&a.n_unfinished[a.t], 1);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// RewardCriterion (Utils.py:295-317): mask[b,0] = 1, mask[b,t] = (seq[b,t-1] > 0);
+//   loss = -sum(logp * reward * mask) / sum(mask).   One workgroup; also emits coef[b,t] = -reward*mask/denom
+// (= d loss / d logp) for the gradient kernel.  denom = mask_sum_global if > 0 else the local mask sum.
+__global__ __launch_bounds__(256) void reinforce_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ seq,
+                                                             const float* __restrict__ reward, int B, int T,
+                                                             float mask_sum_global, float* __restrict__ coef,
+                                                             float* __restrict__ loss_out, float* __restrict__ mask_sum_out) {
+    __shared__ float smf[4];
+    const int tid = threadIdx.x;
+    float ms = 0.f, ls = 0.f;
+    for (int i = tid; i < B * T; i += 256) {
+        const int t = i % T;
+        const float m = (t == 0) ? 1.f : (seq[i - 1] > 0 ? 1.f : 0.f);
+        ms += m;
+        ls += -logp[i] * reward[i] * m;
+    }
+    ms = block_sum_256(ms, smf);
+    ls = block_sum_256(ls, smf);
+    const float denom = mask_sum_global > 0.f ? mask_sum_global : ms;
+    for (int i = tid; i < B * T; i += 256) {
+        const int t = i % T;
+        const float m = (t == 0) ? 1.f : (seq[i - 1] > 0 ? 1.f : 0.f);
+        coef[i] = -reward[i] * m / denom;
+    }
+    if (tid == 0) {
+        if (loss_out) loss_out[0] = ls / denom;
+        if (mask_sum_out) mask_sum_out[0] = ms;
+    }
+}
+
+// d loss / d logits for the whole rollout (row = t*B + b):
+//   dlogits[row,v] = coef[b,t] * (1[v == draw] - softmax(logits)[v])         (log_softmax + gather backward)
+// Written in place over the saved logits; pad columns [V, ldl) are zeroed.
+__global__ __launch_bounds__(256) void reinforce_dlogits_kernel(float* __restrict__ logits, int V, int ldl,
+                                                                const int32_t* __restrict__ draw, const float* __restrict__ lse,
+                                                                const float* __restrict__ coef, int B, int T) {
+    const int row = blockIdx.y;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= ldl) return;
+    const int t = row / B, b = row % B;
+    float* l = logits + (size_t)row * ldl;
+    const float c = coef[(size_t)b * T + t];
+    const int d = draw[row];
+    float g = 0.f;
+    if (v < V && d >= 0 && c != 0.f) g = c * ((v == d ? 1.f : 0.f) - expf(l[v] - lse[row]));
+    l[v] = g;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LabelSmoothingLoss (Utils.py:268-286) on one time step of the XE forward (rows = rows active at t):
+//   loss_row = sum_v true_v (log true_v - logp_v),  true = 1-s at the target, s/(V-1) elsewhere
+//   dlogits  = (softmax - true) / N_tokens          (KLDiv(log_softmax) backward)
+// One workgroup per row; per-row loss goes to loss_rows (summed later in fixed order).
+__global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict__ logits, int V, int ldl,
+                                                              const int64_t* __restrict__ target, int tgt_stride,
+                                                              float smoothing, float inv_n, float* __restrict__ loss_rows) {
+    __shared__ float smf[4];
+    const int row = blockIdx.x, tid = threadIdx.x;
+    float* l = logits + (size_t)row * ldl;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, l[v]);
+    mx = block_max_256(mx, smf);
+    float se = 0.f;
+    for (int v = tid; v < V; v += 256) se += expf(l[v] - mx);
+    se = block_sum_256(se, smf);
+    const float lse = mx + logf(se);
+    const int tg = (int)target[(size_t)row * tgt_stride];
+    const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
+    const float lconf = conf > 0.f ? logf(conf) : 0.f, llow = low > 0.f ? logf(low) : 0.f;
+    float ls = 0.f;
+    for (int v = tid; v < ldl; v += 256) {
+        float g = 0.f;
+        if (v < V) {
+            const float lp = l[v] - lse;
+            const float tr = (v == tg) ? conf : low;
+            if (tr > 0.f) ls += tr * (((v == tg) ? lconf : llow) - lp);
+            g = (expf(lp) - tr) * inv_n;
+        }
+        l[v] = g;
+    }
+    ls = block_sum_256(ls, smf);
+    if (tid == 0) loss_rows[row] = ls;
+}
+
+// sum of n floats in fixed order by one workgroup, scaled
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+    __shared__ float smf[4];
+    float s = 0.f;
+    for (int i = threadIdx.x; i < n; i += 256) s += x[i];
+    s = block_sum_256(s, smf);
+    if (threadIdx.x == 0) out[0] = s * scale;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// LSTMCell backward, pointwise part.  dh = sum of up to three slab sets (+ optional dropped-output term),
+// dc = dc_in (optional).  Emits d(pre-activation gates) [rows,4H] and dc_prev.
+struct LstmBwdArgs {
+    const float* dh_a; int ns_a;      // slabs [ns][rows][lda_a] read at column offset 0..H
+    int lda_a;
+    const float* dh_b; int ns_b; int lda_b;
+    const float* dh_c; int ns_c; int lda_c;
+    const float* dhdrop;              // [rows,H] gradient w.r.t. the dropped copy of h (predict input) or null
+    const float* dc_in;               // [rows,H] or null
+    const float* gates;               // [rows,4H] activated i,f,g,o
+    const float* c_prev;              // [rows,H] or null (= zeros)
+    const float* c_cur;               // [rows,H]
+    float* dgates;                    // [rows,4H]
+    float* dc_prev;                   // [rows,H]
+    int rows, H;
+    int rows_a, rows_b, rows_c;       // row counts of the slab sets (slab stride = rows_x * lda_x)
+    int dc_in_rows;                   // valid rows of dc_in
+};
+__device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_stride, size_t off) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (!p) return s;
+    s = *reinterpret_cast<const f32x4*>(p + off);
+    for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * slab_stride + off);
+    return s;
+}
+__global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, DropCfg dc) {
+    const int row = blockIdx.y;
+    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (j >= a.H) return;
+    const int H = a.H, G = 4 * H;
+    // a slab set only holds rows_x rows (XE: the batch shrinks with t); rows beyond contribute zero
+    f32x4 dh = {0.f, 0.f, 0.f, 0.f};
+    if (row < a.rows_a) dh += sum_slabs4(a.dh_a, a.ns_a, (size_t)a.rows_a * a.lda_a, (size_t)row * a.lda_a + j);
+    if (row < a.rows_b) dh += sum_slabs4(a.dh_b, a.ns_b, (size_t)a.rows_b * a.lda_b, (size_t)row * a.lda_b + j);
+    if (row < a.rows_c) dh += sum_slabs4(a.dh_c, a.ns_c, (size_t)a.rows_c * a.lda_c, (size_t)row * a.lda_c + j);
+    if (a.dhdrop) {
+        f32x4 d = *reinterpret_cast<const f32x4*>(a.dhdrop + (size_t)row * H + j);
+        if (dc.mode) {
+            uint32_t k = dc.keep4((uint64_t)row * H + j);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d[e] = ((k >> e) & 1u) ? d[e] * 2.0f : 0.f;
+        }
+        dh += d;
+    }
+    const float* g = a.gates + (size_t)row * G + j;
+    const f32x4 gi = *reinterpret_cast<const f32x4*>(g), gf = *reinterpret_cast<const f32x4*>(g + H);
+    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 2 * H), go = *reinterpret_cast<const f32x4*>(g + 3 * H);
+    const f32x4 cc = *reinterpret_cast<const f32x4*>(a.c_cur + (size_t)row * H + j);
+    f32x4 cp = {0.f, 0.f, 0.f, 0.f}, dcin = {0.f, 0.f, 0.f, 0.f};
+    if (a.c_prev) cp = *reinterpret_cast<const f32x4*>(a.c_prev + (size_t)row * H + j);
+    if (a.dc_in && row < a.dc_in_rows) dcin = *reinterpret_cast<const f32x4*>(a.dc_in + (size_t)row * H + j);
+    f32x4 dai, daf, dag, dao, dcp;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float tc = tanhf(cc[e]);
+        const float dcv = dcin[e] + dh[e] * go[e] * (1.f - tc * tc);
+        dao[e] = dh[e] * tc * go[e] * (1.f - go[e]);
+        dai[e] = dcv * gg[e] * gi[e] * (1.f - gi[e]);
+        daf[e] = dcv * cp[e] * gf[e] * (1.f - gf[e]);
+        dag[e] = dcv * gi[e] * (1.f - gg[e] * gg[e]);
+        dcp[e] = dcv * gf[e];
+    }
+    float* o = a.dgates + (size_t)row * G + j;
+    *reinterpret_cast<f32x4*>(o) = dai;
+    *reinterpret_cast<f32x4*>(o + H) = daf;
+    *reinterpret_cast<f32x4*>(o + 2 * H) = dag;
+    *reinterpret_cast<f32x4*>(o + 3 * H) = dao;
+    *reinterpret_cast<f32x4*>(a.dc_prev + (size_t)row * H + j) = dcp;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// SoftAttention backward, part 1:  dalpha[row,r] = dctx[row,:] . feats[img,r,:]   (one wave per (row, r))
+// dctx = sum of slabs [ns][rows][ldc] columns 0..D (the LM-LSTM dgrad GEMM output).
+__global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __restrict__ dctx, int ns, int ldc, int rows,
+                                                             const float* __restrict__ feats, int R, int D,
+                                                             float* __restrict__ dalpha) {
+    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t ss = (size_t)rows * ldc;
+    for (int r = blockIdx.y * 4 + wave; r < R; r += 4 * gridDim.y) {
+        const float* f = feats + ((size_t)row * R + r) * D;
+        float acc = 0.f;
+        for (int c = lane * 4; c < D; c += 256) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
+            f32x4 g = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+            acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) dalpha[(size_t)row * R + r] = acc;
+    }
+}
+
+// SoftAttention backward, part 2 (grid (rows, parts)):
+//   ds_r = alpha_r (dalpha_r - sum_r' alpha_r' dalpha_r')                       softmax backward
+//   zpre = enc_ctx[row,r,a] + dec_ctx[row,a];  keep = dropout keep-bit
+//   dz   = (zpre > 0 && keep) ? ds_r * w_aff[a] * scale : 0                     relu + dropout + affine backward
+//   denc_acc[row,r,a] += dz                     (accumulated over time steps: enc_ctx is shared by all steps)
+//   ddec_part[part,row,a] = sum_{r in part} dz  (slabs over parts; summed by the consumer)
+//   dwaff_acc[row,part,a] += sum_{r in part} ds_r * relu(zpre)*keep*scale      (reduced over rows/parts at the end)
+struct AttBwdArgs {
+    const float* enc_ctx; const float* dec_ctx; const float* w_aff;
+    const float* alpha; const float* dalpha;
+    float* denc_acc; float* ddec_part; float* dwaff_acc;
+    int rows, R, A; int first;     // first != 0: dwaff_acc / denc_acc are overwritten instead of accumulated
+};
+__global__ __launch_bounds__(256) void att_bwd_kernel(AttBwdArgs a, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][A] dd partials, [4][A] dw partials
+    const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // softmax backward scalars (every wave redundantly; R <= 64)
+    const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
+    const float da = lane < a.R ? a.dalpha[(size_t)row * a.R + lane] : 0.f;
+    const float dot = wave_sum(al * da);
+    const float ds_l = al * (da - dot);
+    float* sdd = sm + (size_t)wave * a.A;
+    float* sdw = sm + (size_t)(4 + wave) * a.A;
+    for (int c = lane * 4; c < a.A; c += 256) {
+        *reinterpret_cast<f32x4*>(sdd + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(sdw + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
+    }
+    const int per = (a.R + nparts - 1) / nparts;
+    const int r_end = min(a.R, (part + 1) * per);
+    const float sc = dc.mode ? 2.0f : 1.0f;
+    for (int r = part * per + wave; r < r_end; r += 4) {
+        const float ds = __shfl(ds_l, r, 64);
+        const size_t eoff = ((size_t)row * a.R + r) * a.A;
+        for (int c = lane * 4; c < a.A; c += 256) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(a.enc_ctx + eoff + c);
+            f32x4 d = *reinterpret_cast<const f32x4*>(a.dec_ctx + (size_t)row * a.A + c);
+            f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+            uint32_t k = dc.mode ? dc.keep4(eoff + c) : 0xFu;
+            f32x4 dz, zz;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float zp = x[j] + d[j];
+                const bool on = (zp > 0.f) && ((k >> j) & 1u);
+                dz[j] = on ? ds * w[j] * sc : 0.f;
+                zz[j] = on ? zp * sc * ds : 0.f;
+            }
+            f32x4* de = reinterpret_cast<f32x4*>(a.denc_acc + eoff + c);
+            *de = a.first ? dz : (*de + dz);
+            *reinterpret_cast<f32x4*>(sdd + c) += dz;
+            *reinterpret_cast<f32x4*>(sdw + c) += zz;
+        }
+    }
+    __syncthreads();
+    for (int c = tid * 4; c < a.A; c += 1024) {
+        f32x4 dd = *reinterpret_cast<f32x4*>(sm + c);
+        f32x4 dw = *reinterpret_cast<f32x4*>(sm + (size_t)4 * a.A + c);
+#pragma unroll
+        for (int w = 1; w < 4; ++w) {
+            dd += *reinterpret_cast<f32x4*>(sm + (size_t)w * a.A + c);
+            dw += *reinterpret_cast<f32x4*>(sm + (size_t)(4 + w) * a.A + c);
+        }
+        *reinterpret_cast<f32x4*>(a.ddec_part + ((size_t)part * a.rows + row) * a.A + c) = dd;
+        f32x4* wa = reinterpret_cast<f32x4*>(a.dwaff_acc + ((size_t)row * nparts + part) * a.A + c);
+        *wa = a.first ? dw : (*wa + dw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// out[n] = sum_k X[k, n] (column sums over K rows; bias gradients).  Fixed order -> reproducible.
+// grid.x covers N in chunks of 256 columns; blockDim 256; each thread owns a column and 4 row-lanes are not
+// needed: K is a few thousand at most.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int K, int N, int ldx, float* __restrict__ out) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += X[(size_t)k * ldx + n];
+    out[n] = s;
+}
+
+// out[b, n] = sum_t X[t, b, n]   (time sum of the TD gate gradients for the hoisted mean-feature weights)
+__global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ X, int T, size_t BN, float* __restrict__ out) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= BN) return;
+    f32x4 s = *reinterpret_cast<const f32x4*>(X + i);
+    for (int t = 1; t < T; ++t) s += *reinterpret_cast<const f32x4*>(X + (size_t)t * BN + i);
+    *reinterpret_cast<f32x4*>(out + i) = s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Embedding gradient (Embedding -> ReLU -> Dropout backward), one workgroup per vocabulary row:
+//   dE[v,:] = sum over (t,b) with tok[t,b] == v of demb[t,b,:] * (emb[t,b,:] > 0 ? scale : 0)
+// No atomics: the (t,b) list is scanned in fixed order, rows without occurrences are written as zeros.
+__global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, int n_tok,
+                                                         const float* __restrict__ demb, int ns, size_t slab_stride,
+                                                         const float* __restrict__ emb, float scale, int E,
+                                                         float* __restrict__ dE) {
+    extern __shared__ int hits[];     // indices of matching (t,b) entries, capacity n_tok
+    __shared__ int nhit;
+    const int v = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) nhit = 0;
+    __syncthreads();
+    // ordered compaction: each thread scans a contiguous slice, then slices are concatenated in order
+    const int per = (n_tok + 255) / 256;
+    const int i0 = tid * per, i1 = min(n_tok, i0 + per);
+    int cnt = 0;
+    for (int i = i0; i < i1; ++i) cnt += (tok[i] == v);
+    __shared__ int offs[257];
+    offs[tid + 1] = cnt;
+    if (tid == 0) offs[0] = 0;
+    __syncthreads();
+    if (tid == 0) {
+        for (int i = 0; i < 256; ++i) offs[i + 1] += offs[i];
+        nhit = offs[256];
+    }
+    __syncthreads();
+    int o = offs[tid];
+    for (int i = i0; i < i1; ++i)
+        if (tok[i] == v) hits[o++] = i;
+    __syncthreads();
+    const int nh = nhit;
+    for (int e = tid * 4; e < E; e += 1024) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int h = 0; h < nh; ++h) {
+            const size_t off = (size_t)hits[h] * E + e;
+            f32x4 g = sum_slabs4(demb, ns, slab_stride, off);
+            f32x4 x = *reinterpret_cast<const f32x4*>(emb + off);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s[j] += x[j] > 0.f ? g[j] * scale : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e) = s;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// weight_norm backward (one wave per row):  w = g v / ||v||
+//   dg[r] = dw[r,:] . v[r,:] / ||v||;   dv[r,:] = (g/||v||) (dw[r,:] - (dg/||v||) v[r,:])
+__global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __restrict__ dw, int lddw, const float* __restrict__ v,
+                                                              const float* __restrict__ g, const float* __restrict__ norm,
+                                                              float* __restrict__ dv, float* __restrict__ dg, int rows, int cols) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* vr = v + (size_t)row * cols;
+    const float* dr = dw + (size_t)row * lddw;
+    float dot = 0.f;
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+        dot += x[0] * d[0] + x[1] * d[1] + x[2] * d[2] + x[3] * d[3];
+    }
+    dot = wave_sum(dot);
+    const float nrm = norm[row];
+    const float dgv = dot / nrm;
+    const float s = g[row] / nrm;
+    float* o = dv + (size_t)row * cols;
+    for (int c = lane * 4; c < cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+        *reinterpret_cast<f32x4*>(o + c) = (d - x * (dgv / nrm)) * s;
+    }
+    if (lane == 0) dg[row] = dgv;
+}
+
+// out[a] = sum_i X[i, a]  for the affine weight gradient partials (rows*parts, A) -> (A)
+// (same as colsum; kept separate for clarity of the call sites)
+
+// ---------------------------------------------------------------------------------------------------------
+// clip_gradient (Utils.py:241-250) + Adam (Utils.py:219-220) fused, elementwise.
+__global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                         float* __restrict__ v, size_t n, float lr, float clip, float bc1,
+                                                         float sqrt_bc2) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    float gv = fminf(fmaxf(g[i], -clip), clip);
+    const float mn = m[i] * b1 + gv * (1.f - b1);
+    const float vn = v[i] * b2 + (gv * gv) * (1.f - b2);
+    m[i] = mn;
+    v[i] = vn;
+    const float denom = sqrtf(vn) / sqrt_bc2 + eps;
+    p[i] = p[i] - (lr / bc1) * (mn / denom);
+}
+
+}  // namespace
 }  // namespace icz

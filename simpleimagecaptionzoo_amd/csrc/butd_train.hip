@@ -1,0 +1,472 @@
+// BUTD training paths: sample_rl rollout + REINFORCE backward, teacher-forced XE forward + backward.
+// Both share one BPTT (Butd::bptt): per-step dgrad GEMMs (NN) and pointwise kernels run sequentially in
+// reverse time; every weight gradient is one batched GEMM (TN) over all (time, row) pairs at the end.
+#include <math.h>
+
+#include "butd_impl.h"
+
+namespace icz {
+
+static inline int round4(int x) { return (x + 3) & ~3; }
+
+int Butd::ensure_train(int B, int T) {
+    if (tb.B >= B && tb.T >= T) return ICZ_OK;
+    ICZ_REQUIRE(B <= dims.max_rows, "butd: batch %d exceeds capacity %d", B, dims.max_rows);
+    ICZ_REQUIRE(T <= dims.max_len, "butd: %d steps exceed max_len %d", T, dims.max_len);
+    // allocate once for the handle's full capacity
+    B = dims.max_rows;
+    T = dims.max_len;
+    const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
+    const size_t Vp = round4(dims.V);
+    const size_t TB = (size_t)T * B;
+    auto zalloc = [&](void** p, size_t bytes) -> int {
+        ICZ_TRY(alloc(p, bytes));
+        ICZ_CHECK_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+        return ICZ_OK;
+    };
+    ICZ_TRY(zalloc((void**)&tb.tok, sizeof(int64_t) * (TB + B)));
+    ICZ_TRY(zalloc((void**)&tb.emb, sizeof(float) * TB * E));
+    ICZ_TRY(zalloc((void**)&tb.h1, sizeof(float) * (TB + B) * H));
+    ICZ_TRY(zalloc((void**)&tb.c1, sizeof(float) * (TB + B) * H));
+    ICZ_TRY(zalloc((void**)&tb.h2, sizeof(float) * (TB + B) * H));
+    ICZ_TRY(zalloc((void**)&tb.c2, sizeof(float) * (TB + B) * H));
+    ICZ_TRY(zalloc((void**)&tb.gtd, sizeof(float) * TB * 4 * H));
+    ICZ_TRY(zalloc((void**)&tb.glm, sizeof(float) * TB * 4 * H));
+    ICZ_TRY(zalloc((void**)&tb.dec, sizeof(float) * TB * A));
+    ICZ_TRY(zalloc((void**)&tb.alpha, sizeof(float) * TB * R));
+    ICZ_TRY(zalloc((void**)&tb.ctx, sizeof(float) * TB * D));
+    ICZ_TRY(zalloc((void**)&tb.h2d, sizeof(float) * TB * H));
+    ICZ_TRY(zalloc((void**)&tb.logit, sizeof(float) * TB * Vp));
+    ICZ_TRY(zalloc((void**)&tb.draw, sizeof(int32_t) * TB));
+    ICZ_TRY(zalloc((void**)&tb.lse, sizeof(float) * TB));
+    ICZ_TRY(zalloc((void**)&tb.unf, B));
+    ICZ_TRY(zalloc((void**)&tb.nunf, sizeof(int) * T));
+    ICZ_TRY(zalloc((void**)&tb.coef, sizeof(float) * TB));
+    ICZ_TRY(zalloc((void**)&tb.loss_rows, sizeof(float) * TB));
+    ICZ_TRY(zalloc((void**)&tb.dGtd, sizeof(float) * TB * 4 * H));
+    ICZ_TRY(zalloc((void**)&tb.dGlm, sizeof(float) * TB * 4 * H));
+    ICZ_TRY(zalloc((void**)&tb.dDec, sizeof(float) * TB * A));
+    ICZ_TRY(zalloc((void**)&tb.dEmb, sizeof(float) * TB * E));
+    ICZ_TRY(zalloc((void**)&tb.dH2d, sizeof(float) * TB * H));
+    ICZ_TRY(zalloc((void**)&tb.dEnc, sizeof(float) * (size_t)B * R * A));
+    ICZ_TRY(zalloc((void**)&tb.dwaff, sizeof(float) * (size_t)B * ATT_PARTS * A));
+    ICZ_TRY(zalloc((void**)&tb.ddec_part, sizeof(float) * (size_t)B * ATT_PARTS * A));
+    ICZ_TRY(zalloc((void**)&tb.dalpha, sizeof(float) * (size_t)B * R));
+    ICZ_TRY(zalloc((void**)&tb.dGsum, sizeof(float) * (size_t)B * 4 * H));
+    for (int i = 0; i < 2; ++i) {
+        ICZ_TRY(zalloc((void**)&tb.dc1[i], sizeof(float) * (size_t)B * H));
+        ICZ_TRY(zalloc((void**)&tb.dc2[i], sizeof(float) * (size_t)B * H));
+    }
+    tb.xfloats = (size_t)TARGET_WGS * 4096 * 2 + (size_t)B * (D + H);
+    for (int i = 0; i < 4; ++i) ICZ_TRY(zalloc((void**)&tb.X[i], sizeof(float) * tb.xfloats));
+    ICZ_TRY(zalloc((void**)&tb.dWp, sizeof(float) * Vp * H));
+    ICZ_TRY(zalloc((void**)&tb.dWenc, sizeof(float) * A * D));
+    ICZ_TRY(zalloc((void**)&tb.dWdec, sizeof(float) * A * H));
+    ICZ_TRY(zalloc((void**)&tb.dWaff, sizeof(float) * A));
+    ICZ_TRY(zalloc((void**)&tb.scalars, sizeof(float) * 16));
+    (void)V;
+    tb.B = B;
+    tb.T = T;
+    return ICZ_OK;
+}
+
+static DropCfg make_drop(const icz_rng& r, bool train, const uint8_t* base, size_t per_step, uint32_t stream, int t) {
+    DropCfg d = {0, nullptr, r.seed, stream, (uint32_t)t};
+    if (!train) return d;
+    if (base) { d.mode = 1; d.mask = base + per_step * t; }
+    else d.mode = 2;
+    return d;
+}
+
+// ------------------------------------------------------------------------------------------------
+// forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
+int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st) {
+    const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
+    const size_t Vp = round4(dims.V);
+    const size_t slot = (size_t)t * Bs;
+    StepIO s = {};
+    s.rows = rows; s.feats = feats; s.it = tb.tok + slot;
+    s.h1_in = tb.h1 + slot * H; s.c1_in = tb.c1 + slot * H; s.h2_in = tb.h2 + slot * H; s.c2_in = tb.c2 + slot * H;
+    s.h1_out = tb.h1 + (slot + Bs) * H; s.c1_out = tb.c1 + (slot + Bs) * H;
+    s.h2_out = tb.h2 + (slot + Bs) * H; s.c2_out = tb.c2 + (slot + Bs) * H;
+    s.emb_out = tb.emb + slot * E;
+    s.gates_td_out = tb.gtd + slot * 4 * H; s.gates_lm_out = tb.glm + slot * 4 * H;
+    s.dec_ctx_out = tb.dec + slot * A; s.alpha_out = tb.alpha + slot * R; s.ctx_out = tb.ctx + slot * D;
+    s.h2drop_out = tb.h2d + slot * H; s.logits_out = tb.logit + slot * Vp; s.logits_ld = (int)Vp;
+    s.drop_emb = make_drop(rng, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
+    s.drop_att = make_drop(rng, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
+    s.drop_out = make_drop(rng, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
+    return step(s, st);
+}
+
+int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && seq_out && logp_out && r, "butd sample: null argument");
+    ICZ_REQUIRE(B > 0 && T > 0, "butd sample: bad B/T");
+    ICZ_TRY(ensure_train(B, T));
+    rng = *r;
+    mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats;
+    rows_t.assign(T, B);
+    const size_t H = dims.H;
+    const size_t Vp = round4(dims.V);
+    ICZ_TRY(prologue(feats, B, st));
+    // slot 0 of the state buffers = zeros (they are only ever written from slot 1 on, but an XE call with a larger
+    // stride may have written there)
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.h1, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.c1, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.h2, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.c2, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.unf, 1, B, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.nunf, 0, sizeof(int) * T, st));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, tb.tok, (int64_t)1, B);
+    for (int t = 0; t < T; ++t) {
+        ICZ_TRY(train_step(feats, B, B, t, true, st));
+        SampleSelArgs a = {};
+        a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
+        a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
+        a.seed = rng.seed; a.t = t; a.T = T;
+        a.unfinished = tb.unf; a.n_unfinished = tb.nunf;
+        a.seq_out = seq_out; a.logp_out = logp_out;
+        a.it_next = tb.tok + (size_t)(t + 1) * B;
+        a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
+        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), 0, st, a);
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    cur_seq = seq_out; cur_logp = logp_out;
+    return ICZ_OK;
+}
+
+int Butd::sample_mask_sum(float* out, hipStream_t st) {
+    ICZ_REQUIRE(mode == 1, "butd: no rollout stored (call icz_butd_sample first)");
+    ICZ_REQUIRE(out, "null output");
+    // reuse the loss kernel with zero reward (coef scratch is overwritten later by backward)
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.loss_rows, 0, sizeof(float) * cur_B * cur_T, st));
+    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, tb.loss_rows, cur_B, cur_T,
+                       0.f, tb.coef, (float*)nullptr, out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,
+                          float mask_sum_global, hipStream_t st) {
+    ICZ_REQUIRE(mode == 1, "butd: no rollout stored (call icz_butd_sample first)");
+    ICZ_REQUIRE(reward && G, "butd sample_backward: null argument");
+    const int B = cur_B, T = cur_T;
+    const int Vp = round4(dims.V);
+    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, mask_sum_global,
+                       tb.coef, loss_out, mask_sum_out);
+    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
+                       tb.draw, tb.lse, tb.coef, B, T);
+    ICZ_CHECK_HIP(hipGetLastError());
+    mode = 0;   // the saved logits are consumed
+    return bptt(*G, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void captions_to_tok_kernel(const int64_t* __restrict__ cap, int B, int L, int T, int64_t* __restrict__ tok) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;   // i = t*B + b
+    if (i >= T * B) return;
+    int t = i / B, b = i % B;
+    tok[i] = cap[(size_t)b * L + t];
+}
+__global__ void gather_packed_kernel(const float* __restrict__ logit, int V, int ldl, int B, const int* __restrict__ row_off,
+                                     const int* __restrict__ rows_t, int T, float* __restrict__ out) {
+    // grid (V/256, T*B): copy logits of active (t,b) to packed row row_off[t] + b
+    const int tb_ = blockIdx.y, t = tb_ / B, b = tb_ % B;
+    if (b >= rows_t[t]) return;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= V) return;
+    out[(size_t)(row_off[t] + b) * V + v] = logit[(size_t)tb_ * ldl + v];
+}
+
+int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_rng* r,
+                     int train, float* packed_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && captions && lengths && B > 0 && L > 1, "butd xe_forward: bad arguments");
+    int T = 0;
+    for (int b = 0; b < B; ++b) {
+        ICZ_REQUIRE(lengths[b] >= 1 && lengths[b] <= L - 1, "butd xe_forward: length %d out of range 1..%d", lengths[b], L - 1);
+        ICZ_REQUIRE(b == 0 || lengths[b] <= lengths[b - 1], "butd xe_forward: lengths must be sorted in decreasing order (Engine.py:179)");
+        if (lengths[b] > T) T = lengths[b];
+    }
+    ICZ_TRY(ensure_train(B, T));
+    if (r) rng = *r; else { rng = {}; }
+    ICZ_REQUIRE(!train || r, "butd xe_forward: training mode needs an icz_rng");
+    mode = 2; cur_B = B; cur_T = T; cur_train = train != 0; cur_feats = feats;
+    rows_t.assign(T, 0);
+    n_tokens = 0;
+    for (int t = 0; t < T; ++t) {
+        int c = 0;
+        for (int b = 0; b < B; ++b) c += lengths[b] > t;
+        rows_t[t] = c;
+        n_tokens += c;
+    }
+    const size_t H = dims.H;
+    const size_t Vp = round4(dims.V);
+    ICZ_TRY(prologue(feats, B, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.h1, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.c1, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.h2, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.c2, 0, sizeof(float) * B * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.logit, 0, sizeof(float) * (size_t)T * B * Vp, st));
+    hipLaunchKernelGGL(captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tb.tok);
+    cur_captions = captions; cur_L = L;
+    for (int t = 0; t < T; ++t) ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
+    if (packed_out) {
+        std::vector<int> off(T), rt(T);
+        int acc = 0;
+        for (int t = 0; t < T; ++t) { off[t] = acc; rt[t] = rows_t[t]; acc += rows_t[t]; }
+        int* d_off = (int*)tb.scalars_i;
+        if (!tb.scalars_i || tb.scalars_i_cap < 2 * T) {
+            ICZ_TRY(alloc((void**)&tb.scalars_i, sizeof(int) * 2 * dims.max_len));
+            tb.scalars_i_cap = 2 * dims.max_len;
+            d_off = (int*)tb.scalars_i;
+        }
+        ICZ_CHECK_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
+        ICZ_CHECK_HIP(hipMemcpyAsync(d_off + T, rt.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
+        ICZ_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
+        hipLaunchKernelGGL(gather_packed_kernel, dim3(cdiv(dims.V, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, (int)Vp, B,
+                           d_off, d_off + T, T, packed_out);
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st) {
+    ICZ_REQUIRE(mode == 2, "butd: no XE forward stored (call icz_butd_xe_forward first)");
+    ICZ_REQUIRE(G, "butd xe_backward: null grads");
+    const int B = cur_B, T = cur_T;
+    const int Vp = round4(dims.V);
+    const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.loss_rows, 0, sizeof(float) * T * B, st));
+    for (int t = 0; t < T; ++t) {
+        // targets: captions[b, t+1]
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(rows_t[t]), dim3(256), 0, st, tb.logit + (size_t)t * B * Vp, dims.V, Vp,
+                           cur_captions + (t + 1), cur_L, smoothing, 1.0f / n, tb.loss_rows + (size_t)t * B);
+    }
+    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, loss_out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    mode = 0;
+    return bptt(*G, st);
+}
+
+// ------------------------------------------------------------------------------------------------
+// helpers for the backward GEMMs
+int Butd::gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st) {
+    // direct output (nsplit 1) if there are already enough tiles, else slabs
+    g.nsplit = gemm_pick_split(g, TARGET_WGS);
+    if (g.nsplit > 1) {
+        ICZ_REQUIRE(slab && gemm_slab_floats(g.M, g.N, g.nsplit) <= slab_floats, "butd: slab buffer too small (%d x %d x %d)", g.nsplit, g.M, g.N);
+        g.out = slab; g.ldo = g.N; g.bias = nullptr; g.accumulate = 0;
+    }
+    if (ns_out) *ns_out = g.nsplit;
+    return gemm_f32(layout, g, st);
+}
+
+// C (ldc) = A^T B over K rows, written directly (no split): weight gradients
+int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st) {
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {dY, X, ldy, ldx, K, nullptr};
+    g.M = M; g.N = N; g.out = out; g.ldo = ldo; g.nsplit = 1;
+    return gemm_f32(GEMM_TN, g, st);
+}
+
+int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
+    const int B = cur_B, T = cur_T;
+    const int H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
+    const int Vp = round4(V);
+    const int TB = T * B;
+    const float* feats = cur_feats;
+    const size_t sH = (size_t)B * H;
+
+    // ---- predict layer, all time steps at once
+    {
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {tb.logit, w_pred, Vp, H, Vp, nullptr};
+        g.M = TB; g.N = H; g.out = tb.dH2d; g.ldo = H;
+        int ns;
+        ICZ_TRY(gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st));
+        if (ns > 1) {
+            size_t MN = (size_t)TB * H;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, H, (const float*)nullptr, tb.dH2d);
+        }
+        ICZ_TRY(wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, st));
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, tb.logit, TB, V, Vp, G.predict_b);
+        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
+                           G.predict_v, G.predict_g, V, H);
+    }
+    // ---- zero the accumulators / inactive rows
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.dGtd, 0, sizeof(float) * (size_t)TB * 4 * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.dGlm, 0, sizeof(float) * (size_t)TB * 4 * H, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.dDec, 0, sizeof(float) * (size_t)TB * A, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.dEnc, 0, sizeof(float) * (size_t)B * R * A, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tb.dwaff, 0, sizeof(float) * (size_t)B * ATT_PARTS * A, st));
+
+    // ---- reverse-time loop
+    int cur = 0;
+    int ns1 = 1, ns2 = 1, ns3 = 1, ns4 = 1;
+    int bnext = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const int bt = rows_t[t];
+        const size_t slot = (size_t)t * B;
+        DropCfg d_out = make_drop(rng, cur_train, rng.out_mask, (size_t)B * H, RNG_OUT, t);
+        DropCfg d_att = make_drop(rng, cur_train, rng.att_mask, (size_t)B * R * A, RNG_ATT, t);
+        DropCfg d_off = {0, nullptr, 0, 0, 0};
+        {   // language LSTM backward (pointwise)
+            LstmBwdArgs a = {};
+            a.dh_a = bnext ? tb.X[2] : nullptr; a.ns_a = ns3; a.lda_a = H; a.rows_a = bnext;
+            a.dhdrop = tb.dH2d + slot * H;
+            a.dc_in = bnext ? tb.dc2[cur] : nullptr; a.dc_in_rows = bnext;
+            a.gates = tb.glm + slot * 4 * H;
+            a.c_prev = tb.c2 + slot * H; a.c_cur = tb.c2 + slot * H + sH;
+            a.dgates = tb.dGlm + slot * 4 * H; a.dc_prev = tb.dc2[cur ^ 1];
+            a.rows = bt; a.H = H;
+            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 1024), bt), dim3(256), 0, st, a, d_out);
+        }
+        {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
+            GemmArgs g = {};
+            g.nseg = 1;
+            g.seg[0] = {tb.dGlm + slot * 4 * H, P.lm_w_ih, 4 * H, D + H, 4 * H, nullptr};
+            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H;
+            ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
+        }
+        {   // attention backward
+            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, 3), dim3(256), 0, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
+            AttBwdArgs a = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dEnc, tb.ddec_part, tb.dwaff,
+                            bt, R, A, 0};
+            hipLaunchKernelGGL(att_bwd_kernel, dim3(bt, ATT_PARTS), dim3(256), sizeof(float) * 8 * A, st, a, d_att);
+            size_t MN = (size_t)bt * A;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, tb.ddec_part, ATT_PARTS, MN, A,
+                               (const float*)nullptr, tb.dDec + slot * A);
+            // X2 = dDec . w_dec   [bt, H]
+            GemmArgs g = {};
+            g.nseg = 1;
+            g.seg[0] = {tb.dDec + slot * A, w_dec, A, H, A, nullptr};
+            g.M = bt; g.N = H; g.out = tb.X[1]; g.ldo = H;
+            ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[1], tb.xfloats, &ns2, st));
+        }
+        {   // TD LSTM backward (pointwise): dh1 = carry + X1[:, D:] + X2
+            LstmBwdArgs a = {};
+            a.dh_a = bnext ? tb.X[3] : nullptr; a.ns_a = ns4; a.lda_a = H; a.rows_a = bnext;
+            a.dh_b = tb.X[0] + D; a.ns_b = ns1; a.lda_b = D + H; a.rows_b = bt;
+            a.dh_c = tb.X[1]; a.ns_c = ns2; a.lda_c = H; a.rows_c = bt;
+            a.dc_in = bnext ? tb.dc1[cur] : nullptr; a.dc_in_rows = bnext;
+            a.gates = tb.gtd + slot * 4 * H;
+            a.c_prev = tb.c1 + slot * H; a.c_cur = tb.c1 + slot * H + sH;
+            a.dgates = tb.dGtd + slot * 4 * H; a.dc_prev = tb.dc1[cur ^ 1];
+            a.rows = bt; a.H = H;
+            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 1024), bt), dim3(256), 0, st, a, d_off);
+        }
+        if (t > 0) {
+            {   // X3 = dG_lm . W_hh_lm + dG_td . W_ih_td[:, :H]   -> d h2_{t-1}
+                GemmArgs g = {};
+                g.nseg = 2;
+                g.seg[0] = {tb.dGlm + slot * 4 * H, P.lm_w_hh, 4 * H, H, 4 * H, nullptr};
+                g.seg[1] = {tb.dGtd + slot * 4 * H, P.td_w_ih, 4 * H, H + D + E, 4 * H, nullptr};
+                g.M = bt; g.N = H; g.out = tb.X[2]; g.ldo = H;
+                ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[2], tb.xfloats, &ns3, st));
+            }
+            {   // X4 = dG_td . W_hh_td   -> d h1_{t-1}
+                GemmArgs g = {};
+                g.nseg = 1;
+                g.seg[0] = {tb.dGtd + slot * 4 * H, P.td_w_hh, 4 * H, H, 4 * H, nullptr};
+                g.M = bt; g.N = H; g.out = tb.X[3]; g.ldo = H;
+                ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[3], tb.xfloats, &ns4, st));
+            }
+        }
+        bnext = bt;
+        cur ^= 1;
+    }
+
+    // ---- embedding gradient: dEmb = dG_td . W_ih_td[:, H+D:] for all steps, then ordered scatter
+    {
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {tb.dGtd, P.td_w_ih + H + D, 4 * H, H + D + E, 4 * H, nullptr};
+        g.M = TB; g.N = E; g.out = tb.dEmb; g.ldo = E;
+        int ns;
+        ICZ_TRY(gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st));
+        if (ns > 1) {
+            size_t MN = (size_t)TB * E;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, E, (const float*)nullptr, tb.dEmb);
+        }
+        // inactive (t,b) rows have dG = 0 -> dEmb = 0; their token ids are whatever the buffer held (valid ids)
+        hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), sizeof(int) * TB, st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb,
+                           cur_train ? 2.0f : 1.0f, E, G.embed_weight);
+    }
+    // ---- weight gradients: one TN GEMM each over all (t, b)
+    const int ldtd = H + D + E, ldlm = D + H;
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st));                 // h2_{t-1}
+    hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)B * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)B * 4 * H, tb.dGsum);
+    ICZ_TRY(wgrad(tb.dGsum, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));               // mean features
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st));         // embedding
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st));                     // h1_{t-1}
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st));                 // ctx_t
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st));         // h1_t
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
+    ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
+    ICZ_TRY(wgrad(tb.dEnc, A, A, feats, D, D, B * R, tb.dWenc, D, st));
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih);
+    ICZ_CHECK_HIP(hipMemcpyAsync(G.td_b_hh, G.td_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
+    ICZ_CHECK_HIP(hipMemcpyAsync(G.lm_b_hh, G.lm_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dDec, TB, A, A, G.dec_att_b);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dEnc, B * R, A, A, G.enc_att_b);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff);
+    // d loss / d affine.bias is identically zero (softmax shift invariance)
+    ICZ_CHECK_HIP(hipMemsetAsync(G.affine_b, 0, sizeof(float), st));
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc,
+                       G.enc_att_v, G.enc_att_g, A, D);
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWdec, H, P.dec_att_v, P.dec_att_g, n_dec,
+                       G.dec_att_v, G.dec_att_g, A, H);
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(1), dim3(256), 0, st, tb.dWaff, A, P.affine_v, P.affine_g, n_aff,
+                       G.affine_v, G.affine_g, 1, A);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // namespace icz
+
+// ================================================================================================
+using namespace icz;
+extern "C" {
+
+int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
+                    int64_t* seq_out, float* logprobs_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->sample(feats, B, max_len, rng, seq_out, logprobs_out, (hipStream_t)stream);
+}
+int icz_butd_sample_backward(icz_butd_t* h, const float* reward, const icz_butd_params* grads, float* loss_out,
+                             float* mask_sum_out, float mask_sum_global, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->sample_backward(reward, grads, loss_out, mask_sum_out, mask_sum_global, (hipStream_t)stream);
+}
+int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->sample_mask_sum(mask_sum_out, (hipStream_t)stream);
+}
+int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L,
+                        const int32_t* lengths_host, const icz_rng* rng, int32_t train, float* packed_logits_out,
+                        void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->xe_forward(feats, captions, B, L, lengths_host, rng, train, packed_logits_out, (hipStream_t)stream);
+}
+int icz_butd_xe_backward(icz_butd_t* h, float smoothing, const icz_butd_params* grads, float* loss_out,
+                         float n_tokens_global, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->xe_backward(smoothing, grads, loss_out, n_tokens_global, (hipStream_t)stream);
+}
+
+int icz_adam_clamp_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n, float lr,
+                        float clip, int32_t step, void* stream) {
+    ICZ_REQUIRE(param && grad && exp_avg && exp_avg_sq && n > 0 && step >= 1, "icz_adam_clamp_step: bad arguments");
+    const double b1 = 0.9, b2 = 0.999;
+    const float bc1 = (float)(1.0 - pow(b1, (double)step));
+    const float sbc2 = (float)sqrt(1.0 - pow(b2, (double)step));
+    hipLaunchKernelGGL(adam_clamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
+                       exp_avg, exp_avg_sq, (size_t)n, lr, clip, bc1, sbc2);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // extern "C"

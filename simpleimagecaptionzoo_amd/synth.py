@@ -1,0 +1,39 @@
+"""Synthetic, seeded stand-ins for what the benchmark cannot download: reference-style random-init weights
+(Models/BUTD_Model.py:75-90 + torch defaults), 36x2048 bottom-up features, a <pad>/<sta>/<end>/<unk>+w_i
+vocabulary, Zipf references and a document-frequency table."""
+import math
+
+import torch
+
+
+def random_butd_params(R, D, H, E, A, V, device, seed=1234):
+    """Tensors keyed by the reference's state_dict names (without 'decoder.'), initialised like the reference:
+    LSTMCell / Linear U(-1/sqrt(fan), 1/sqrt(fan)); embed and predict.weight U(-0.1, 0.1); predict.bias 0;
+    weight_norm g = ||v|| per row (BUTD_Model.py:87-90)."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+
+    def U(shape, bound):
+        return (torch.rand(shape, generator=g) * 2 - 1) * bound
+
+    p = {}
+    p["embed.0.weight"] = U((V, E), 0.1)
+    k = 1.0 / math.sqrt(H)
+    p["TD_atten.weight_ih"] = U((4 * H, H + D + E), k)
+    p["TD_atten.weight_hh"] = U((4 * H, H), k)
+    p["TD_atten.bias_ih"] = U((4 * H,), k)
+    p["TD_atten.bias_hh"] = U((4 * H,), k)
+    p["language_model.weight_ih"] = U((4 * H, D + H), k)
+    p["language_model.weight_hh"] = U((4 * H, H), k)
+    p["language_model.bias_ih"] = U((4 * H,), k)
+    p["language_model.bias_hh"] = U((4 * H,), k)
+    for name, (o, i) in (("atten.enc_att", (A, D)), ("atten.dec_att", (A, H)), ("atten.affine", (1, A))):
+        v = U((o, i), 1.0 / math.sqrt(i))
+        p[name + ".weight_v"] = v
+        p[name + ".weight_g"] = v.norm(dim=1, keepdim=True)
+        p[name + ".bias"] = U((o,), 1.0 / math.sqrt(i))
+    v = U((V, H), 0.1)
+    p["predict.weight_v"] = v
+    p["predict.weight_g"] = v.norm(dim=1, keepdim=True)
+    p["predict.bias"] = torch.zeros(V)
+    return {k_: t.to(device=device, dtype=torch.float32).contiguous() for k_, t in p.items()}
