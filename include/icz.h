@@ -138,7 +138,8 @@ typedef struct icz_ciderd icz_ciderd_t;
 /* df table: open-addressing hash of n-grams of token ids.  keys [cap,4] int32 (unused slots -1-filled, n-gram
  * right-padded with -1), idf [cap] float64 = log(ref_len) - log(max(1, df)); cap is a power of two.
  * default_idf = log(ref_len) (n-gram absent from the table).  penalty [64] float64: exp(-d^2/(2 sigma^2)) for
- * |delta| = 0..63 computed on the host exactly as the reference does. */
+ * |delta| = 0..63 computed on the host exactly as the reference does.  The three arrays are DEVICE arrays owned
+ * by the caller and must outlive the handle. */
 int icz_ciderd_create(const int32_t* df_keys, const double* df_idf, int64_t cap, double default_idf,
                       const double* penalty, icz_ciderd_t** out);
 int icz_ciderd_destroy(icz_ciderd_t* h);

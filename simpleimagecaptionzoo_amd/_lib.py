@@ -77,6 +77,9 @@ def lib():
         "icz_butd_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_butd_xe_backward": (C.c_int, [vp, f32, C.POINTER(ButdParams), vp, f32, vp]),
         "icz_adam_clamp_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, i32, vp]),
+        "icz_ciderd_create": (C.c_int, [vp, vp, i64, C.c_double, vp, C.POINTER(vp)]),
+        "icz_ciderd_destroy": (C.c_int, [vp]),
+        "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
         "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),
     }

@@ -1,0 +1,218 @@
+// CIDEr-D reward on the device (float64), replacing the per-batch pure-Python scorer of the reference:
+//   Utils.py:319-367 get_self_critical_reward -> ciderD.py:30-55 -> ciderD_scorer.py:17-32 (precook),
+//   :127-206 (compute_cider).
+// One wave per hypothesis (2B of them: B sampled, B greedy).  Hypotheses are at most T <= 60 tokens, so a
+// hypothesis has at most 4T n-gram positions; lanes work on positions in parallel (dedup, df lookup, match against
+// the cooked references) and lane 0 performs every floating-point accumulation in the reference's dict-insertion
+// order, which makes the scores bit-identical to the reference's float64 results.
+#include "icz_common.h"
+
+namespace icz {
+
+struct CiderD {
+    int32_t* keys = nullptr;     // [cap,4]
+    double* idf = nullptr;       // [cap]
+    double* penalty = nullptr;   // [64]
+    int64_t cap = 0;
+    double default_idf = 0.0;
+};
+
+constexpr int CD_MAXT = 60;                 // max tokens per hypothesis
+constexpr int CD_MAXP = 4 * CD_MAXT;        // max n-gram positions
+
+__host__ __device__ inline uint32_t ngram_hash(int a, int b, int c, int d) {
+    uint32_t h = 2166136261u;
+    h = (h ^ (uint32_t)a) * 16777619u;
+    h = (h ^ (uint32_t)b) * 16777619u;
+    h = (h ^ (uint32_t)c) * 16777619u;
+    h = (h ^ (uint32_t)d) * 16777619u;
+    h ^= h >> 15;
+    return h;
+}
+
+struct CiderArgs {
+    const int32_t* keys; const double* idf; const double* penalty; int64_t cap; double default_idf;
+    const int64_t* gen; const int64_t* greedy; int B, T;
+    const int32_t* img_ref_ptr; const int32_t* ref_ent_ptr; const int32_t* ent_key; const int32_t* ent_order;
+    const double* ent_w; const double* ref_norm; const int32_t* ref_len;
+    double* scores;      // [2B]
+};
+
+__global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
+    __shared__ int tok[CD_MAXT];
+    __shared__ int pkey[CD_MAXP][4];
+    __shared__ int porder[CD_MAXP];       // 1..4
+    __shared__ int pcount[CD_MAXP];       // occurrences if this position is the first occurrence, else 0
+    __shared__ double pw[CD_MAXP];        // tf-idf weight of the n-gram first seen at this position
+    __shared__ double pmatch[CD_MAXP];    // weight of the same n-gram in the current reference (0 if absent)
+    const int hyp = blockIdx.x, lane = threadIdx.x;
+    const int b = hyp % a.B;
+    const bool is_greedy = hyp >= a.B;
+    const int64_t* ids = (is_greedy ? a.greedy : a.gen) + (size_t)b * a.T;
+    // ---- sentence length (Utils.py:337-356)
+    int len;
+    if (is_greedy) {
+        len = a.T;
+        for (int i = 0; i < a.T; ++i)
+            if (ids[i] == 2) { len = i; break; }
+    } else {
+        int end = 0;
+        for (int e = a.T - 1; e >= 0; --e) {
+            end = e;
+            if (ids[e] != 0) break;
+        }
+        len = end + 1;
+    }
+    for (int i = lane; i < len; i += 64) tok[i] = (int)ids[i];
+    __syncthreads();
+    // ---- n-gram positions in precook order: k = 1..4, i = 0..len-k
+    int npos = 0, start[5];
+    for (int k = 1; k <= 4; ++k) { start[k] = npos; npos += (len - k + 1 > 0) ? (len - k + 1) : 0; }
+    for (int p = lane; p < npos; p += 64) {
+        int k = 4;
+        while (k > 1 && p < start[k]) --k;
+        const int i = p - start[k];
+        porder[p] = k;
+        for (int j = 0; j < 4; ++j) pkey[p][j] = (j < k) ? tok[i + j] : -1;
+    }
+    __syncthreads();
+    // ---- dedup: a position is "first" if no earlier position holds the same n-gram; count = #occurrences
+    for (int p = lane; p < npos; p += 64) {
+        const int k = porder[p];
+        bool first = true;
+        int cnt = 0;
+        const int s0 = start[k], s1 = s0 + (len - k + 1);
+        for (int q = s0; q < s1; ++q) {
+            const bool same = pkey[q][0] == pkey[p][0] && pkey[q][1] == pkey[p][1] && pkey[q][2] == pkey[p][2] && pkey[q][3] == pkey[p][3];
+            if (same) { ++cnt; if (q < p) first = false; }
+        }
+        pcount[p] = first ? cnt : 0;
+        double w = 0.0;
+        if (first) {
+            // document-frequency lookup (open addressing, linear probing)
+            double idfv = a.default_idf;
+            uint32_t h = ngram_hash(pkey[p][0], pkey[p][1], pkey[p][2], pkey[p][3]);
+            for (int64_t probe = 0; probe < a.cap; ++probe) {
+                const int64_t s = (int64_t)((h + (uint32_t)probe) & (uint32_t)(a.cap - 1));
+                const int32_t* kk = a.keys + s * 4;
+                if (kk[0] == -1) break;   // empty slot (token ids are >= 0, so key[0] == -1 marks empty)
+                if (kk[0] == pkey[p][0] && kk[1] == pkey[p][1] && kk[2] == pkey[p][2] && kk[3] == pkey[p][3]) { idfv = a.idf[s]; break; }
+            }
+            w = (double)cnt * idfv;      // float(term_freq) * (ref_len - df)   (ciderD_scorer.py:145)
+        }
+        pw[p] = w;
+    }
+    __syncthreads();
+    // ---- hypothesis norms and length (lane 0, insertion order)   (:146-152)
+    __shared__ double hnorm[4];
+    __shared__ int hlen;
+    if (lane == 0) {
+        double nn[4] = {0.0, 0.0, 0.0, 0.0};
+        int l2 = 0;
+        for (int p = 0; p < npos; ++p)
+            if (pcount[p]) {
+                nn[porder[p] - 1] += pw[p] * pw[p];
+                if (porder[p] == 2) l2 += pcount[p];
+            }
+        for (int n = 0; n < 4; ++n) hnorm[n] = sqrt(nn[n]);
+        hlen = l2;
+    }
+    __syncthreads();
+    // ---- references of this image
+    const int r0 = a.img_ref_ptr[b], r1 = a.img_ref_ptr[b + 1];
+    double score[4] = {0.0, 0.0, 0.0, 0.0};
+    for (int r = r0; r < r1; ++r) {
+        const int e0 = a.ref_ent_ptr[r], e1 = a.ref_ent_ptr[r + 1];
+        for (int p = lane; p < npos; p += 64) {
+            double m = 0.0;
+            if (pcount[p]) {
+                for (int e = e0; e < e1; ++e) {
+                    const int32_t* kk = a.ent_key + (size_t)e * 4;
+                    if (a.ent_order[e] == porder[p] && kk[0] == pkey[p][0] && kk[1] == pkey[p][1] && kk[2] == pkey[p][2] && kk[3] == pkey[p][3]) {
+                        m = a.ent_w[e];
+                        break;
+                    }
+                }
+            }
+            pmatch[p] = m;
+        }
+        __syncthreads();
+        if (lane == 0) {
+            double val[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int p = 0; p < npos; ++p)
+                if (pcount[p]) {
+                    const double h = pw[p], rr = pmatch[p];
+                    val[porder[p] - 1] += (h < rr ? h : rr) * rr;       // min(vec_hyp, vec_ref) * vec_ref  (:172-175)
+                }
+            int d = hlen - a.ref_len[r];
+            if (d < 0) d = -d;
+            const double pen = a.penalty[d > 63 ? 63 : d];
+            for (int n = 0; n < 4; ++n) {
+                const double nr = a.ref_norm[(size_t)r * 4 + n];
+                if (hnorm[n] != 0.0 && nr != 0.0) val[n] /= (hnorm[n] * nr);
+                val[n] *= pen;
+                score[n] += val[n];
+            }
+        }
+        __syncthreads();
+    }
+    if (lane == 0) {
+        double s = score[0];
+        s += score[1]; s += score[2]; s += score[3];
+        s = s / 4.0;                      // np.mean over n
+        s /= (double)(r1 - r0);           // / len(refs)
+        s *= 10.0;
+        a.scores[hyp] = s;
+    }
+}
+
+__global__ void ciderd_reward_kernel(const double* __restrict__ scores, int B, int T, float* __restrict__ reward) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T) return;
+    int b = i / T;
+    reward[i] = (float)(scores[b] - scores[B + b]);
+}
+
+}  // namespace icz
+
+using namespace icz;
+extern "C" {
+
+int icz_ciderd_create(const int32_t* df_keys, const double* df_idf, int64_t cap, double default_idf,
+                      const double* penalty, icz_ciderd_t** out) {
+    ICZ_REQUIRE(df_keys && df_idf && penalty && out, "icz_ciderd_create: null argument");
+    ICZ_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0, "icz_ciderd_create: cap must be a power of two");
+    CiderD* c = new CiderD();
+    c->cap = cap;
+    c->default_idf = default_idf;
+    c->keys = const_cast<int32_t*>(df_keys);
+    c->idf = const_cast<double*>(df_idf);
+    c->penalty = const_cast<double*>(penalty);
+    *out = reinterpret_cast<icz_ciderd_t*>(c);
+    return ICZ_OK;
+}
+
+int icz_ciderd_destroy(icz_ciderd_t* h) {
+    delete reinterpret_cast<CiderD*>(h);
+    return ICZ_OK;
+}
+
+int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
+                      const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
+                      const int32_t* ent_order, const double* ent_w, const double* ref_norm, const int32_t* ref_len,
+                      float* reward_out, double* scores_out, void* stream) {
+    ICZ_REQUIRE(h && gen && greedy && img_ref_ptr && ref_ent_ptr && ent_key && ent_order && ent_w && ref_norm && ref_len,
+                "icz_ciderd_reward: null argument");
+    ICZ_REQUIRE(scores_out, "icz_ciderd_reward: scores_out (2B float64 scratch) is required");
+    ICZ_REQUIRE(B > 0 && T > 0 && T <= CD_MAXT, "icz_ciderd_reward: T=%d out of range 1..%d", T, CD_MAXT);
+    CiderD* c = reinterpret_cast<CiderD*>(h);
+    CiderArgs a = {c->keys, c->idf, c->penalty, c->cap, c->default_idf, gen, greedy, B, T,
+                   img_ref_ptr, ref_ent_ptr, ent_key, ent_order, ent_w, ref_norm, ref_len, scores_out};
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(ciderd_kernel, dim3(2 * B), dim3(64), 0, st, a);
+    if (reward_out) hipLaunchKernelGGL(ciderd_reward_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, st, scores_out, B, T, reward_out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // extern "C"

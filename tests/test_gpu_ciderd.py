@@ -1,0 +1,71 @@
+"""GPU parity: device CIDEr-D (csrc/ciderd.hip) vs scores produced by the reference scorer (bit-exact float64)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _df(js):
+    return {tuple(k): v for k, v in js["document_frequency"]}, js["ref_len"]
+
+
+@pytest.mark.parametrize("which", ["cases", "abstract"])
+def test_scores_bit_exact(golden_dir, which):
+    from simpleimagecaptionzoo_amd.ciderd import CiderDReward
+    fx = json.load(open(os.path.join(golden_dir, "ciderd_cases.json")))
+    if which == "abstract":
+        fx = fx["abstract"]
+    df, ref_len = _df(fx["df"])
+    # id 2 terminates a greedy row, so the literal *word* "<end>" (it occurs in the synthetic sentences) gets an
+    # ordinary id and slot 2 is a dummy that never occurs
+    words = ["<pad>", "<sta>", "__terminator__", "<unk>"]
+    for r in fx["res"]:
+        for w in r["caption"][0].split():
+            if w not in words:
+                words.append(w)
+    w2i = {w: i for i, w in enumerate(words)}
+    scorer = CiderDReward(df, ref_len, w2i)
+    n = len(fx["res"])
+    T = max(len(r["caption"][0].split()) for r in fx["res"]) + 1
+    greedy = np.full((n, T), 2, dtype=np.int64)
+    for i, r in enumerate(fx["res"]):
+        ids = [w2i[w] for w in r["caption"][0].split()]
+        greedy[i, :len(ids)] = ids
+    gts = {i: fx["gts"][str(r["image_id"])] for i, r in enumerate(fx["res"])}
+    gen = np.zeros((n, T), dtype=np.int64)
+    _, scores = scorer.reward(torch.tensor(gen), torch.tensor(greedy), gts, list(range(n)), return_scores=True)
+    got = scores.cpu().numpy()[n:]
+    want = np.array(fx["scores"])
+    assert np.array_equal(got, want), np.abs(got - want).max()
+    # the sampled channel sees an all-zero row as the one-word sentence "<pad>" (Utils.py:338-346)
+    pad_scores = scores.cpu().numpy()[:n]
+    i_pad = [i for i, r in enumerate(fx["res"]) if r["caption"][0] == "<pad>"]
+    for i in i_pad:
+        assert pad_scores[i] == want[i]
+
+
+def test_self_critical_reward_matches_reference(golden_dir):
+    from simpleimagecaptionzoo_amd.ciderd import CiderDReward
+    g = dict(np.load(os.path.join(golden_dir, "butd_engine_tiny.npz")))
+    fx = json.load(open(os.path.join(golden_dir, "butd_engine_tiny.json")))
+    df, ref_len = _df(fx["df"])
+    w2i = {w: i for i, w in enumerate(fx["vocab"])}
+    scorer = CiderDReward(df, ref_len, w2i)
+    B = g["r1_gen"].shape[0]
+    gts = {int(k): v for k, v in fx["r1_gts"].items()}
+    r = scorer.reward(torch.tensor(g["r1_gen"]), torch.tensor(g["r1_greedy"]), gts, list(range(B)))
+    got = r.cpu().numpy()
+    assert got.dtype == np.float32 and np.array_equal(got, g["r1_reward"]), np.abs(got - g["r1_reward"]).max()
+    # the rewards recorded inside the reference's SCST steps (fresh scorer: cooked references are cached per
+    # image id, and the fixture reuses ids 0..B-1 with different references)
+    scorer = CiderDReward(df, ref_len, w2i)
+    for s in range(2):
+        pre = "rl%d_" % s
+        gts = {int(k): v for k, v in fx[pre + "gts"].items()}
+        ids = [int(i) for i in g[pre + "img_ids"]]
+        r = scorer.reward(torch.tensor(g[pre + "seq"]), torch.tensor(g[pre + "greedy_ids"]), gts, ids)
+        assert np.array_equal(r.cpu().numpy(), g[pre + "reward"])
