@@ -97,6 +97,9 @@ int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_le
  * local one; mask_sum_out (1 float, device, may be NULL) always receives the local mask sum. */
 int icz_butd_sample_backward(icz_butd_t* h, const float* reward, const icz_butd_params* grads, float* loss_out,
                              float* mask_sum_out, float mask_sum_global, void* stream);
+/* Same backward, driven by an arbitrary upstream gradient d loss / d logprobs [B,max_len] (what autograd hands to
+ * the sampler_rl output when the reference's own RewardCriterion + loss.backward() are used, Engine.py:266-270). */
+int icz_butd_sample_backward_dlogp(icz_butd_t* h, const float* dlogp, const icz_butd_params* grads, void* stream);
 /* local sum of the REINFORCE mask of the last rollout (1 float, device) without running backward */
 int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream);
 
@@ -109,6 +112,10 @@ int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captio
                         float* packed_logits_out, void* stream);
 int icz_butd_xe_backward(icz_butd_t* h, float smoothing, const icz_butd_params* grads, float* loss_out,
                          float n_tokens_global, void* stream);
+
+/* XE backward driven by an upstream gradient w.r.t. the packed logits [sum(lengths), V] (autograd path:
+ * criterion(predictions[0], targets[0]).backward(), Engine.py:182-186). */
+int icz_butd_xe_backward_dlogits(icz_butd_t* h, const float* dpacked, const icz_butd_params* grads, void* stream);
 
 /* DecoderRNN.beam_search_sample (BUTD_Model.py:236-318) for n_img images at once (the reference runs one image
  * per call, Utils.py:72-73).  feats [n_img,R,D]; seqs_out [n_img, max_steps+1] float32 incl. the leading <sta>

@@ -73,6 +73,9 @@ def lib():
         "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_butd_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(Rng), vp, vp, vp]),
         "icz_butd_sample_backward": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp, vp, f32, vp]),
+        "icz_butd_sample_backward_dlogp": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp]),
+        "icz_butd_xe_backward_dlogits": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp]),
+        "icz_butd_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "icz_butd_sample_mask_sum": (C.c_int, [vp, vp, vp]),
         "icz_butd_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_butd_xe_backward": (C.c_int, [vp, f32, C.POINTER(ButdParams), vp, f32, vp]),

@@ -131,6 +131,29 @@ class ButdHandle:
                                          stream_ptr()))
         return loss
 
+    def sample_backward_dlogp(self, dlogp, grads):
+        """BPTT of the last sample() for an upstream gradient d loss / d logprobs (B,T)."""
+        dlogp = dlogp.to(device=self.device, dtype=torch.float32).contiguous()
+        gs = self._grad_struct(grads)
+        check(lib().icz_butd_sample_backward_dlogp(self._h, ptr(dlogp), C.byref(gs), stream_ptr()))
+
+    def xe_backward_dlogits(self, dpacked, grads):
+        """BPTT of the last xe_forward() for an upstream gradient w.r.t. the packed logits (sum(lengths), V)."""
+        dpacked = dpacked.to(device=self.device, dtype=torch.float32).contiguous()
+        gs = self._grad_struct(grads)
+        check(lib().icz_butd_xe_backward_dlogits(self._h, ptr(dpacked), C.byref(gs), stream_ptr()))
+
+    def beam_search(self, feats, beam_size=5, max_steps=50):
+        """DecoderRNN.beam_search_sample (BUTD_Model.py:236-318) for all images of `feats` at once.
+        Returns (seqs float32 (n_img, max_steps+1) zero-padded, lens int32 (n_img,)); row i[:lens[i]] is what the
+        reference returns for image i (leading <sta>, trailing <end> if finished)."""
+        feats = self._check_feats(feats)
+        n = feats.shape[0]
+        seqs = torch.zeros(n, max_steps + 1, dtype=torch.float32, device=feats.device)
+        lens = torch.zeros(n, dtype=torch.int32, device=feats.device)
+        check(lib().icz_butd_beam_search(self._h, ptr(feats), n, beam_size, max_steps, ptr(seqs), ptr(lens), stream_ptr()))
+        return seqs, lens
+
     def step(self, feats, it, h1, c1, h2, c2):
         """One decoder step from an explicit state (BUTD_Model.py:172-182); state tensors are updated in place.
         Returns (ctx, alpha, logits)."""

@@ -44,6 +44,13 @@ struct TrainBuf {
     int* scalars_i = nullptr; int scalars_i_cap = 0;
 };
 
+struct BeamBuf {
+    int cap_rows = 0, cap_L = 0;
+    int* n_act = nullptr; float* run = nullptr; int32_t* seqs[2] = {nullptr, nullptr};
+    int32_t *src_row = nullptr, *img_of_row = nullptr, *best_seq = nullptr;
+    float* best_score = nullptr; int *best_len = nullptr, *has_complete = nullptr, *n_live = nullptr, *n_live_host = nullptr;
+};
+
 struct Butd {
     static constexpr int TARGET_WGS = 512;   // ~2 workgroups per CU on 256 CUs
     static constexpr int ATT_PARTS = 4;
@@ -74,6 +81,10 @@ struct Butd {
     int zero_state(int rows, int which, hipStream_t st);
     int greedy(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
 
+    // beam search (butd_beam.hip)
+    BeamBuf bm;
+    int beam_search(const float* feats, int n_img, int k, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
+
     // training paths (butd_train.hip)
     TrainBuf tb;
     icz_rng rng = {};
@@ -91,6 +102,9 @@ struct Butd {
                         float mask_sum_global, hipStream_t st);
     int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_rng* r,
                    int train, float* packed_out, hipStream_t st);
+    int sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hipStream_t st);
+    int xe_backward_dlogits(const float* dpacked, const icz_butd_params* G, hipStream_t st);
+    int upload_pack_index(hipStream_t st);
     int xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
     int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
     int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);

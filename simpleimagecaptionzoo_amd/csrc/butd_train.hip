@@ -211,23 +211,69 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     cur_captions = captions; cur_L = L;
     for (int t = 0; t < T; ++t) ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
     if (packed_out) {
-        std::vector<int> off(T), rt(T);
-        int acc = 0;
-        for (int t = 0; t < T; ++t) { off[t] = acc; rt[t] = rows_t[t]; acc += rows_t[t]; }
-        int* d_off = (int*)tb.scalars_i;
-        if (!tb.scalars_i || tb.scalars_i_cap < 2 * T) {
-            ICZ_TRY(alloc((void**)&tb.scalars_i, sizeof(int) * 2 * dims.max_len));
-            tb.scalars_i_cap = 2 * dims.max_len;
-            d_off = (int*)tb.scalars_i;
-        }
-        ICZ_CHECK_HIP(hipMemcpyAsync(d_off, off.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
-        ICZ_CHECK_HIP(hipMemcpyAsync(d_off + T, rt.data(), sizeof(int) * T, hipMemcpyHostToDevice, st));
-        ICZ_CHECK_HIP(hipStreamSynchronize(st));   // host vectors go out of scope
+        ICZ_TRY(upload_pack_index(st));
         hipLaunchKernelGGL(gather_packed_kernel, dim3(cdiv(dims.V, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, (int)Vp, B,
-                           d_off, d_off + T, T, packed_out);
+                           tb.scalars_i, tb.scalars_i + T, T, packed_out);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
+}
+
+// device copy of the packed-sequence index: row_off[t] (first packed row of step t) and rows_t[t]
+int Butd::upload_pack_index(hipStream_t st) {
+    const int T = cur_T;
+    std::vector<int> hostv(2 * T);
+    int acc = 0;
+    for (int t = 0; t < T; ++t) { hostv[t] = acc; hostv[T + t] = rows_t[t]; acc += rows_t[t]; }
+    if (!tb.scalars_i) {
+        ICZ_TRY(alloc((void**)&tb.scalars_i, sizeof(int) * 2 * dims.max_len));
+        tb.scalars_i_cap = 2 * dims.max_len;
+    }
+    ICZ_CHECK_HIP(hipMemcpyAsync(tb.scalars_i, hostv.data(), sizeof(int) * 2 * T, hipMemcpyHostToDevice, st));
+    ICZ_CHECK_HIP(hipStreamSynchronize(st));   // the host vector goes out of scope
+    return ICZ_OK;
+}
+
+__global__ void scatter_packed_kernel(const float* __restrict__ dpacked, int V, int ldl, int B, const int* __restrict__ row_off,
+                                      const int* __restrict__ rows_t, int T, float* __restrict__ logit) {
+    // inverse of gather_packed_kernel; inactive rows and pad columns become zero
+    const int tb_ = blockIdx.y, t = tb_ / B, b = tb_ % B;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v >= ldl) return;
+    float g = 0.f;
+    if (b < rows_t[t] && v < V) g = dpacked[(size_t)(row_off[t] + b) * V + v];
+    logit[(size_t)tb_ * ldl + v] = g;
+}
+
+int Butd::xe_backward_dlogits(const float* dpacked, const icz_butd_params* G, hipStream_t st) {
+    ICZ_REQUIRE(mode == 2, "butd: no XE forward stored (call icz_butd_xe_forward first)");
+    ICZ_REQUIRE(dpacked && G, "butd xe_backward_dlogits: null argument");
+    const int B = cur_B, T = cur_T;
+    const int Vp = round4(dims.V);
+    ICZ_TRY(upload_pack_index(st));
+    hipLaunchKernelGGL(scatter_packed_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, dpacked, dims.V, Vp, B, tb.scalars_i,
+                       tb.scalars_i + T, T, tb.logit);
+    ICZ_CHECK_HIP(hipGetLastError());
+    mode = 0;
+    return bptt(*G, st);
+}
+
+__global__ void transpose_coef_kernel(const float* __restrict__ dlogp, int n, float* __restrict__ coef) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) coef[i] = dlogp[i];
+}
+
+int Butd::sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hipStream_t st) {
+    ICZ_REQUIRE(mode == 1, "butd: no rollout stored (call icz_butd_sample first)");
+    ICZ_REQUIRE(dlogp && G, "butd sample_backward_dlogp: null argument");
+    const int B = cur_B, T = cur_T;
+    const int Vp = round4(dims.V);
+    ICZ_CHECK_HIP(hipMemcpyAsync(tb.coef, dlogp, sizeof(float) * B * T, hipMemcpyDeviceToDevice, st));
+    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
+                       tb.draw, tb.lse, tb.coef, B, T);
+    ICZ_CHECK_HIP(hipGetLastError());
+    mode = 0;
+    return bptt(*G, st);
 }
 
 int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st) {
@@ -440,6 +486,14 @@ int icz_butd_sample_backward(icz_butd_t* h, const float* reward, const icz_butd_
                              float* mask_sum_out, float mask_sum_global, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Butd*>(h)->sample_backward(reward, grads, loss_out, mask_sum_out, mask_sum_global, (hipStream_t)stream);
+}
+int icz_butd_sample_backward_dlogp(icz_butd_t* h, const float* dlogp, const icz_butd_params* grads, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->sample_backward_dlogp(dlogp, grads, (hipStream_t)stream);
+}
+int icz_butd_xe_backward_dlogits(icz_butd_t* h, const float* dpacked, const icz_butd_params* grads, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->xe_backward_dlogits(dpacked, grads, (hipStream_t)stream);
 }
 int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");

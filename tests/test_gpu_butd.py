@@ -152,3 +152,36 @@ def test_xe_forward_backward(golden_dir, name):
     torch.cuda.synchronize()
     assert abs(loss.item() - float(g["xe_loss"])) < 1e-4
     _check_grads(grads, g, "xe_grad.")
+
+
+def _beam_regime_sd(g, regime):
+    sd = {k: v.copy() for k, v in sd_of(g).items()}
+    if regime == "early":
+        sd["predict.bias"][2] = 4.0
+    elif regime == "never":
+        sd["predict.bias"][2] = -1e4
+    elif regime == "track":
+        tok = int(g["beam_track_tok"])
+        sd["predict.weight_v"][2] = sd["predict.weight_v"][tok]
+        sd["predict.weight_g"][2] = sd["predict.weight_g"][tok]
+        sd["predict.bias"][2] = sd["predict.bias"][tok] - 0.2
+    return sd
+
+
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("regime", ["nat", "early", "never", "track"])
+def test_beam_search_token_exact(golden_dir, name, regime):
+    """Batched device beam search vs the reference's one-image-at-a-time beam search (k = 1, 3, 5)."""
+    g = load(golden_dir, name)
+    B = int(g["dims"][0])
+    n = min(B, 3)
+    h, _ = make_handle(g, _beam_regime_sd(g, regime), max_rows=n * 5)
+    feats = torch.tensor(g["feats"][:n], device="cuda")
+    for k in (1, 3, 5):
+        seqs, lens = h.beam_search(feats, k, 50)
+        torch.cuda.synchronize()
+        seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+        for i in range(n):
+            want = g["beam_%s_k%d_i%d" % (regime, k, i)].ravel()
+            assert lens[i] == want.shape[0], (regime, k, i, lens[i], want.shape)
+            assert np.array_equal(seqs[i, :lens[i]], want), (regime, k, i)
