@@ -1,0 +1,259 @@
+"""Engine subclasses for the hot path (drop-ins for ModelEngines/BUTD_Engine.py on top of Engine.py).
+
+Mirrors the reference's Engine methods that sit on the path -- same names, argument meaning, batch-tuple layouts
+and output contract:
+    modify_visual_inputs          BUTD_Engine.py:23-47
+    training_epoch                Engine.py:169-188      (XE: forward, label-smoothed loss, backward, clamp 0.1, Adam)
+    SCST_training_epoch           Engine.py:251-272      (greedy baseline, sampled rollout, CIDEr-D reward, REINFORCE,
+                                                          clamp 0.25, Adam)
+    eval_captions_json_generation Engine.py:274-300      (greedy or beam decode -> [{'image_id', 'caption'}])
+Everything between the batch tuple and the updated parameters runs in libicz; the host only moves the feature batch
+to the device and (for evaluation) turns ids into words.  With torch.distributed initialised (dist.py) the same
+methods run data-parallel: per-rank shards, all-reduced loss normaliser and gradients.
+"""
+import json
+
+import numpy as np
+import torch
+
+from ._lib import BUTD_PARAM_KEYS, check, lib, ptr, stream_ptr
+from .captioner import BUTDDetection_Captioner
+from .ciderd import CiderDReward
+from . import dist as icz_dist
+
+
+class FusedAdam:
+    """clip_gradient (Utils.py:241-250) + torch.optim.Adam(betas=(0.9,0.999), eps=1e-8, weight_decay=0)
+    (Utils.py:219-220) as one HIP kernel per parameter tensor.  Exposes param_groups like a torch optimizer so the
+    reference's set_lr / get_lr helpers (Utils.py:231-239) keep working."""
+
+    def __init__(self, params, lr):
+        if isinstance(params, (list, tuple)) and params and isinstance(params[0], dict):
+            self.param_groups = [dict(g) for g in params]
+            for g in self.param_groups:
+                g.setdefault("lr", lr)
+        else:
+            self.param_groups = [{"params": list(params), "lr": lr}]
+        self.state = {}
+
+    def zero_grad(self):
+        pass
+
+    def step_with(self, grads_by_param, clip):
+        """grads_by_param: {parameter: gradient tensor}."""
+        for group in self.param_groups:
+            for p in group["params"]:
+                g = grads_by_param.get(p)
+                if g is None:
+                    continue
+                st = self.state.get(p)
+                if st is None:
+                    st = {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
+                    self.state[p] = st
+                st["step"] += 1
+                check(lib().icz_adam_clamp_step(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
+                                                p.numel(), float(group["lr"]), float(clip), st["step"], stream_ptr()))
+
+
+def init_optimizer(optimizer_type, params, learning_rate):
+    """Utils.py:222-229 (Adam only on the fused path)."""
+    if optimizer_type != "Adam":
+        raise ValueError("the fused optimiser implements Adam (the reference's default, Main.py:171)")
+    if len(params) == 0:
+        return None
+    return FusedAdam(params, learning_rate)
+
+
+class Engine(object):
+    """The part of Engine.py:16-41 the hot path needs (construction, device, vocabulary, tag)."""
+
+    def __init__(self, model_settings_json, dataset_name, caption_vocab, data_dir=None, use_bu="unused", device="cuda:0",
+                 cider_df=None, max_batch=128):
+        if isinstance(model_settings_json, dict):
+            self.settings = dict(model_settings_json)
+        else:
+            self.settings = json.load(open(model_settings_json, "r"))
+        self.device = torch.device(device)
+        self.data_dir = data_dir
+        self.dataset_name = dataset_name
+        self.use_bu = use_bu
+        self.caption_vocab = caption_vocab
+        self.tag = "Model_" + self.settings["model_type"] + "_Dataset_" + dataset_name
+        self.model = self.model_construction(max_batch)
+        self.model.to(self.device)
+        self.cnn_ft_model = 0
+        self._cider_df = cider_df
+        self._scorer = None
+        self._pinned = None
+
+    def model_construction(self, max_batch):
+        raise NotImplementedError
+
+
+class BUTDDetection_Eng(Engine):
+    """ModelEngines/BUTD_Engine.py:21-47 + the three hot Engine methods on libicz."""
+
+    def model_construction(self, max_batch):
+        s = self.settings
+        assert s["model_type"] in ("BUTDDetection", "BUTDSpatial")
+        return BUTDDetection_Captioner(atten_dim=s["atten_dim"], embed_dim=s["embed_dim"], hidden_dim=s["hidden_dim"],
+                                       vocab_size=len(self.caption_vocab), device=str(self.device),
+                                       num_regions=s.get("num_regions", 36), enc_dim=s.get("enc_dim", 2048),
+                                       max_batch=max_batch)
+
+    # ---- E4 -------------------------------------------------------------------------------------------------
+    def modify_visual_inputs(self, img_tensors, supp_info_datas=None):
+        """BUTD_Engine.py:23-47: stack per-image (n_i, D) features into (B, max_n, D) fp32 + mask (None if all
+        rows are full).  Staged through a reusable pinned buffer and copied asynchronously."""
+        bu_feats = [s["bu_feat"] for s in supp_info_datas]
+        bu_bboxes = [s["bu_bbox"] for s in supp_info_datas]
+        max_len = max(f.shape[0] for f in bu_feats)
+        B, D = len(bu_feats), bu_feats[0].shape[1]
+        if self._pinned is None or self._pinned.shape[0] < B or tuple(self._pinned.shape[1:]) != (max_len, D):
+            self._pinned = torch.zeros(max(B, 1), max_len, D, dtype=torch.float32).pin_memory()
+        host = self._pinned[:B]
+        hv = host.numpy()
+        masks = np.zeros((B, max_len), dtype="float32")
+        for i, f in enumerate(bu_feats):
+            n = f.shape[0]
+            hv[i, :n] = f
+            if n < max_len:
+                hv[i, n:] = 0
+            masks[i, :n] = 1
+        bu_masks = None if masks.sum() == masks.size else torch.from_numpy(masks).float().to(self.device)
+        feats = host.to(self.device, non_blocking=True)
+        return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": bu_masks}
+
+    # ---- helpers ------------------------------------------------------------------------------------------
+    def _grads(self):
+        """Gradient buffers as views into ONE flat fp32 buffer (a single all-reduce over xGMI moves them all)."""
+        if getattr(self, "_flat", None) is None:
+            named = self.model._named()
+            offs, total = {}, 0
+            for k, p in named.items():
+                offs[k] = total
+                total += (p.numel() + 63) // 64 * 64
+            self._flat = torch.zeros(total, dtype=torch.float32, device=self.device)
+            self._gviews = {k: self._flat[o:o + named[k].numel()].view_as(named[k]) for k, o in offs.items()}
+        return self._gviews
+
+    def _apply(self, optimizer, clip):
+        named = self.model._named()
+        grads = self._gviews
+        if isinstance(optimizer, FusedAdam):
+            optimizer.step_with({named[k]: grads[k] for k in BUTD_PARAM_KEYS}, clip)
+        else:   # a torch optimizer handed in by unmodified reference code
+            for k in BUTD_PARAM_KEYS:
+                named[k].grad = grads[k].clamp(-clip, clip)
+            optimizer.step()
+
+    def scorer(self):
+        if self._scorer is None:
+            df = self._cider_df
+            if df is None:
+                raise RuntimeError("SCST needs the CIDEr document-frequency table: pass cider_df={'document_frequency':"
+                                   " ..., 'ref_len': n} (the content of cider/data/<dataset>-train.p)")
+            if isinstance(df, str):
+                import pickle
+                df = pickle.load(open(df, "rb"), encoding="latin1")
+            self._scorer = CiderDReward(df["document_frequency"], df["ref_len"], self.caption_vocab.word2ix, self.device)
+        return self._scorer
+
+    # ---- E1 -------------------------------------------------------------------------------------------------
+    def training_epoch(self, dataloader, optimizer, criterion, tqdm_visible=True, rngs=None):
+        """Engine.py:169-188.  `criterion` is the reference's LabelSmoothingLoss (only its .smoothing is read: the
+        loss and its gradient are fused into the backward kernels).  `rngs` (tests) supplies one icz_rng per batch."""
+        self.model.train()
+        smoothing = float(getattr(criterion, "smoothing", 0.0))
+        monitor = _monitor(dataloader, "Training Process", tqdm_visible)
+        losses = []
+        for batch_i, (img_ids, img_tensors, captions, lengths, supp_info_datas) in enumerate(monitor):
+            visual_inputs = self.modify_visual_inputs(img_tensors, supp_info_datas)
+            lengths = [cap_len - 1 for cap_len in lengths]
+            h = self.model._handle()
+            rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
+            h.xe_forward(visual_inputs["bu_feats"], captions, lengths, rng, train=True)
+            grads = self._grads()
+            n_tok = float(sum(lengths))
+            n_glob = icz_dist.all_reduce_scalar(n_tok) if icz_dist.is_distributed() else 0.0
+            loss = h.xe_backward(grads, smoothing, n_glob)
+            if icz_dist.is_distributed():
+                icz_dist.all_reduce_sum_(self._flat)
+            self._apply(optimizer, 0.1)
+            losses.append(loss)
+            if tqdm_visible:
+                monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))
+        return losses
+
+    # ---- E2 -------------------------------------------------------------------------------------------------
+    def SCST_training_epoch(self, dataloader, optimizer, criterion, tqdm_visible=True, rngs=None):
+        """Engine.py:251-272: greedy baseline (eval mode) + multinomial rollout (train mode) + CIDEr-D reward +
+        REINFORCE + clamp 0.25 + Adam, all on the device; `criterion` (RewardCriterion) is implied."""
+        self.model.train()
+        monitor = _monitor(dataloader, "Training Process", tqdm_visible)
+        scorer = self.scorer()
+        losses = []
+        for batch_i, (img_ids, img_tensors, img_gts, supp_info_datas) in enumerate(monitor):
+            visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
+            feats = visual_inputs["bu_feats"]
+            h = self.model._handle()
+            greedy_res = h.greedy(feats, 20)
+            rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
+            seq_gen, seq_logprobs = h.sample(feats, 20, rng)
+            rewards = scorer.reward(seq_gen, greedy_res, img_gts, img_ids)
+            grads = self._grads()
+            msum_glob = 0.0
+            if icz_dist.is_distributed():
+                msum_glob = icz_dist.all_reduce_scalar(h.sample_mask_sum())
+            loss, _ = h.sample_backward(rewards, grads, msum_glob)
+            if icz_dist.is_distributed():
+                icz_dist.all_reduce_sum_(self._flat)
+            self._apply(optimizer, 0.25)
+            losses.append(loss)
+            if tqdm_visible:
+                monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))
+        return losses
+
+    # ---- E3 -------------------------------------------------------------------------------------------------
+    def eval_captions_json_generation(self, dataloader, eval_beam_size=-1, tqdm_visible=True):
+        """Engine.py:274-300.  Beam search accepts any batch size here (the reference's loader uses 1)."""
+        self.model.eval()
+        result = []
+        print("Generating captions json for evaluation. Beam Search: %s" % (eval_beam_size != -1))
+        monitor = _monitor(dataloader, "Generating Process", tqdm_visible)
+        ix2word = self.caption_vocab.ix2word
+        for batch_i, (image_ids, img_tensors, supp_info_datas) in enumerate(monitor):
+            visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
+            h = self.model._handle()
+            if eval_beam_size != -1:
+                seqs, lens = h.beam_search(visual_inputs["bu_feats"], eval_beam_size, 50)
+                seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+                rows = [seqs[i, :lens[i]] for i in range(len(lens))]
+            else:
+                rows = list(h.greedy(visual_inputs["bu_feats"], 20).cpu().numpy())
+            for image_idx, sampled_ids in enumerate(rows):
+                sampled_caption = []
+                for word_id in sampled_ids:
+                    word = ix2word[int(word_id)]
+                    if word == "<end>":
+                        break
+                    elif word != "<sta>":
+                        sampled_caption.append(word)
+                result.append({"image_id": int(image_ids[image_idx]), "caption": " ".join(sampled_caption)})
+        return result
+
+
+class BUTDSpatial_Eng(BUTDDetection_Eng):
+    """Same decoder over a 7x7x2048 grid fed as precomputed features (49 regions); the CNN encoder of
+    BUTD_Model.py:8-38 is outside the hot path."""
+
+    def model_construction(self, max_batch):
+        self.settings.setdefault("num_regions", self.settings.get("enc_img_size", 7) ** 2)
+        return super().model_construction(max_batch)
+
+
+def _monitor(dataloader, desc, visible):
+    if not visible:
+        return dataloader
+    import tqdm
+    return tqdm.tqdm(dataloader, desc=desc)

@@ -1,0 +1,175 @@
+"""GPU parity at Engine level: two XE steps + two SCST steps + eval JSON against what the reference Engine produced
+(tests/golden/butd_engine_tiny.*), through the drop-in Engine subclass and through the reference-style autograd path."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from synth import feats_from_seed, masks_from_seed, probe_indices  # noqa: E402
+
+
+class _Crit:
+    smoothing = 0.1
+
+
+def _load(golden_dir):
+    g = dict(np.load(os.path.join(golden_dir, "butd_engine_tiny.npz")))
+    fx = json.load(open(os.path.join(golden_dir, "butd_engine_tiny.json")))
+    return g, fx
+
+
+def _engine(g, fx):
+    from simpleimagecaptionzoo_amd.engine import BUTDDetection_Eng
+    from simpleimagecaptionzoo_amd.vocab import Caption_Vocabulary
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    vocab = Caption_Vocabulary()
+    for w in fx["vocab"]:
+        vocab.add_word(w)
+    df = {"document_frequency": {tuple(k): v for k, v in fx["df"]["document_frequency"]}, "ref_len": fx["df"]["ref_len"]}
+    eng = BUTDDetection_Eng({"model_type": "BUTDDetection", "atten_dim": A, "embed_dim": E, "hidden_dim": H},
+                            "SYN", vocab, data_dir="/tmp/", use_bu="fixed", device="cuda:0", cider_df=df, max_batch=8)
+    sd = {k[4:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd0.")}
+    missing = eng.model.load_state_dict(sd, strict=True)
+    assert not missing.missing_keys and not missing.unexpected_keys
+    return eng, vocab
+
+
+def _supp(feats):
+    return tuple({"bu_feat": feats[i], "bu_bbox": np.zeros((feats.shape[1], 4), np.float32)} for i in range(feats.shape[0]))
+
+
+def _check_pinned(g, prefix, model, slack):
+    sd = model.state_dict()
+    for k, v in sd.items():
+        a = v.detach().cpu().numpy()
+        base = "%s%s/" % (prefix, k)
+        if k == "decoder.atten.affine.bias":
+            # zero-gradient scalar: the reference feeds Adam rounding noise (see tests/test_oracle_golden.py)
+            np.testing.assert_allclose(a, g[base + "full"], atol=slack * 1.01 + 1e-7, rtol=0)
+        elif base + "full" in g:
+            np.testing.assert_allclose(a, g[base + "full"], atol=5e-6, rtol=0, err_msg=k)
+        else:
+            f = a.reshape(-1)
+            np.testing.assert_allclose(f[probe_indices(f.size)], g[base + "sample"], atol=5e-6, rtol=0, err_msg=k)
+            assert abs(f.astype(np.float64).sum() - float(g[base + "sum"])) < 2e-5 * max(1.0, np.sqrt(f.size)), k
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    g, fx = _load(golden_dir)
+    eng, _ = _engine(g, fx)
+    want = sorted(k[4:] for k in g if k.startswith("sd0."))
+    assert sorted(eng.model.state_dict().keys()) == want
+    for k, v in eng.model.state_dict().items():
+        assert tuple(v.shape) == g["sd0." + k].shape, k
+
+
+def test_eval_json_greedy_and_beam(golden_dir):
+    g, fx = _load(golden_dir)
+    eng, _ = _engine(g, fx)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    feats = feats_from_seed(int(g["eval_feats_seed"]), B, R, D)
+    ids = tuple(int(i) for i in g["eval_img_ids"])
+    res = eng.eval_captions_json_generation([(ids, None, _supp(feats))], eval_beam_size=-1, tqdm_visible=False)
+    assert res == fx["eval_greedy_json"]
+    res = eng.eval_captions_json_generation([(ids, None, _supp(feats))], eval_beam_size=3, tqdm_visible=False)
+    assert res == fx["eval_beam3_json"]
+    vi = eng.modify_visual_inputs(None, _supp(feats))
+    assert vi["bu_masks"] is None and tuple(vi["bu_feats"].shape) == (B, R, D)
+    assert np.array_equal(eng.model.sampler(vi, 20).cpu().numpy(), g["eval_greedy_ids"])
+    one = eng.modify_visual_inputs(None, _supp(feats[:1]))
+    s = eng.model.beam_search_sampler(one, 3)
+    assert s.dtype == torch.float32 and np.array_equal(s.cpu().numpy().ravel(), g["eval_beam3_seq_0"])
+
+
+@pytest.mark.parametrize("path", ["fused", "autograd"])
+def test_xe_then_scst_steps_match_reference_engine(golden_dir, path):
+    """Engine.training_epoch x2 then SCST_training_epoch x2 with the reference's masks / uniforms injected."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import init_optimizer
+    g, fx = _load(golden_dir)
+    eng, vocab = _engine(g, fx)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    dev = "cuda"
+
+    def rng_of(seed, T, with_u):
+        em, am, om, u = masks_from_seed(seed, T, B, R, E, A, H)
+        return make_rng(0, torch.tensor(u, dtype=torch.float32, device=dev) if with_u else None,
+                        torch.tensor(em, device=dev), torch.tensor(am, device=dev), torch.tensor(om, device=dev))
+
+    if path == "fused":
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 4e-4}), 4e-4)
+    else:
+        opt = torch.optim.Adam(eng.model.get_param_groups({"lr": 4e-4}), lr=4e-4, betas=(0.9, 0.999), eps=1e-8)
+    for s in range(2):
+        pre = "xe%d_" % s
+        feats = feats_from_seed(int(g[pre + "feats_seed"]), B, R, D)
+        caps = torch.tensor(g[pre + "captions"])
+        lens = [int(x) for x in g[pre + "lengths"]]
+        rng = rng_of(int(g[pre + "mask_seed"]), max(lens) - 1, False)
+        batch = (tuple(range(B)), None, caps, lens, _supp(feats))
+        if path == "fused":
+            losses = eng.training_epoch([batch], opt, _Crit(), tqdm_visible=False, rngs=[rng])
+            loss = losses[0].item()
+        else:   # what the reference's own Engine.training_epoch does (Engine.py:176-188), on our Captioner
+            eng.model.train()
+            vi = eng.modify_visual_inputs(None, _supp(feats))
+            capd = caps.to(dev)
+            l1 = [x - 1 for x in lens]
+            from torch.nn.utils.rnn import pack_padded_sequence
+            targets = pack_padded_sequence(capd[:, 1:], l1, batch_first=True)
+            eng.model.zero_grad()
+            pred = eng.model(vi, capd, l1, rng=rng)
+            lp = torch.log_softmax(pred[0], dim=-1)
+            true = torch.full_like(lp, 0.1 / (V - 1)).scatter_(1, targets[0].unsqueeze(1), 0.9)
+            loss_t = torch.nn.functional.kl_div(lp, true, reduction="none").sum(1).sum() / lp.size(0)
+            loss_t.backward()
+            for p in eng.model.parameters():
+                p.grad.data.clamp_(-0.1, 0.1)
+            opt.step()
+            loss = loss_t.item()
+        torch.cuda.synchronize()
+        assert abs(loss - float(g[pre + "loss"])) < 1e-4
+        _check_pinned(g, pre + "sd.", eng.model, slack=4e-4 * (s + 1))
+
+    if path == "fused":
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    else:
+        opt = torch.optim.Adam(eng.model.get_param_groups({"lr": 2e-5}), lr=2e-5, betas=(0.9, 0.999), eps=1e-8)
+    for s in range(2):
+        pre = "rl%d_" % s
+        feats = feats_from_seed(int(g[pre + "feats_seed"]), B, R, D)
+        rng = rng_of(int(g[pre + "mask_seed"]), 20, True)
+        img_ids = tuple(int(i) for i in g[pre + "img_ids"])
+        gts = {int(k): v for k, v in fx[pre + "gts"].items()}
+        batch = (img_ids, None, gts, _supp(feats))
+        if path == "fused":
+            losses = eng.SCST_training_epoch([batch], opt, None, tqdm_visible=False, rngs=[rng])
+            loss = losses[0].item()
+        else:   # Engine.py:255-272 on our Captioner + our reward function
+            vi = eng.modify_visual_inputs(None, _supp(feats))
+            eng.model.zero_grad()
+            eng.model.eval()
+            with torch.no_grad():
+                greedy_res = eng.model.sampler(vi, max_len=20)
+            assert np.array_equal(greedy_res.cpu().numpy(), g[pre + "greedy_ids"])
+            eng.model.train()
+            seq_gen, seq_lp = eng.model.sampler_rl(vi, max_len=20, rng=rng)
+            assert np.array_equal(seq_gen.cpu().numpy(), g[pre + "seq"])
+            np.testing.assert_allclose(seq_lp.detach().cpu().numpy(), g[pre + "logprobs"], atol=1e-4)
+            rewards = eng.scorer().reward(seq_gen, greedy_res, gts, img_ids)
+            assert np.array_equal(rewards.cpu().numpy(), g[pre + "reward"])
+            mask = (seq_gen > 0).float()
+            mask = torch.cat([mask.new_ones(mask.size(0), 1), mask[:, :-1]], 1)
+            loss_t = (-seq_lp * rewards * mask).sum() / mask.sum()
+            loss_t.backward()
+            for p in eng.model.parameters():
+                p.grad.data.clamp_(-0.25, 0.25)
+            opt.step()
+            loss = loss_t.item()
+        torch.cuda.synchronize()
+        assert abs(loss - float(g[pre + "loss"])) < 1e-4
+        _check_pinned(g, pre + "sd.", eng.model, slack=8e-4 + 2e-5 * (s + 1))
