@@ -1,0 +1,166 @@
+#!/usr/bin/env python3
+"""Benchmark of the hot path: captions/sec of the BUTDDetection SCST step (BASELINE.json metric).
+
+One "step" = Engine.SCST_training_epoch on one batch of 64 images per GPU: greedy baseline (20 steps) + sampled
+rollout (20 steps, dropout on) + CIDEr-D reward + REINFORCE backward + clamp 0.25 + Adam, at the reference sizes
+(36 x 2048 bottom-up features, hidden = embed = attention = 1024, COCO14-size vocabulary 10102, fp32).  Synthetic
+features / references / random-init weights (no network), already resident in HBM when the timed region starts.
+
+    python bench.py --gpus 1 --steps 10 --warmup 3
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Rank 0 prints ONE JSON line (see the keys below).  `roofline` is measured live with HIP events around every launch of
+the dominant kernel (gemm_nt_kernel<4>, the forward GEMMs of the decoder step) during the timed steps;
+`cpu_baseline` times the CPU oracle (our port of the reference path, oracle/) on a bounded sample on rank 0.
+"""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+R, D, H, E, A, V, T = 36, 2048, 1024, 1024, 1024, 10102, 20
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
+MFMA_F32_PEAK_TFLOPS = 157.3
+
+
+def build_engine(device, B):
+    from simpleimagecaptionzoo_amd.engine import BUTDDetection_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.synth import document_frequency, random_butd_params, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    df = document_frequency(synthetic_references(2000, words, seed=0))
+    eng = BUTDDetection_Eng({"model_type": "BUTDDetection", "atten_dim": A, "embed_dim": E, "hidden_dim": H},
+                            "SYN", vocab, data_dir="/tmp/", use_bu="fixed", device=device, cider_df=df, max_batch=B)
+    params = random_butd_params(R, D, H, E, A, V, device, seed=1234)      # identical on every rank (replicas)
+    eng.model.load_state_dict({"decoder." + k: v for k, v in params.items()})
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    return eng, opt, vocab, words
+
+
+def make_batches(n, B, words, device, rank):
+    from simpleimagecaptionzoo_amd.synth import synthetic_references
+    g = torch.Generator(device="cpu")
+    batches = []
+    for i in range(n):
+        g.manual_seed(1234 + 1000 * rank + i)
+        feats = torch.relu(torch.randn(B, R, D, generator=g)).to(device)
+        ids = tuple(range((rank * n + i) * B, (rank * n + i + 1) * B))
+        refs = synthetic_references(B, words, seed=77 + rank * n + i)
+        gts = {ids[j]: refs[j] for j in range(B)}
+        batches.append((ids, None, gts, {"bu_feats": feats}))
+    return batches
+
+
+def cpu_baseline(words, rows=8):
+    """One SCST step of the CPU oracle (port of the reference path) at full model size on `rows` images."""
+    from oracle import butd as ob
+    from oracle import ciderd as oc
+    from simpleimagecaptionzoo_amd.synth import document_frequency, random_butd_params, synthetic_references
+    torch.manual_seed(0)
+    p = {k: v.clone().requires_grad_(True) for k, v in random_butd_params(R, D, H, E, A, V, "cpu", seed=1234).items()}
+    feats = torch.relu(torch.randn(rows, R, D))
+    refs = synthetic_references(rows, words, seed=5)
+    docfreq = oc.DocFreq(document_frequency(synthetic_references(2000, words, seed=0))["document_frequency"], 2000)
+    ix2word = dict(enumerate(words))
+    rng = np.random.RandomState(3)
+    em = (rng.rand(T, rows, E) < 0.5)
+    am = (rng.rand(T, rows, R, A) < 0.5)
+    om = (rng.rand(T, rows, H) < 0.5)
+    u = rng.rand(T, rows)
+    opt = ob.Adam(p, 2e-5)
+    t0 = time.time()
+    with torch.no_grad():
+        gre, _, _ = ob.greedy(feats, p, T)
+    seq, lp, _ = ob.sample_rl(feats, p, u, em, am, om, T, early_exit=False)
+    rew = oc.self_critical_reward(seq.numpy(), gre.numpy(), {i: refs[i] for i in range(rows)}, list(range(rows)), ix2word, docfreq)
+    loss = ob.reward_criterion(lp, seq, torch.from_numpy(rew))
+    grads = dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()))))
+    opt.step(grads, 0.25)
+    dt = time.time() - t0
+    return {"value": rows / dt, "unit": "captions/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": "1 SCST step of the CPU oracle (torch-CPU fp32 port of Engine.SCST_training_epoch), %d of the 64 "
+                      "images of a batch, full model size, %.1f s" % (rows, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE config: 64)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-rows", type=int, default=64)
+    args = ap.parse_args()
+
+    from simpleimagecaptionzoo_amd import dist as icz_dist
+    from simpleimagecaptionzoo_amd._lib import lib
+    rank, world, local = icz_dist.init_from_env()
+    if args.gpus != world:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
+    device = "cuda:%d" % local
+    torch.cuda.set_device(local)
+    B = args.batch
+    eng, opt, vocab, words = build_engine(device, B)
+    n_distinct = 2
+    batches = make_batches(n_distinct, B, words, device, rank)
+
+    def run(n):
+        loader = [batches[i % n_distinct] for i in range(n)]
+        eng.SCST_training_epoch(loader, opt, None, tqdm_visible=False)
+
+    run(max(args.warmup, n_distinct))          # also cooks + caches the references of every distinct batch
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    lib().icz_prof_begin()
+    t0 = time.perf_counter()
+    run(args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        torch.distributed.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    avg_us, bpl, fpl, nl = C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
+    lib().icz_prof_end(C.byref(avg_us), C.byref(bpl), C.byref(fpl), C.byref(nl))
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank != 0:
+        return
+    value = world * B * args.steps / dt
+    ach_gbs = bpl.value / (avg_us.value * 1e-6) / 1e9 if avg_us.value > 0 else 0.0
+    ach_tf = fpl.value / (avg_us.value * 1e-6) / 1e12 if avg_us.value > 0 else 0.0
+    out = {
+        "metric": "captions/sec (SCST step), BUTDDetection COCO14-size vocab",
+        "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "BUTDDetection SCST step (greedy + sampled rollout + CIDEr-D reward + REINFORCE backward "
+                               "+ clamp + Adam), batch %d per GPU, 36x2048 features, H=E=A=1024, V=10102, 20 decode steps" % B,
+                   "global_batch": world * B, "parallelism": "dp%d" % world},
+        "roofline": {"kernel": "gemm_nt_kernel<4> (decoder-step forward GEMMs: LSTM gates, dec_att, predict, prologue)",
+                     "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "avg_launch_us": avg_us.value, "launches": nl.value, "bytes_per_launch": bpl.value,
+                     "mfma_f32_tflops": ach_tf, "mfma_f32_frac": ach_tf / MFMA_F32_PEAK_TFLOPS},
+    }
+    if not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(words, args.cpu_rows)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

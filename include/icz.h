@@ -172,6 +172,13 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
                  size_t workspace_floats, void* stream);
 size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
 
+/* Live timing of the dominant kernel (gemm_nt_kernel<4>: every forward GEMM of the decoder step) with HIP events on
+ * its launch stream, for bench.py's roofline line.  Between begin and end every launch is bracketed by an event
+ * pair; end synchronises on them and reports the average duration [us] and the ALGORITHMIC bytes / flops per launch
+ * (A read once + W read once + C written once; 2MNK). */
+int icz_prof_begin(void);
+int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,4 +1,6 @@
 // fp32 MFMA GEMMs (see gemm_f32.h for the tiling rationale).  gfx950 only.
+#include <vector>
+
 #include "gemm_f32.h"
 
 namespace icz {
@@ -345,6 +347,24 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// Optional timing of every gemm_nt_kernel<4> launch with HIP events on the launch stream (bench.py's live
+// roofline measurement).  Off by default; nothing is recorded or allocated unless enabled.
+struct GemmProf {
+    bool on = false;
+    std::vector<hipEvent_t> ev;      // pairs
+    size_t used = 0;
+    double bytes = 0.0, flops = 0.0;
+};
+static GemmProf g_prof;
+
+static void prof_account(const GemmArgs& a) {
+    double kb = 0.0, k = 0.0;
+    for (int s = 0; s < a.nseg; ++s) { k += a.seg[s].K; }
+    kb = ((double)a.M * k + (double)a.N * k + (double)a.M * a.N) * 4.0;   // read A once, read W once, write C once
+    g_prof.bytes += kb;
+    g_prof.flops += 2.0 * a.M * a.N * k;
+}
+
 size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N : 0; }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs) {
@@ -397,7 +417,22 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, mt * 16), a.nsplit);
         if (mt == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, stream, a);
         else if (mt == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, stream, a);
-        else hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, block, 0, stream, a);
+        else {
+            hipEvent_t e0 = nullptr, e1 = nullptr;
+            if (g_prof.on) {
+                if (g_prof.used + 2 > g_prof.ev.size()) {
+                    for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) g_prof.ev.push_back(e); }
+                }
+                if (g_prof.used + 2 <= g_prof.ev.size()) {
+                    e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
+                    g_prof.used += 2;
+                    prof_account(a);
+                    (void)hipEventRecord(e0, stream);
+                }
+            }
+            hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, block, 0, stream, a);
+            if (e1) (void)hipEventRecord(e1, stream);
+        }
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
         hipLaunchKernelGGL(gemm_nn_kernel, grid, block, 0, stream, a);
@@ -409,4 +444,31 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     return ICZ_OK;
 }
 
+void gemm_prof_begin() {
+    g_prof.on = true; g_prof.used = 0; g_prof.bytes = 0.0; g_prof.flops = 0.0;
+}
+int gemm_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
+    g_prof.on = false;
+    const size_t n = g_prof.used / 2;
+    double tot_ms = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        ICZ_CHECK_HIP(hipEventSynchronize(g_prof.ev[2 * i + 1]));
+        float ms = 0.f;
+        ICZ_CHECK_HIP(hipEventElapsedTime(&ms, g_prof.ev[2 * i], g_prof.ev[2 * i + 1]));
+        tot_ms += ms;
+    }
+    if (avg_us) *avg_us = n ? tot_ms * 1e3 / (double)n : 0.0;
+    if (bytes_per_launch) *bytes_per_launch = n ? g_prof.bytes / (double)n : 0.0;
+    if (flops_per_launch) *flops_per_launch = n ? g_prof.flops / (double)n : 0.0;
+    if (launches) *launches = (long long)n;
+    return ICZ_OK;
+}
+
 }  // namespace icz
+
+extern "C" {
+int icz_prof_begin(void) { icz::gemm_prof_begin(); return ICZ_OK; }
+int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
+    return icz::gemm_prof_end(avg_us, bytes_per_launch, flops_per_launch, launches);
+}
+}

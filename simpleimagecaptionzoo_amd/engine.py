@@ -105,6 +105,9 @@ class BUTDDetection_Eng(Engine):
     def modify_visual_inputs(self, img_tensors, supp_info_datas=None):
         """BUTD_Engine.py:23-47: stack per-image (n_i, D) features into (B, max_n, D) fp32 + mask (None if all
         rows are full).  Staged through a reusable pinned buffer and copied asynchronously."""
+        if isinstance(supp_info_datas, dict) and torch.is_tensor(supp_info_datas.get("bu_feats")):
+            # extension: a batch already resident in HBM (prefetching loaders, bench.py)
+            return {"bu_feats": supp_info_datas["bu_feats"], "bu_bboxes": supp_info_datas.get("bu_bboxes"), "bu_masks": None}
         bu_feats = [s["bu_feat"] for s in supp_info_datas]
         bu_bboxes = [s["bu_bbox"] for s in supp_info_datas]
         max_len = max(f.shape[0] for f in bu_feats)

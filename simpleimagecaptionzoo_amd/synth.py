@@ -37,3 +37,35 @@ def random_butd_params(R, D, H, E, A, V, device, seed=1234):
     p["predict.weight_g"] = v.norm(dim=1, keepdim=True)
     p["predict.bias"] = torch.zeros(V)
     return {k_: t.to(device=device, dtype=torch.float32).contiguous() for k_, t in p.items()}
+
+
+def synthetic_references(n_img, vocab_words, seed=0, min_len=8, max_len=12):
+    """5 references per image, length U{8..12}, Zipf(1.3) tokens over the vocabulary."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    V = len(vocab_words)
+    gts = {}
+    for i in range(n_img):
+        refs = []
+        for _ in range(5):
+            L = rng.randint(min_len, max_len + 1)
+            z = np.minimum(rng.zipf(1.3, size=L), V - 4) - 1 + 4      # skip the 4 special tokens
+            refs.append(" ".join(vocab_words[j] for j in z))
+        gts[i] = refs
+    return gts
+
+
+def document_frequency(gts):
+    """The rule of PreProcess/CIDEr_idf_preproccess.py:41-83: df[ngram] = number of images whose references contain
+    it (n = 1..4); ref_len = number of images."""
+    df = {}
+    for refs in gts.values():
+        seen = set()
+        for ref in refs:
+            w = ref.split()
+            for k in range(1, 5):
+                for i in range(len(w) - k + 1):
+                    seen.add(tuple(w[i:i + k]))
+        for g in seen:
+            df[g] = df.get(g, 0.0) + 1.0
+    return {"document_frequency": df, "ref_len": len(gts)}
