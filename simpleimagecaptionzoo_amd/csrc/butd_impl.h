@@ -42,6 +42,7 @@ struct TrainBuf {
     float* X[4] = {nullptr, nullptr, nullptr, nullptr}; size_t xfloats = 0;
     float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;
     int* scalars_i = nullptr; int scalars_i_cap = 0;
+    float* colsum_part = nullptr;
 };
 
 struct BeamBuf {
@@ -54,6 +55,7 @@ struct BeamBuf {
 struct Butd {
     static constexpr int TARGET_WGS = 512;   // ~2 workgroups per CU on 256 CUs
     static constexpr int ATT_PARTS = 4;
+    static constexpr int COLSUM_PARTS = 64;
     icz_butd_dims dims;
     icz_butd_params P;
     bool bound = false, fresh = false;
@@ -108,6 +110,7 @@ struct Butd {
     int xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
     int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
     int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);
+    int colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st);
     int bptt(const icz_butd_params& G, hipStream_t st);
 };
 

@@ -636,14 +636,23 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(AttBwdArgs a, DropCfg dc) 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// out[n] = sum_k X[k, n] (column sums over K rows; bias gradients).  Fixed order -> reproducible.
-// grid.x covers N in chunks of 256 columns; blockDim 256; each thread owns a column and 4 row-lanes are not
-// needed: K is a few thousand at most.
-__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int K, int N, int ldx, float* __restrict__ out) {
+// out[n] = sum_k X[k, n] (column sums over K rows; bias gradients), two stages, fixed order -> reproducible:
+// stage 1: grid (N/256, KS) -- block (x, y) sums rows [y*rows_per, (y+1)*rows_per) of its 256 columns into part[y, n];
+// stage 2: out[n] = sum_y part[y, n].
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int K, int N, int ldx, int rows_per,
+                                                          float* __restrict__ part) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int k0 = blockIdx.y * rows_per, k1 = min(K, k0 + rows_per);
+    float s = 0.f;
+    for (int k = k0; k < k1; ++k) s += X[(size_t)k * ldx + n];
+    part[(size_t)blockIdx.y * N + n] = s;
+}
+__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int KS, int N, float* __restrict__ out) {
     const int n = blockIdx.x * 256 + threadIdx.x;
     if (n >= N) return;
     float s = 0.f;
-    for (int k = 0; k < K; ++k) s += X[(size_t)k * ldx + n];
+    for (int y = 0; y < KS; ++y) s += part[(size_t)y * N + n];
     out[n] = s;
 }
 

@@ -64,6 +64,11 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dWdec, sizeof(float) * A * H));
     ICZ_TRY(zalloc((void**)&tb.dWaff, sizeof(float) * A));
     ICZ_TRY(zalloc((void**)&tb.scalars, sizeof(float) * 16));
+    {
+        size_t nmax = Vp > 4 * H ? Vp : 4 * H;
+        if (A > nmax) nmax = A;
+        ICZ_TRY(zalloc((void**)&tb.colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
+    }
     (void)V;
     tb.B = B;
     tb.T = T;
@@ -316,6 +321,16 @@ int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N,
     return gemm_f32(GEMM_TN, g, st);
 }
 
+int Butd::colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st) {
+    int KS = cdiv(K, 16);
+    if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
+    const int rows_per = cdiv(K, KS);
+    KS = cdiv(K, rows_per);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), KS), dim3(256), 0, st, X, K, N, ldx, rows_per, tb.colsum_part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, tb.colsum_part, KS, N, out);
+    return ICZ_OK;
+}
+
 int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     const int B = cur_B, T = cur_T;
     const int H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
@@ -337,7 +352,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, H, (const float*)nullptr, tb.dH2d);
         }
         ICZ_TRY(wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, st));
-        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 256)), dim3(256), 0, st, tb.logit, TB, V, Vp, G.predict_b);
+        ICZ_TRY(colsum(tb.logit, TB, V, Vp, G.predict_b, st));
         hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
                            G.predict_v, G.predict_g, V, H);
     }
@@ -452,13 +467,13 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
     ICZ_TRY(wgrad(tb.dEnc, A, A, feats, D, D, B * R, tb.dWenc, D, st));
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(4 * H, 256)), dim3(256), 0, st, tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih);
+    ICZ_TRY(colsum(tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih, st));
+    ICZ_TRY(colsum(tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih, st));
     ICZ_CHECK_HIP(hipMemcpyAsync(G.td_b_hh, G.td_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lm_b_hh, G.lm_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dDec, TB, A, A, G.dec_att_b);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dEnc, B * R, A, A, G.enc_att_b);
-    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(A, 256)), dim3(256), 0, st, tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff);
+    ICZ_TRY(colsum(tb.dDec, TB, A, A, G.dec_att_b, st));
+    ICZ_TRY(colsum(tb.dEnc, B * R, A, A, G.enc_att_b, st));
+    ICZ_TRY(colsum(tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff, st));
     // d loss / d affine.bias is identically zero (softmax shift invariance)
     ICZ_CHECK_HIP(hipMemsetAsync(G.affine_b, 0, sizeof(float), st));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc,

@@ -8,54 +8,83 @@ namespace icz {
 // ------------------------------------------------------------------------------------------------
 // chunk bookkeeping: the K dimension is the concatenation of the segments, cut into 64-deep chunks
 // (a segment's last chunk may be partial; loads beyond K are zero-filled).
-struct ChunkPos { int seg; int k0; };
-
-__device__ __forceinline__ ChunkPos locate_chunk(const GemmArgs& a, int chunk) {
-    ChunkPos p; p.seg = 0; p.k0 = 0;
-    int c = chunk;
-#pragma unroll
-    for (int s = 0; s < GEMM_MAX_SEG; ++s) {
-        if (s < a.nseg) {
-            int n = (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
-            if (c < n || s == a.nseg - 1) { p.seg = s; p.k0 = c * GEMM_BK; return p; }
-            c -= n;
-        }
-    }
-    return p;
-}
-
 static int total_chunks(const GemmArgs& a) {
     int t = 0;
     for (int s = 0; s < a.nseg; ++s) t += cdiv(a.seg[s].K, GEMM_BK);
     return t;
 }
 
-__device__ __forceinline__ f32x4 ld4(const float* p, bool ok) {
-    f32x4 z = {0.f, 0.f, 0.f, 0.f};
-    return ok ? *reinterpret_cast<const f32x4*>(p) : z;
+// Walks the chunk sequence of one split: (segment, k offset) advance with scalar arithmetic only; the segment's
+// operand descriptors are re-read from the kernel arguments only when the segment changes.
+struct ChunkCursor {
+    int seg, k0;
+    const float* A; const float* B;
+    int lda, ldb, K;
+    __device__ __forceinline__ void load_seg(const GemmArgs& a) {
+        const GemmSeg& g = a.seg[seg];
+        A = g.A; B = g.B; lda = g.lda; ldb = g.ldb; K = g.K;
+    }
+    __device__ __forceinline__ void seek(const GemmArgs& a, int chunk) {
+        seg = 0;
+        int c = chunk;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG - 1; ++s) {
+            if (seg == s && s < a.nseg - 1) {
+                int n = (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+                if (c >= n) { c -= n; seg = s + 1; }
+            }
+        }
+        k0 = c * GEMM_BK;
+        load_seg(a);
+    }
+    __device__ __forceinline__ void next(const GemmArgs& a) {
+        k0 += GEMM_BK;
+        if (k0 >= K && seg < a.nseg - 1) { ++seg; k0 = 0; load_seg(a); }
+    }
+};
+
+__device__ __forceinline__ int split_range(const GemmArgs& a, int z, int* c_end_out) {
+    const int c_begin = z * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    int tot = 0;
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s)
+        if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+    *c_end_out = c_end > tot ? tot : c_end;
+    return c_begin;
+}
+
+// unconditional 16-byte load from a (clamped, always valid) address; zero-filled by a select when !ok.
+// No branch -> the compiler issues a chunk's loads back to back and waits only at their first use.
+// TAIL = false (every segment's K is a multiple of 64, the production shapes): a plain load, so nothing consumes
+// the value before the MFMA block and the loads stay in flight behind it.
+template <bool TAIL>
+__device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p);
+    if (TAIL) {
+        f32x4 z = {0.f, 0.f, 0.f, 0.f};
+        return ok ? v : z;
+    }
+    return v;
 }
 
 // ------------------------------------------------------------------------------------------------
 // NT: C = X W^T.  A chunk through LDS (shared by the 4 waves), W fragments straight to registers.
 // Lane (i = lane&15, q = lane>>4).  MFMA operand maps (16x16x4 f32): A[i][k=q], B[k=q][j=i];
 // one float4 along k per lane feeds 4 MFMAs (component c <-> k = 16s + 4q + c, same on both operands).
-template <int MT>
+// Rows beyond M / columns beyond N are read from a clamped (valid) row: they only feed accumulator rows /
+// columns that are never stored, so no zero-fill is needed; only the K tail must be zero.
+template <int MT, bool TAIL>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * GEMM_LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * (MT * 16), z = blockIdx.z;
-    const int c_begin = z * a.chunks_per_split;
-    int c_end = c_begin + a.chunks_per_split;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int s = 0; s < GEMM_MAX_SEG; ++s)
-            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
-        if (c_end > tot) c_end = tot;
-    }
+    int c_end;
+    const int c_begin = split_range(a, z, &c_end);
     const int ncol = n0 + wave * 16 + li;          // this lane's W row (= output column)
     const bool ncol_ok = ncol < a.N;
+    const size_t ncol_c = ncol_ok ? ncol : a.N - 1;
 
     f32x4 acc[MT];
 #pragma unroll
@@ -64,56 +93,48 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int XL = (MT * 16 * 16 + 255) / 256;   // float4 staging loads per thread per chunk
     f32x4 xr[XL];
     f32x4 wcur[4], wnxt[4];
+    size_t xrow[XL];
+    int xlds[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int idx = tid + 256 * j;
+        int row = idx >> 4;
+        if (row > MT * 16 - 1) row = MT * 16 - 1;
+        int m = m0 + row;
+        if (m > a.M - 1) m = a.M - 1;
+        xrow[j] = (size_t)m;
+        xlds[j] = row * GEMM_LDS_STRIDE + 4 * (idx & 15);
+    }
+    const int xk = 4 * (tid & 15);
 
-    auto load_chunk = [&](int chunk, f32x4 (&w)[4]) {
-        ChunkPos p = locate_chunk(a, chunk);
-        const GemmSeg& sg = a.seg[p.seg];
-        // W fragments: row ncol, k = k0 + 16s + 4q
+    ChunkCursor cc;
+    auto load_chunk = [&](f32x4 (&w)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            int k = p.k0 + 16 * s + 4 * lq;
-            w[s] = ld4(sg.B + (size_t)ncol * sg.ldb + k, ncol_ok && k < sg.K);
+            const int k = cc.k0 + 16 * s + 4 * lq;
+            const int kc = k < cc.K ? k : cc.K - 4;
+            w[s] = ld4z<TAIL>(cc.B + ncol_c * cc.ldb + kc, k < cc.K);
         }
-        // A staging: idx -> (row, c4)
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
-            int idx = tid + 256 * j;
-            int row = idx >> 4, c4 = idx & 15;
-            int m = m0 + row, k = p.k0 + 4 * c4;
-            bool ok = (row < MT * 16) && (m < a.M) && (k < sg.K);
-            const float* src;
-            if (sg.gather) {
-                int64_t g = ok ? sg.gather[m] : 0;
-                src = sg.A + (size_t)g * sg.lda + k;
-            } else {
-                src = sg.A + (size_t)m * sg.lda + k;
-            }
-            f32x4 v = ld4(src, ok);
-            if (sg.gather) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            xr[j] = v;
+            const int k = cc.k0 + xk;
+            const int kc = k < cc.K ? k : cc.K - 4;
+            xr[j] = ld4z<TAIL>(cc.A + xrow[j] * cc.lda + kc, k < cc.K);
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < XL; ++j) {
-            int idx = tid + 256 * j;
-            int row = idx >> 4, c4 = idx & 15;
-            if (row < MT * 16)
-                *reinterpret_cast<f32x4*>(&lds[buf][row * GEMM_LDS_STRIDE + 4 * c4]) = xr[j];
-        }
+        for (int j = 0; j < XL; ++j)
+            if (MT * 16 * 16 >= 256 * (j + 1) || tid + 256 * j < MT * 16 * 16)
+                *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
     };
 
     if (c_begin < c_end) {
-        load_chunk(c_begin, wcur);
+        cc.seek(a, c_begin);
+        load_chunk(wcur);
         store_stage(0);
         __syncthreads();
-        for (int c = c_begin; c < c_end; ++c) {
-            const int buf = (c - c_begin) & 1;
-            const bool more = (c + 1 < c_end);
-            if (more) load_chunk(c + 1, wnxt);
+        auto compute = [&](int buf, const f32x4 (&w)[4]) {
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 f32x4 af[MT];
@@ -125,13 +146,26 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
                 for (int e = 0; e < 4; ++e) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], wcur[s][e], acc[t], 0, 0, 0);
+                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], w[s][e], acc[t], 0, 0, 0);
                 }
             }
-            if (more) store_stage(buf ^ 1);
+        };
+        // two chunks per iteration with ping-pong W register sets (no register copies between chunks)
+        int c = c_begin;
+        while (c < c_end) {
+            bool more = (c + 1 < c_end);
+            if (more) { cc.next(a); load_chunk(wnxt); }
+            compute(0, wcur);
+            if (more) store_stage(1);
             __syncthreads();
-#pragma unroll
-            for (int s = 0; s < 4; ++s) wcur[s] = wnxt[s];
+            ++c;
+            if (c >= c_end) break;
+            more = (c + 1 < c_end);
+            if (more) { cc.next(a); load_chunk(wcur); }
+            compute(1, wnxt);
+            if (more) store_stage(0);
+            __syncthreads();
+            ++c;
         }
     }
 
@@ -168,62 +202,56 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 // Mirror image of NT: the B chunk (64 k x 64 n, shared by the 4 waves) goes through LDS, each wave owns 16
 // rows and all 64 columns; A fragments straight to registers.  Column tiles are interleaved: a lane's
 // float4 along n at [k][4i..4i+3] supplies column 4i+j to column tile j, so one ds_read_b128 feeds 4 MFMAs.
+template <bool TAIL>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float lds[2][GEMM_BK * GEMM_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM, z = blockIdx.z;
-    const int c_begin = z * a.chunks_per_split;
-    int c_end = c_begin + a.chunks_per_split;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int s = 0; s < GEMM_MAX_SEG; ++s)
-            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
-        if (c_end > tot) c_end = tot;
-    }
+    int c_end;
+    const int c_begin = split_range(a, z, &c_end);
     const int mrow = m0 + wave * 16 + li;
-    const bool mrow_ok = mrow < a.M;
+    const size_t mrow_c = mrow < a.M ? mrow : a.M - 1;
 
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
     f32x4 br[4];
     f32x4 acur[4], anxt[4];
+    // B staging: thread -> (row = idx>>4, n = n0 + 4*(idx&15)); columns beyond N are clamped (never stored)
+    int bn = n0 + 4 * (tid & 15);
+    if (bn > a.N - 4) bn = a.N - 4;
 
-    auto load_chunk = [&](int chunk, f32x4 (&av)[4]) {
-        ChunkPos p = locate_chunk(a, chunk);
-        const GemmSeg& sg = a.seg[p.seg];
+    ChunkCursor cc;
+    auto load_chunk = [&](f32x4 (&av)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            int k = p.k0 + 16 * s + 4 * lq;
-            av[s] = ld4(sg.A + (size_t)mrow * sg.lda + k, mrow_ok && k < sg.K);
+            const int k = cc.k0 + 16 * s + 4 * lq;
+            const int kc = k < cc.K ? k : cc.K - 4;
+            av[s] = ld4z<TAIL>(cc.A + mrow_c * cc.lda + kc, k < cc.K);
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int idx = tid + 256 * j;
-            int row = idx >> 4, c4 = idx & 15;
-            int k = p.k0 + row, n = n0 + 4 * c4;
-            br[j] = ld4(sg.B + (size_t)k * sg.ldb + n, (k < sg.K) && (n < a.N));
+            const int k = cc.k0 + (tid >> 4) + 16 * j;
+            const int kc = k < cc.K ? k : cc.K - 1;
+            br[j] = ld4z<TAIL>(cc.B + (size_t)kc * cc.ldb + bn, k < cc.K);
         }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            int idx = tid + 256 * j;
-            int row = idx >> 4, c4 = idx & 15;
-            *reinterpret_cast<f32x4*>(&lds[buf][row * GEMM_BN + 4 * c4]) = br[j];
-        }
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<f32x4*>(&lds[buf][((tid >> 4) + 16 * j) * GEMM_BN + 4 * (tid & 15)]) = br[j];
     };
 
     if (c_begin < c_end) {
-        load_chunk(c_begin, acur);
+        cc.seek(a, c_begin);
+        load_chunk(acur);
         store_stage(0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
             const int buf = (c - c_begin) & 1;
             const bool more = (c + 1 < c_end);
-            if (more) load_chunk(c + 1, anxt);
+            if (more) { cc.next(a); load_chunk(anxt); }
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
 #pragma unroll
@@ -269,48 +297,51 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
 // takes a quarter of the chunk's k range and the whole 64 x 64 tile (16 accumulators); a lane's float4 along
 // m (resp. n) at row k supplies row 4i+j to row tile j (resp. column 4i+j to column tile j): 2 loads feed
 // 16 MFMAs.  The four waves' partial tiles are summed through LDS at the end.
+template <bool TAIL>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
     __shared__ __attribute__((aligned(16))) float red[3][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM, z = blockIdx.z;
-    const int c_begin = z * a.chunks_per_split;
-    int c_end = c_begin + a.chunks_per_split;
-    {
-        int tot = 0;
-#pragma unroll
-        for (int s = 0; s < GEMM_MAX_SEG; ++s)
-            if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
-        if (c_end > tot) c_end = tot;
-    }
+    int c_end;
+    const int c_begin = split_range(a, z, &c_end);
     f32x4 acc[4][4];
 #pragma unroll
     for (int t = 0; t < 4; ++t)
 #pragma unroll
         for (int u = 0; u < 4; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int mcol = m0 + 4 * li, ncol = n0 + 4 * li;
-    const bool m_ok = mcol < a.M, n_ok = ncol < a.N;
+    int mcol = m0 + 4 * li, ncol = n0 + 4 * li;
+    if (mcol > a.M - 4) mcol = a.M - 4;      // clamped columns feed only never-stored outputs
+    if (ncol > a.N - 4) ncol = a.N - 4;
 
-    for (int c = c_begin; c < c_end; ++c) {
-        ChunkPos p = locate_chunk(a, c);
-        const GemmSeg& sg = a.seg[p.seg];
-        // wave w handles k = k0 + 16w + 4s' + q   (s' = 0..3)
-        f32x4 av[4], bv[4];
+    ChunkCursor cc;
+    f32x4 av[4], bv[4], an[4], bn_[4];
+    auto load_chunk = [&](f32x4 (&x)[4], f32x4 (&y)[4]) {
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
-            int k = p.k0 + 16 * wave + 4 * s + lq;
-            bool kok = k < sg.K;
-            av[s] = ld4(sg.A + (size_t)k * sg.lda + mcol, kok && m_ok);
-            bv[s] = ld4(sg.B + (size_t)k * sg.ldb + ncol, kok && n_ok);
+            const int k = cc.k0 + 16 * wave + 4 * s + lq;
+            const int kc = k < cc.K ? k : cc.K - 1;
+            x[s] = ld4z<TAIL>(cc.A + (size_t)kc * cc.lda + mcol, k < cc.K);
+            y[s] = ld4z<TAIL>(cc.B + (size_t)kc * cc.ldb + ncol, k < cc.K);
         }
+    };
+    if (c_begin < c_end) {
+        cc.seek(a, c_begin);
+        load_chunk(av, bv);
+        for (int c = c_begin; c < c_end; ++c) {
+            const bool more = (c + 1 < c_end);
+            if (more) { cc.next(a); load_chunk(an, bn_); }
 #pragma unroll
-        for (int s = 0; s < 4; ++s)
+            for (int s = 0; s < 4; ++s)
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
+                for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int u = 0; u < 4; ++u)
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[s][u], acc[t][u], 0, 0, 0);
+                    for (int u = 0; u < 4; ++u)
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[s][t], bv[s][u], acc[t][u], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) { av[s] = an[s]; bv[s] = bn_[s]; }
+        }
     }
     // acc[t][u][r] <-> row m0 + 4*(4q + r) + t, column n0 + 4*i + u.  Tile-local (row, col) in [0,64)^2.
     // waves 1..3 park their tiles in LDS, wave 0 sums in fixed order (bitwise reproducible).
@@ -389,6 +420,7 @@ static int check_args(GemmLayout layout, const GemmArgs& a) {
         ICZ_REQUIRE(g.A && g.B && g.K > 0, "gemm: segment %d null operand or K<=0", s);
         ICZ_REQUIRE(((uintptr_t)g.A & 15) == 0 && ((uintptr_t)g.B & 15) == 0, "gemm: segment %d operands must be 16-byte aligned", s);
         ICZ_REQUIRE(g.lda % 4 == 0 && g.ldb % 4 == 0, "gemm: segment %d leading dims must be multiples of 4 (lda %d ldb %d)", s, g.lda, g.ldb);
+        ICZ_REQUIRE(!g.gather, "gemm: row gather is not supported");
         if (layout == GEMM_NT) {
             ICZ_REQUIRE(g.K % 4 == 0, "gemm NT: segment %d K=%d must be a multiple of 4", s, g.K);
         } else if (layout == GEMM_NN) {
@@ -412,33 +444,35 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     a.chunks_per_split = cdiv(tot, a.nsplit);
     ICZ_REQUIRE(cdiv(tot, a.chunks_per_split) == a.nsplit, "gemm: nsplit %d leaves empty splits (chunks %d)", a.nsplit, tot);
     dim3 block(256);
+    bool tail = false;
+    for (int s = 0; s < a.nseg; ++s) tail |= (a.seg[s].K % GEMM_BK) != 0;
     if (layout == GEMM_NT) {
         int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, mt * 16), a.nsplit);
-        if (mt == 1) hipLaunchKernelGGL(gemm_nt_kernel<1>, grid, block, 0, stream, a);
-        else if (mt == 2) hipLaunchKernelGGL(gemm_nt_kernel<2>, grid, block, 0, stream, a);
-        else {
-            hipEvent_t e0 = nullptr, e1 = nullptr;
-            if (g_prof.on) {
-                if (g_prof.used + 2 > g_prof.ev.size()) {
-                    for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) g_prof.ev.push_back(e); }
-                }
-                if (g_prof.used + 2 <= g_prof.ev.size()) {
-                    e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
-                    g_prof.used += 2;
-                    prof_account(a);
-                    (void)hipEventRecord(e0, stream);
-                }
+        hipEvent_t e0 = nullptr, e1 = nullptr;
+        if (g_prof.on && mt == 4) {
+            if (g_prof.used + 2 > g_prof.ev.size()) {
+                for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) g_prof.ev.push_back(e); }
             }
-            hipLaunchKernelGGL(gemm_nt_kernel<4>, grid, block, 0, stream, a);
-            if (e1) (void)hipEventRecord(e1, stream);
+            if (g_prof.used + 2 <= g_prof.ev.size()) {
+                e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
+                g_prof.used += 2;
+                prof_account(a);
+                (void)hipEventRecord(e0, stream);
+            }
         }
+        if (mt == 1) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, block, 0, stream, a); }
+        else if (mt == 2) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, block, 0, stream, a); }
+        else { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), grid, block, 0, stream, a); }
+        if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
-        hipLaunchKernelGGL(gemm_nn_kernel, grid, block, 0, stream, a);
+        if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
     } else {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
-        hipLaunchKernelGGL(gemm_tn_kernel, grid, block, 0, stream, a);
+        if (tail) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, stream, a);
+        else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, stream, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
