@@ -304,7 +304,7 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
     g.nseg = 1;
     g.seg[0] = {X, W, ldx, ldw, K, nullptr};
     g.M = M; g.N = N; g.out = C; g.ldo = ldc; g.bias = bias;
-    g.nsplit = nsplit > 0 ? nsplit : gemm_pick_split(g, Butd::TARGET_WGS);
+    g.nsplit = nsplit > 0 ? nsplit : gemm_pick_split(g, Butd::TARGET_WGS, (GemmLayout)layout);
     {   // normalise a caller-chosen split so that no split is empty
         int tot = cdiv(K, GEMM_BK);
         if (g.nsplit > tot) g.nsplit = tot;

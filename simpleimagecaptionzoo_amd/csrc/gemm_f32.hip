@@ -72,27 +72,35 @@ __device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
 // NT: C = X W^T.  A chunk through LDS (shared by the 4 waves), W fragments straight to registers.
 // Lane (i = lane&15, q = lane>>4).  MFMA operand maps (16x16x4 f32): A[i][k=q], B[k=q][j=i];
 // one float4 along k per lane feeds 4 MFMAs (component c <-> k = 16s + 4q + c, same on both operands).
+// Wave w owns NTW adjacent 16-column tiles and all MT row tiles: NTW = 2 halves the activation traffic and the
+// LDS reads / barriers per MFMA (workgroup tile 64 x 128).
 // Rows beyond M / columns beyond N are read from a clamped (valid) row: they only feed accumulator rows /
-// columns that are never stored, so no zero-fill is needed; only the K tail must be zero.
-template <int MT, bool TAIL>
+// columns that are never stored, so no zero-fill is needed; only the K tail must be zero (TAIL variant).
+template <int MT, int NTW, bool TAIL>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int BN = 64 * NTW;
     __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * GEMM_LDS_STRIDE];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
-    const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * (MT * 16), z = blockIdx.z;
+    const int n0 = blockIdx.x * BN, m0 = blockIdx.y * (MT * 16), z = blockIdx.z;
     int c_end;
     const int c_begin = split_range(a, z, &c_end);
-    const int ncol = n0 + wave * 16 + li;          // this lane's W row (= output column)
-    const bool ncol_ok = ncol < a.N;
-    const size_t ncol_c = ncol_ok ? ncol : a.N - 1;
-
-    f32x4 acc[MT];
+    int ncol[NTW];
+    size_t ncol_c[NTW];
 #pragma unroll
-    for (int t = 0; t < MT; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int nt = 0; nt < NTW; ++nt) {
+        ncol[nt] = n0 + (wave * NTW + nt) * 16 + li;        // this lane's W row (= output column) of tile nt
+        ncol_c[nt] = ncol[nt] < a.N ? ncol[nt] : a.N - 1;
+    }
+
+    f32x4 acc[MT][NTW];
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     constexpr int XL = (MT * 16 * 16 + 255) / 256;   // float4 staging loads per thread per chunk
     f32x4 xr[XL];
-    f32x4 wcur[4], wnxt[4];
     size_t xrow[XL];
     int xlds[XL];
 #pragma unroll
@@ -107,80 +115,134 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     }
     const int xk = 4 * (tid & 15);
 
+    // chunk cursor with per-lane operand pointers: inside a segment a chunk step is "pointer += 64 floats"
     ChunkCursor cc;
-    auto load_chunk = [&](f32x4 (&w)[4]) {
+    const float* wp[NTW];
+    const float* xp[XL];
+    auto set_ptrs = [&]() {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            const int k = cc.k0 + 16 * s + 4 * lq;
-            const int kc = k < cc.K ? k : cc.K - 4;
-            w[s] = ld4z<TAIL>(cc.B + ncol_c * cc.ldb + kc, k < cc.K);
+        for (int nt = 0; nt < NTW; ++nt) wp[nt] = cc.B + ncol_c[nt] * cc.ldb + cc.k0 + 4 * lq;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) xp[j] = cc.A + xrow[j] * cc.lda + cc.k0 + xk;
+    };
+    auto advance = [&]() {
+        const int seg0 = cc.seg;
+        cc.next(a);
+        if (cc.seg != seg0) set_ptrs();
+        else {
+#pragma unroll
+            for (int nt = 0; nt < NTW; ++nt) wp[nt] += GEMM_BK;
+#pragma unroll
+            for (int j = 0; j < XL; ++j) xp[j] += GEMM_BK;
         }
+    };
+    // X first, W second: the LDS store of X only has to wait for the X loads (vmcnt is in issue order), the W loads
+    // of the chunk after next stay in flight across the barrier.
+    auto load_chunk = [&](f32x4 (&w)[NTW][4]) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
-            const int k = cc.k0 + xk;
-            const int kc = k < cc.K ? k : cc.K - 4;
-            xr[j] = ld4z<TAIL>(cc.A + xrow[j] * cc.lda + kc, k < cc.K);
+            if (TAIL) {
+                const int k = cc.k0 + xk;
+                xr[j] = ld4z<true>(k < cc.K ? xp[j] : xp[j] - (k - (cc.K - 4)), k < cc.K);
+            } else {
+                xr[j] = *reinterpret_cast<const f32x4*>(xp[j]);
+            }
         }
+#pragma unroll
+        for (int nt = 0; nt < NTW; ++nt)
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                if (TAIL) {
+                    const int k = cc.k0 + 16 * s + 4 * lq;
+                    w[nt][s] = ld4z<true>(k < cc.K ? wp[nt] + 16 * s : wp[nt] + 16 * s - (k - (cc.K - 4)), k < cc.K);
+                } else {
+                    w[nt][s] = *reinterpret_cast<const f32x4*>(wp[nt] + 16 * s);
+                }
+            }
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < XL; ++j)
-            if (MT * 16 * 16 >= 256 * (j + 1) || tid + 256 * j < MT * 16 * 16)
-                *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
+            *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
     };
-
-    if (c_begin < c_end) {
-        cc.seek(a, c_begin);
-        load_chunk(wcur);
-        store_stage(0);
-        __syncthreads();
-        auto compute = [&](int buf, const f32x4 (&w)[4]) {
+    // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer), so the LDS
+    // latency hides behind the MFMAs instead of stalling the wave four times per chunk.
+    auto compute = [&](int buf, const f32x4 (&w)[NTW][4]) {
+        f32x4 af[2][MT];
+        const float* base = &lds[buf][li * GEMM_LDS_STRIDE + 4 * lq];
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                f32x4 af[MT];
+        for (int t = 0; t < MT; ++t) af[0][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * GEMM_LDS_STRIDE);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+            if (s < 3) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    af[t] = *reinterpret_cast<const f32x4*>(
-                        &lds[buf][(t * 16 + li) * GEMM_LDS_STRIDE + 16 * s + 4 * lq]);
+                    af[(s + 1) & 1][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * GEMM_LDS_STRIDE + 16 * (s + 1));
+            }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[t][e], w[s][e], acc[t], 0, 0, 0);
-                }
-            }
+                        acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][t][e], w[nt][s][e], acc[t][nt], 0, 0, 0);
+        }
+    };
+
+    // Software pipeline, prefetch distance 2 chunks: while chunk i is multiplied, the loads of chunk i+2 are in
+    // flight (W into a ring of 3 register sets, X into registers and, after the barrier that retires the reads of
+    // chunk i, into the LDS buffer chunk i used).  One barrier per chunk.
+    const int n = c_end - c_begin;
+    f32x4 w0[NTW][4], w1[NTW][4], w2[NTW][4];
+    if (n > 0) {
+        cc.seek(a, c_begin);
+        set_ptrs();
+        load_chunk(w0);
+        store_stage(0);
+        if (n > 1) { advance(); load_chunk(w1); store_stage(1); }
+        __syncthreads();
+        // steady state (chunk i+2 exists): branch-free body = one scheduling region
+        auto body = [&](int i, const f32x4 (&wuse)[NTW][4], f32x4 (&wload)[NTW][4]) {
+            advance();
+            load_chunk(wload);
+            // keep the loads HERE: without the fence hipcc sinks them below the MFMAs, next to their first use (the
+            // LDS store after the barrier), and every chunk then waits a full memory latency
+            __builtin_amdgcn_sched_barrier(0);
+            compute(i & 1, wuse);
+            __syncthreads();
+            store_stage(i & 1);
         };
-        // two chunks per iteration with ping-pong W register sets (no register copies between chunks)
-        int c = c_begin;
-        while (c < c_end) {
-            bool more = (c + 1 < c_end);
-            if (more) { cc.next(a); load_chunk(wnxt); }
-            compute(0, wcur);
-            if (more) store_stage(1);
+        auto tail_body = [&](int i, const f32x4 (&wuse)[NTW][4]) {
+            compute(i & 1, wuse);
             __syncthreads();
-            ++c;
-            if (c >= c_end) break;
-            more = (c + 1 < c_end);
-            if (more) { cc.next(a); load_chunk(wcur); }
-            compute(1, wnxt);
-            if (more) store_stage(0);
-            __syncthreads();
-            ++c;
+        };
+        int i = 0;
+        for (; i + 2 < n; i += 3) {
+            body(i, w0, w2);
+            if (i + 3 < n) body(i + 1, w1, w0); else { tail_body(i + 1, w1); if (i + 2 < n) tail_body(i + 2, w2); i = n; break; }
+            if (i + 4 < n) body(i + 2, w2, w1); else { tail_body(i + 2, w2); if (i + 3 < n) tail_body(i + 3, w0); i = n; break; }
+        }
+        // at most two chunks are left, already loaded (ring slots 0 and 1 because i % 3 == 0)
+        if (i < n) {
+            tail_body(i, w0);
+            if (i + 1 < n) tail_body(i + 1, w1);
         }
     }
 
-    // epilogue: acc[t][r] <-> row m0 + 16t + 4q + r, column ncol
-    if (ncol_ok) {
+    // epilogue: acc[t][nt][r] <-> row m0 + 16t + 4q + r, column ncol[nt]
+#pragma unroll
+    for (int nt = 0; nt < NTW; ++nt) {
+        if (ncol[nt] >= a.N) continue;
         if (a.nsplit == 1) {
-            const float b = a.bias ? a.bias[ncol] : 0.f;
+            const float b = a.bias ? a.bias[ncol[nt]] : 0.f;
 #pragma unroll
             for (int t = 0; t < MT; ++t)
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int m = m0 + 16 * t + 4 * lq + r;
                     if (m < a.M) {
-                        float* o = a.out + (size_t)m * a.ldo + ncol;
-                        float v = acc[t][r] + b;
+                        float* o = a.out + (size_t)m * a.ldo + ncol[nt];
+                        float v = acc[t][nt][r] + b;
                         *o = a.accumulate ? (*o + v) : v;
                     }
                 }
@@ -191,7 +253,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) {
                     int m = m0 + 16 * t + 4 * lq + r;
-                    if (m < a.M) slab[(size_t)m * a.N + ncol] = acc[t][r];
+                    if (m < a.M) slab[(size_t)m * a.N + ncol[nt]] = acc[t][nt][r];
                 }
         }
     }
@@ -398,8 +460,14 @@ static void prof_account(const GemmArgs& a) {
 
 size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N : 0; }
 
-int gemm_pick_split(const GemmArgs& a, int target_wgs) {
-    int tiles = cdiv(a.N, GEMM_BN) * cdiv(a.M, GEMM_BM);
+// NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
+static int nt_tile_n(const GemmArgs& a) {
+    if (a.M <= 32) return 64;
+    return 64;   // the 64x128 tile needs 336 VGPRs with the 3-deep W ring (1 wave per SIMD) and measured slower
+}
+
+int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
+    int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
     int tot = total_chunks(a);
     int s = target_wgs / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -448,7 +516,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     for (int s = 0; s < a.nseg; ++s) tail |= (a.seg[s].K % GEMM_BK) != 0;
     if (layout == GEMM_NT) {
         int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
-        dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, mt * 16), a.nsplit);
+        const int bn = nt_tile_n(a);
+        dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
         hipEvent_t e0 = nullptr, e1 = nullptr;
         if (g_prof.on && mt == 4) {
             if (g_prof.used + 2 > g_prof.ev.size()) {
@@ -461,9 +530,10 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
                 (void)hipEventRecord(e0, stream);
             }
         }
-        if (mt == 1) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<1, false>), grid, block, 0, stream, a); }
-        else if (mt == 2) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<2, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<2, false>), grid, block, 0, stream, a); }
-        else { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, false>), grid, block, 0, stream, a); }
+        if (mt == 1) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<1, 1, false>), grid, block, 0, stream, a); }
+        else if (mt == 2) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<2, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<2, 1, false>), grid, block, 0, stream, a); }
+        else if (bn == 128) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, false>), grid, block, 0, stream, a); }
+        else { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false>), grid, block, 0, stream, a); }
         if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
