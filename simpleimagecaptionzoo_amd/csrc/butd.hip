@@ -52,7 +52,9 @@ int Butd::init(const icz_butd_dims& d) {
     ICZ_TRY(alloc((void**)&scores, sizeof(float) * rows * R));
     ICZ_TRY(alloc((void**)&alpha, sizeof(float) * rows * R));
     ICZ_TRY(alloc((void**)&h2drop, sizeof(float) * rows * H));
-    ICZ_TRY(alloc((void**)&logits, sizeof(float) * rows * V));
+    ICZ_TRY(alloc((void**)&logits, sizeof(float) * rows * Vp));      // rows padded to Vp: 16-byte aligned rows
+    ICZ_TRY(alloc((void**)&amax_val, sizeof(float) * rows * ARGMAX_PARTS));
+    ICZ_TRY(alloc((void**)&amax_idx, sizeof(int) * rows * ARGMAX_PARTS));
     ICZ_TRY(alloc((void**)&it, sizeof(int64_t) * rows));
     size_t nmax = 4 * H;
     if (A > nmax) nmax = A;
@@ -130,10 +132,12 @@ int Butd::prologue(const float* feats, int n_img, hipStream_t st) {
 // One decoder step (:172-182) for `rows` decoder rows.  State is read from s.*_in and written to s.*_out.
 int Butd::step(const StepIO& s, hipStream_t st) {
     const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A, V = dims.V;
+    const int Vp = (V + 3) & ~3;
     const int rows = s.rows;
     DropCfg off = {0, nullptr, 0, 0, 0};
-    // embedding -> relu -> dropout
-    hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb_out ? s.emb_out : emb, rows, E, s.drop_emb);
+    // embedding -> relu -> dropout (greedy decode gets it from the previous step's fused argmax epilogue)
+    if (!s.emb_ready)
+        hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb_out ? s.emb_out : emb, rows, E, s.drop_emb);
     const float* embp = s.emb_out ? s.emb_out : emb;
     int ns;
     {   // TD-attention LSTM: [h2, mean, emb] W_ih^T + h1 W_hh^T  (mean part hoisted into premean)
@@ -143,27 +147,26 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {embp, P.td_w_ih + H + D, E, H + D + E, E, nullptr};
         g.seg[2] = {s.h1_in, P.td_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-        g.nsplit = gemm_pick_split(g, TARGET_WGS);
-        if (g.nsplit == 1) g.nsplit = 1;
+        g.nsplit = gemm_pick_split(g, STEP_WGS);
         ns = g.nsplit;
         ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_floats && (size_t)rows * 4 * H <= ws_floats, "butd: workspace too small");
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
-        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, a, off);
+        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, off);
     }
     {   // attention
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {s.h1_out, w_dec, H, H, H, nullptr};
         g.M = rows; g.N = A; g.out = ws; g.ldo = A;
-        g.nsplit = gemm_pick_split(g, TARGET_WGS);
+        g.nsplit = gemm_pick_split(g, STEP_WGS);
         ns = g.nsplit;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         const int parts = rows >= 128 ? 1 : (rows >= 32 ? 4 : 8);
         AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A};
         hipLaunchKernelGGL(att_scores_kernel, dim3(rows, parts), dim3(256), sizeof(float) * A, st, a, s.drop_att);
-        hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 1024)), dim3(256), 0, st, s.feats, s.img_of_row, scores,
+        hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 256)), dim3(256), 0, st, s.feats, s.img_of_row, scores,
                            s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D);
     }
     const float* ctxp = s.ctx_out ? s.ctx_out : ctx;
@@ -174,18 +177,18 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {s.h1_out, P.lm_w_ih + D, H, D + H, H, nullptr};
         g.seg[2] = {s.h2_in, P.lm_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-        g.nsplit = gemm_pick_split(g, TARGET_WGS);
+        g.nsplit = gemm_pick_split(g, STEP_WGS);
         ns = g.nsplit;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
-        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, a, s.drop_out);
+        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, s.drop_out);
     }
     {   // predict: logits = drop(h2) w_pred^T + b   (K = H is short: no split-K, bias fused)
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {s.h2drop_out ? s.h2drop_out : h2drop, w_pred, H, H, H, nullptr};
-        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : V; g.bias = P.predict_b;
+        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : Vp; g.bias = P.predict_b;
         g.nsplit = 1;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     }
@@ -208,14 +211,18 @@ int Butd::greedy(const float* feats, int B, int max_len, int64_t* ids_out, float
     ICZ_TRY(zero_state(B, 0, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
     int cur = 0;
+    const int Vp = (dims.V + 3) & ~3;
     for (int t = 0; t < max_len; ++t) {
         StepIO s = {};
         s.rows = B; s.feats = feats; s.it = it;
+        s.emb_ready = t > 0;           // produced by the previous step's embed_argmax_kernel
         s.h1_in = h1[cur]; s.c1_in = c1[cur]; s.h2_in = h2[cur]; s.c2_in = c2[cur];
         s.h1_out = h1[cur ^ 1]; s.c1_out = c1[cur ^ 1]; s.h2_out = h2[cur ^ 1]; s.c2_out = c2[cur ^ 1];
         if (alphas_out) { s.alpha_out2 = alphas_out + (size_t)t * dims.R; s.alpha2_stride = max_len * dims.R; }
         ICZ_TRY(step(s, st));
-        hipLaunchKernelGGL(argmax_kernel, dim3(B), dim3(256), 0, st, logits, dims.V, it, ids_out, max_len, t);
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
+        hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
+                           P.embed_weight, dims.E, emb, it, ids_out, max_len, t);
         cur ^= 1;
     }
     ICZ_CHECK_HIP(hipGetLastError());
@@ -284,7 +291,7 @@ int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* i
     // in-place update is safe: every consumer of *_in has been launched before the kernel that overwrites it
     // only if input/output buffers differ, so run into the handle's buffers and copy back.
     s.h1_out = b->h1[0]; s.c1_out = b->c1[0]; s.h2_out = b->h2[0]; s.c2_out = b->c2[0];
-    s.ctx_out = ctx_out; s.alpha_out = alpha_out; s.logits_out = logits_out;
+    s.ctx_out = ctx_out; s.alpha_out = alpha_out; s.logits_out = logits_out; s.logits_ld = b->dims.V;
     ICZ_TRY(b->step(s, st));
     const size_t n = sizeof(float) * B * b->dims.H;
     ICZ_CHECK_HIP(hipMemcpyAsync(h1, b->h1[0], n, hipMemcpyDeviceToDevice, st));
@@ -305,11 +312,7 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
     g.seg[0] = {X, W, ldx, ldw, K, nullptr};
     g.M = M; g.N = N; g.out = C; g.ldo = ldc; g.bias = bias;
     g.nsplit = nsplit > 0 ? nsplit : gemm_pick_split(g, Butd::TARGET_WGS, (GemmLayout)layout);
-    {   // normalise a caller-chosen split so that no split is empty
-        int tot = cdiv(K, GEMM_BK);
-        if (g.nsplit > tot) g.nsplit = tot;
-        g.nsplit = cdiv(tot, cdiv(tot, g.nsplit));
-    }
+    g.nsplit = gemm_normalize_split((GemmLayout)layout, g, g.nsplit);   // no empty splits
     hipStream_t st = (hipStream_t)stream;
     if (g.nsplit > 1) {
         ICZ_REQUIRE(workspace, "icz_gemm_f32: split-K needs a workspace");

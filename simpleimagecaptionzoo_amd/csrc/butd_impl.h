@@ -13,6 +13,7 @@ struct StepIO {
     const float* feats;              // [n_img, R, D]
     const int32_t* img_of_row;       // beam search: image of each decoder row; null = identity
     const int64_t* it;               // [rows] input token ids
+    bool emb_ready;                  // the embedding of `it` is already in the emb buffer (skip embed_kernel)
     const float *h1_in, *c1_in, *h2_in, *c2_in;
     float *h1_out, *c1_out, *h2_out, *c2_out;
     float* emb_out;                  // [rows,E]
@@ -55,6 +56,8 @@ struct BeamBuf {
 struct Butd {
     static constexpr int TARGET_WGS = 512;   // ~2 workgroups per CU on 256 CUs
     static constexpr int ATT_PARTS = 4;
+    static constexpr int STEP_WGS = 256;     // skinny decoder-step GEMMs: split-K for ~1 workgroup per CU
+    static constexpr int ARGMAX_PARTS = 8;
     static constexpr int COLSUM_PARTS = 64;
     icz_butd_dims dims;
     icz_butd_params P;
@@ -70,6 +73,7 @@ struct Butd {
     float *h1[2], *c1[2], *h2[2], *c2[2];
     float *emb = nullptr, *ctx = nullptr, *scores = nullptr, *alpha = nullptr, *h2drop = nullptr, *logits = nullptr;
     int64_t* it = nullptr;
+    float* amax_val = nullptr; int* amax_idx = nullptr;
     float* ws = nullptr;
     size_t ws_floats = 0;
 

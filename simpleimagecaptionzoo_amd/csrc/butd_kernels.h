@@ -92,54 +92,52 @@ struct LstmPointArgs {
     float* hdrop_out;                              // [rows,H] or null
     int rows, H;
 };
+// sum of ns split-K slabs at one element, loads issued four at a time (independent), added in slab order
+__device__ __forceinline__ float sum_slabs1(const float* __restrict__ p, int ns, size_t stride, size_t off) {
+    float s = 0.f;
+    int z = 0;
+    for (; z + 4 <= ns; z += 4) {
+        const float a = p[(size_t)z * stride + off], b = p[(size_t)(z + 1) * stride + off];
+        const float c = p[(size_t)(z + 2) * stride + off], d = p[(size_t)(z + 3) * stride + off];
+        s += a; s += b; s += c; s += d;
+    }
+    for (; z < ns; ++z) s += p[(size_t)z * stride + off];
+    return s;
+}
+
+// grid (H/256, rows): one hidden unit per thread (4-byte accesses, 256 B per wave instruction, 4x the workgroups of
+// a float4 layout -- at 64 rows the kernel is latency-bound, not bandwidth-bound)
 __global__ __launch_bounds__(256) void lstm_point_kernel(LstmPointArgs a, DropCfg dc) {
     const int row = blockIdx.y;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.H) return;
     const int H = a.H, G = 4 * H;
     const size_t MN = (size_t)a.rows * G;
-    f32x4 gt[4];
+    float gt[4];
+    const int pr = (a.pre && a.pre_row) ? a.pre_row[row] : row;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const size_t off = (size_t)row * G + q * H + j;
-        f32x4 s = *reinterpret_cast<const f32x4*>(a.slab + off);
-        for (int z = 1; z < a.nsplit; ++z) s += *reinterpret_cast<const f32x4*>(a.slab + (size_t)z * MN + off);
-        if (a.pre) {
-            const int pr = a.pre_row ? a.pre_row[row] : row;
-            s += *reinterpret_cast<const f32x4*>(a.pre + (size_t)pr * G + q * H + j);
-        }
-        s += *reinterpret_cast<const f32x4*>(a.b_ih + q * H + j);
-        s += *reinterpret_cast<const f32x4*>(a.b_hh + q * H + j);
+        float s = sum_slabs1(a.slab, a.nsplit, MN, off);
+        if (a.pre) s += a.pre[(size_t)pr * G + q * H + j];
+        s += a.b_ih[q * H + j];
+        s += a.b_hh[q * H + j];
         gt[q] = s;
     }
-    f32x4 cp = *reinterpret_cast<const f32x4*>(a.c_prev + (size_t)row * H + j);
-    f32x4 hn, cn, gi, gf, gg, go;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        gi[e] = sigmoidf_(gt[0][e]);
-        gf[e] = sigmoidf_(gt[1][e]);
-        gg[e] = tanhf(gt[2][e]);
-        go[e] = sigmoidf_(gt[3][e]);
-        cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-        hn[e] = go[e] * tanhf(cn[e]);
-    }
-    *reinterpret_cast<f32x4*>(a.h_out + (size_t)row * H + j) = hn;
-    *reinterpret_cast<f32x4*>(a.c_out + (size_t)row * H + j) = cn;
+    const float cp = a.c_prev[(size_t)row * H + j];
+    const float gi = sigmoidf_(gt[0]), gf = sigmoidf_(gt[1]), gg = tanhf(gt[2]), go = sigmoidf_(gt[3]);
+    const float cn = gf * cp + gi * gg;
+    const float hn = go * tanhf(cn);
+    a.h_out[(size_t)row * H + j] = hn;
+    a.c_out[(size_t)row * H + j] = cn;
     if (a.gates_out) {
         float* go_ = a.gates_out + (size_t)row * G + j;
-        *reinterpret_cast<f32x4*>(go_) = gi;
-        *reinterpret_cast<f32x4*>(go_ + H) = gf;
-        *reinterpret_cast<f32x4*>(go_ + 2 * H) = gg;
-        *reinterpret_cast<f32x4*>(go_ + 3 * H) = go;
+        go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
     }
     if (a.hdrop_out) {
-        f32x4 hd = hn;
-        if (dc.mode) {
-            uint32_t k = dc.keep4((uint64_t)row * H + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hd[e] = ((k >> e) & 1u) ? hn[e] * 2.0f : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(a.hdrop_out + (size_t)row * H + j) = hd;
+        float hd = hn;
+        if (dc.mode) hd = dc.keep((uint64_t)row * H + j) ? hn * 2.0f : 0.f;
+        a.hdrop_out[(size_t)row * H + j] = hd;
     }
 }
 
@@ -207,6 +205,7 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
                                                       const float* __restrict__ scores, float* __restrict__ alpha_out,
                                                       float* __restrict__ alpha_out2, int alpha2_stride,
                                                       float* __restrict__ ctx, int R, int D) {
+    // grid (rows, D/256): one feature column per thread, 36 independent coalesced loads (1 KiB per wave each)
     const int row = blockIdx.x;
     const int lane = threadIdx.x & 63;
     const float sc = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
@@ -218,47 +217,69 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
         alpha_out[(size_t)row * R + threadIdx.x] = al;
         if (alpha_out2) alpha_out2[(size_t)row * alpha2_stride + threadIdx.x] = al;
     }
-    const int d = (blockIdx.y * 256 + threadIdx.x) * 4;
+    const int d = blockIdx.y * 256 + threadIdx.x;
     const bool valid = d < D;            // no early return: every lane must stay active for the shuffles
     const int img = img_of_row ? img_of_row[row] : row;
     const float* f = feats + (size_t)img * R * D + (valid ? d : 0);
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    float acc = 0.f;
     for (int r = 0; r < R; ++r) {
         const float w = __shfl(al, r, 64);
-        if (valid) acc += *reinterpret_cast<const f32x4*>(f + (size_t)r * D) * w;
+        acc += f[(size_t)r * D] * w;
     }
-    if (valid) *reinterpret_cast<f32x4*>(ctx + (size_t)row * D + d) = acc;
+    if (valid) ctx[(size_t)row * D + d] = acc;
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// greedy epilogue (:183): id = argmax_v logits[row, v] (first maximum wins, as torch.max does)
-__global__ __launch_bounds__(256) void argmax_kernel(const float* __restrict__ logits, int V, int64_t* __restrict__ it_next,
-                                                     int64_t* __restrict__ ids_out, int ids_stride, int t) {
+// greedy epilogue (:183): id = argmax_v logits[row, v] (first maximum wins, as torch.max does), in two stages:
+//   argmax_part_kernel  grid (rows, P): block-wide (value, index) of its slice of the vocabulary -> part[row, p]
+//   embed_argmax_kernel grid (E/1024, rows): reduces the P partials (tiny), records the id, and gathers the next
+//                       step's embedding row (Embedding -> ReLU; eval mode, no dropout) in the same launch.
+__device__ __forceinline__ void argmax_combine(float& best, int& bi, float ob, int oi) {
+    if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+}
+__global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ logits, int V, int ldl, int P,
+                                                          float* __restrict__ part_val, int* __restrict__ part_idx) {
     __shared__ float sv[4];
     __shared__ int si[4];
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const float* l = logits + (size_t)row * V;
+    const int row = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int per = ((V + P - 1) / P + 3) & ~3;
+    const int v0 = p * per, v1 = min(V, v0 + per);
+    const float* l = logits + (size_t)row * ldl;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = tid; v < V; v += 256) {
-        float x = l[v];
+    for (int v = v0 + tid; v < v1; v += 256) {
+        const float x = l[v];
         if (x > best) { best = x; bi = v; }
     }
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) {
-        float ob = __shfl_xor(best, o, 64);
-        int oi = __shfl_xor(bi, o, 64);
-        if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
-    }
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
     if (lane == 0) { sv[wave] = best; si[wave] = bi; }
     __syncthreads();
     if (tid == 0) {
 #pragma unroll
-        for (int w = 1; w < 4; ++w)
-            if (sv[w] > best || (sv[w] == best && si[w] < bi)) { best = sv[w]; bi = si[w]; }
+        for (int w = 1; w < 4; ++w) argmax_combine(best, bi, sv[w], si[w]);
+        part_val[row * P + p] = best;
+        part_idx[row * P + p] = bi;
+    }
+}
+__global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int P,
+                                                           const float* __restrict__ table, int E, float* __restrict__ emb,
+                                                           int64_t* __restrict__ it_next, int64_t* __restrict__ ids_out,
+                                                           int ids_stride, int t) {
+    const int row = blockIdx.y;
+    float best = part_val[row * P];
+    int bi = part_idx[row * P];
+    for (int p = 1; p < P; ++p) argmax_combine(best, bi, part_val[row * P + p], part_idx[row * P + p]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
         it_next[row] = bi;
         if (ids_out) ids_out[(size_t)row * ids_stride + t] = bi;
     }
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= E) return;
+    f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)bi * E + e);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+    *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
@@ -311,6 +332,7 @@ struct SampleSelArgs {
     float* lse_out;               // [rows] max + log(sum exp) (for backward)
 };
 __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the row, then its probabilities
     __shared__ float smf[4];
     __shared__ double smd[256];
     __shared__ int smi[4];
@@ -327,21 +349,23 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
         return;
     }
     const float* l = a.logits + (size_t)row * a.ldl;
+    // one coalesced pass over HBM/L2; every later pass (any access pattern) runs out of LDS
     float mx = -INFINITY;
-    for (int v = tid; v < a.V; v += 256) mx = fmaxf(mx, l[v]);
+    for (int v = tid; v < a.V; v += 256) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
     mx = block_max_256(mx, smf);
     float se = 0.f;
-    for (int v = tid; v < a.V; v += 256) se += expf(l[v] - mx);
+    for (int v = tid; v < a.V; v += 256) se += expf(srow[v] - mx);
     se = block_sum_256(se, smf);
     const float lse = logf(se);
-    // contiguous slice per thread
+    for (int v = tid; v < a.V; v += 256) srow[v] = expf((srow[v] - mx) - lse);     // p = exp(log_softmax)
+    __syncthreads();
+    // contiguous slice per thread -> the global "first index above target" is the minimum over threads
     const int per = (a.V + 255) / 256;
     const int v0 = tid * per, v1 = min(a.V, v0 + per);
     double loc = 0.0;
-    for (int v = v0; v < v1; ++v) loc += (double)expf((l[v] - mx) - lse);
+    for (int v = v0; v < v1; ++v) loc += (double)srow[v];
     smd[tid] = loc;
     __syncthreads();
-    // exclusive prefix by a single wave-free serial pass per thread is O(256^2); do a Hillis-Steele scan instead
     for (int o = 1; o < 256; o <<= 1) {
         double x = (tid >= o) ? smd[tid - o] : 0.0;
         __syncthreads();
@@ -356,7 +380,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     {
         double run = prefix;
         for (int v = v0; v < v1; ++v) {
-            run += (double)expf((l[v] - mx) - lse);
+            run += (double)srow[v];
             if (run > target) { cand = v; break; }
         }
     }

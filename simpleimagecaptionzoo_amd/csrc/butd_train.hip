@@ -133,7 +133,7 @@ int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* se
         a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tb.tok + (size_t)(t + 1) * B;
         a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
-        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), sizeof(float) * dims.V, st, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     cur_seq = seq_out; cur_logp = logp_out;

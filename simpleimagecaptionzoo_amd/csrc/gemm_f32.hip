@@ -1,4 +1,6 @@
 // fp32 MFMA GEMMs (see gemm_f32.h for the tiling rationale).  gfx950 only.
+#include <stdlib.h>
+
 #include <vector>
 
 #include "gemm_f32.h"
@@ -8,9 +10,9 @@ namespace icz {
 // ------------------------------------------------------------------------------------------------
 // chunk bookkeeping: the K dimension is the concatenation of the segments, cut into 64-deep chunks
 // (a segment's last chunk may be partial; loads beyond K are zero-filled).
-static int total_chunks(const GemmArgs& a) {
+static int total_chunks(const GemmArgs& a, int bk = GEMM_BK) {
     int t = 0;
-    for (int s = 0; s < a.nseg; ++s) t += cdiv(a.seg[s].K, GEMM_BK);
+    for (int s = 0; s < a.nseg; ++s) t += cdiv(a.seg[s].K, bk);
     return t;
 }
 
@@ -72,19 +74,28 @@ __device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
 // NT: C = X W^T.  A chunk through LDS (shared by the 4 waves), W fragments straight to registers.
 // Lane (i = lane&15, q = lane>>4).  MFMA operand maps (16x16x4 f32): A[i][k=q], B[k=q][j=i];
 // one float4 along k per lane feeds 4 MFMAs (component c <-> k = 16s + 4q + c, same on both operands).
-// Wave w owns NTW adjacent 16-column tiles and all MT row tiles: NTW = 2 halves the activation traffic and the
-// LDS reads / barriers per MFMA (workgroup tile 64 x 128).
+// Wave w owns NTW adjacent 16-column tiles and all MT row tiles.  BKC = K depth of one pipeline stage (64 or 128):
+// per stage a wave issues BKC/4 * MT * NTW MFMAs between two barriers; the deeper stage halves the per-stage
+// overhead (barrier, waits, address arithmetic) per MFMA.
 // Rows beyond M / columns beyond N are read from a clamped (valid) row: they only feed accumulator rows /
 // columns that are never stored, so no zero-fill is needed; only the K tail must be zero (TAIL variant).
-template <int MT, int NTW, bool TAIL>
+template <int MT, int NTW, bool TAIL, int BKC>
 __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     constexpr int BN = 64 * NTW;
-    __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * GEMM_LDS_STRIDE];
+    constexpr int LDSS = BKC + 8;                 // dwords per staged A row; (LDSS/4) mod 16 == 2 -> conflict-free b128 reads
+    constexpr int NS = BKC / 16;                  // k-groups (of 16) per stage
+    __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * LDSS];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * BN, m0 = blockIdx.y * (MT * 16), z = blockIdx.z;
-    int c_end;
-    const int c_begin = split_range(a, z, &c_end);
+    // stage range of this split (stages are counted in units of BKC; a.chunks_per_split is in the same unit)
+    int tot = 0;
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s)
+        if (s < a.nseg) tot += (a.seg[s].K + BKC - 1) / BKC;
+    const int c_begin = z * a.chunks_per_split;
+    const int c_end = min(tot, c_begin + a.chunks_per_split);
+
     int ncol[NTW];
     size_t ncol_c[NTW];
 #pragma unroll
@@ -92,58 +103,73 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         ncol[nt] = n0 + (wave * NTW + nt) * 16 + li;        // this lane's W row (= output column) of tile nt
         ncol_c[nt] = ncol[nt] < a.N ? ncol[nt] : a.N - 1;
     }
-
     f32x4 acc[MT][NTW];
 #pragma unroll
     for (int t = 0; t < MT; ++t)
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    constexpr int XL = (MT * 16 * 16 + 255) / 256;   // float4 staging loads per thread per chunk
+    constexpr int C4 = BKC / 4;                              // float4 per staged row
+    constexpr int XL = (MT * 16 * C4 + 255) / 256;           // float4 staging loads per thread per stage
     f32x4 xr[XL];
     size_t xrow[XL];
-    int xlds[XL];
+    int xlds[XL], xkk[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
         const int idx = tid + 256 * j;
-        int row = idx >> 4;
+        int row = idx / C4;
         if (row > MT * 16 - 1) row = MT * 16 - 1;
         int m = m0 + row;
         if (m > a.M - 1) m = a.M - 1;
         xrow[j] = (size_t)m;
-        xlds[j] = row * GEMM_LDS_STRIDE + 4 * (idx & 15);
+        xkk[j] = 4 * (idx % C4);
+        xlds[j] = row * LDSS + xkk[j];
     }
-    const int xk = 4 * (tid & 15);
 
-    // chunk cursor with per-lane operand pointers: inside a segment a chunk step is "pointer += 64 floats"
-    ChunkCursor cc;
+    // stage cursor: (segment, k0) + per-lane operand pointers; inside a segment a step is "pointer += BKC floats"
+    int seg = 0, k0 = 0, segK = 0;
+    const float *segA = nullptr, *segB = nullptr;
+    int lda = 0, ldb = 0;
     const float* wp[NTW];
     const float* xp[XL];
-    auto set_ptrs = [&]() {
+    auto load_seg = [&]() {
+        const GemmSeg& g = a.seg[seg];
+        segA = g.A; segB = g.B; lda = g.lda; ldb = g.ldb; segK = g.K;
 #pragma unroll
-        for (int nt = 0; nt < NTW; ++nt) wp[nt] = cc.B + ncol_c[nt] * cc.ldb + cc.k0 + 4 * lq;
+        for (int nt = 0; nt < NTW; ++nt) wp[nt] = segB + ncol_c[nt] * ldb + k0 + 4 * lq;
 #pragma unroll
-        for (int j = 0; j < XL; ++j) xp[j] = cc.A + xrow[j] * cc.lda + cc.k0 + xk;
+        for (int j = 0; j < XL; ++j) xp[j] = segA + xrow[j] * lda + k0 + xkk[j];
+    };
+    auto seek = [&](int stage) {
+        int c = stage;
+        seg = 0;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG - 1; ++s) {
+            if (seg == s && s < a.nseg - 1) {
+                const int nst = (a.seg[s].K + BKC - 1) / BKC;
+                if (c >= nst) { c -= nst; seg = s + 1; }
+            }
+        }
+        k0 = c * BKC;
+        load_seg();
     };
     auto advance = [&]() {
-        const int seg0 = cc.seg;
-        cc.next(a);
-        if (cc.seg != seg0) set_ptrs();
+        k0 += BKC;
+        if (k0 >= segK && seg < a.nseg - 1) { ++seg; k0 = 0; load_seg(); }
         else {
 #pragma unroll
-            for (int nt = 0; nt < NTW; ++nt) wp[nt] += GEMM_BK;
+            for (int nt = 0; nt < NTW; ++nt) wp[nt] += BKC;
 #pragma unroll
-            for (int j = 0; j < XL; ++j) xp[j] += GEMM_BK;
+            for (int j = 0; j < XL; ++j) xp[j] += BKC;
         }
     };
-    // X first, W second: the LDS store of X only has to wait for the X loads (vmcnt is in issue order), the W loads
-    // of the chunk after next stay in flight across the barrier.
-    auto load_chunk = [&](f32x4 (&w)[NTW][4]) {
+    // X first, W second: the LDS store of X only has to wait for the X loads (vmcnt is in issue order)
+    auto load_stage = [&](f32x4 (&w)[NTW][NS]) {
 #pragma unroll
         for (int j = 0; j < XL; ++j) {
             if (TAIL) {
-                const int k = cc.k0 + xk;
-                xr[j] = ld4z<true>(k < cc.K ? xp[j] : xp[j] - (k - (cc.K - 4)), k < cc.K);
+                const int k = k0 + xkk[j];
+                xr[j] = ld4z<true>(k < segK ? xp[j] : xp[j] - (k - (segK - 4)), k < segK);
             } else {
                 xr[j] = *reinterpret_cast<const f32x4*>(xp[j]);
             }
@@ -151,10 +177,10 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
         for (int nt = 0; nt < NTW; ++nt)
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NS; ++s) {
                 if (TAIL) {
-                    const int k = cc.k0 + 16 * s + 4 * lq;
-                    w[nt][s] = ld4z<true>(k < cc.K ? wp[nt] + 16 * s : wp[nt] + 16 * s - (k - (cc.K - 4)), k < cc.K);
+                    const int k = k0 + 16 * s + 4 * lq;
+                    w[nt][s] = ld4z<true>(k < segK ? wp[nt] + 16 * s : wp[nt] + 16 * s - (k - (segK - 4)), k < segK);
                 } else {
                     w[nt][s] = *reinterpret_cast<const f32x4*>(wp[nt] + 16 * s);
                 }
@@ -163,21 +189,21 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < XL; ++j)
-            *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
+            if ((MT * 16 * C4) % 256 == 0 || tid + 256 * j < MT * 16 * C4)
+                *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
     };
-    // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer), so the LDS
-    // latency hides behind the MFMAs instead of stalling the wave four times per chunk.
-    auto compute = [&](int buf, const f32x4 (&w)[NTW][4]) {
+    // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer)
+    auto compute = [&](int buf, const f32x4 (&w)[NTW][NS]) {
         f32x4 af[2][MT];
-        const float* base = &lds[buf][li * GEMM_LDS_STRIDE + 4 * lq];
+        const float* base = &lds[buf][li * LDSS + 4 * lq];
 #pragma unroll
-        for (int t = 0; t < MT; ++t) af[0][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * GEMM_LDS_STRIDE);
+        for (int t = 0; t < MT; ++t) af[0][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * LDSS);
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
-            if (s < 3) {
+        for (int s = 0; s < NS; ++s) {
+            if (s < NS - 1) {
 #pragma unroll
                 for (int t = 0; t < MT; ++t)
-                    af[(s + 1) & 1][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * GEMM_LDS_STRIDE + 16 * (s + 1));
+                    af[(s + 1) & 1][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * LDSS + 16 * (s + 1));
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e)
@@ -189,43 +215,34 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         }
     };
 
-    // Software pipeline, prefetch distance 2 chunks: while chunk i is multiplied, the loads of chunk i+2 are in
-    // flight (W into a ring of 3 register sets, X into registers and, after the barrier that retires the reads of
-    // chunk i, into the LDS buffer chunk i used).  One barrier per chunk.
+    // Software pipeline (double-buffered LDS + two W register sets): while stage i is multiplied, the loads of
+    // stage i+1 are in flight; they are stored to the other LDS buffer after the MFMAs.  One barrier per stage.
     const int n = c_end - c_begin;
-    f32x4 w0[NTW][4], w1[NTW][4], w2[NTW][4];
+    f32x4 wa[NTW][NS], wb[NTW][NS];
     if (n > 0) {
-        cc.seek(a, c_begin);
-        set_ptrs();
-        load_chunk(w0);
+        seek(c_begin);
+        load_stage(wa);
         store_stage(0);
-        if (n > 1) { advance(); load_chunk(w1); store_stage(1); }
         __syncthreads();
-        // steady state (chunk i+2 exists): branch-free body = one scheduling region
-        auto body = [&](int i, const f32x4 (&wuse)[NTW][4], f32x4 (&wload)[NTW][4]) {
+        auto body = [&](int buf, const f32x4 (&wuse)[NTW][NS], f32x4 (&wload)[NTW][NS]) {
             advance();
-            load_chunk(wload);
-            // keep the loads HERE: without the fence hipcc sinks them below the MFMAs, next to their first use (the
-            // LDS store after the barrier), and every chunk then waits a full memory latency
+            load_stage(wload);
+            // keep the loads HERE: without the fence hipcc sinks them below the MFMAs, next to their first use
             __builtin_amdgcn_sched_barrier(0);
-            compute(i & 1, wuse);
-            __syncthreads();
-            store_stage(i & 1);
-        };
-        auto tail_body = [&](int i, const f32x4 (&wuse)[NTW][4]) {
-            compute(i & 1, wuse);
+            compute(buf, wuse);
+            store_stage(buf ^ 1);
             __syncthreads();
         };
         int i = 0;
-        for (; i + 2 < n; i += 3) {
-            body(i, w0, w2);
-            if (i + 3 < n) body(i + 1, w1, w0); else { tail_body(i + 1, w1); if (i + 2 < n) tail_body(i + 2, w2); i = n; break; }
-            if (i + 4 < n) body(i + 2, w2, w1); else { tail_body(i + 2, w2); if (i + 3 < n) tail_body(i + 3, w0); i = n; break; }
+        for (; i + 2 < n; i += 2) {
+            body(0, wa, wb);
+            body(1, wb, wa);
         }
-        // at most two chunks are left, already loaded (ring slots 0 and 1 because i % 3 == 0)
-        if (i < n) {
-            tail_body(i, w0);
-            if (i + 1 < n) tail_body(i + 1, w1);
+        if (i + 1 < n) {            // two stages left
+            body(0, wa, wb);
+            compute(1, wb);
+        } else {                    // one stage left
+            compute(0, wa);
         }
     }
 
@@ -460,6 +477,17 @@ static void prof_account(const GemmArgs& a) {
 
 size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N : 0; }
 
+// NT pipeline-stage depth: 128 when every segment's K is a multiple of 128 and the tile is full height (MT = 4)
+static int nt_stage_k(const GemmArgs& a) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ICZ_GEMM_BK"); force = e ? atoi(e) : 0; }
+    if (a.M <= 32) return 64;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % 128) return 64;
+    return force == 64 ? 64 : 128;
+}
+static int stage_k(GemmLayout layout, const GemmArgs& a) { return layout == GEMM_NT ? nt_stage_k(a) : GEMM_BK; }
+
 // NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
 static int nt_tile_n(const GemmArgs& a) {
     if (a.M <= 32) return 64;
@@ -468,7 +496,7 @@ static int nt_tile_n(const GemmArgs& a) {
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
-    int tot = total_chunks(a);
+    int tot = total_chunks(a, stage_k(layout, a));
     int s = target_wgs / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
     if (s > tot) s = tot;
@@ -476,6 +504,13 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     // make every split non-empty
     int cps = cdiv(tot, s);
     return cdiv(tot, cps);
+}
+
+int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit) {
+    const int tot = total_chunks(a, stage_k(layout, a));
+    if (nsplit < 1) nsplit = 1;
+    if (nsplit > tot) nsplit = tot;
+    return cdiv(tot, cdiv(tot, nsplit));
 }
 
 static int check_args(GemmLayout layout, const GemmArgs& a) {
@@ -508,7 +543,7 @@ static int check_args(GemmLayout layout, const GemmArgs& a) {
 int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     ICZ_TRY(check_args(layout, a));
-    int tot = total_chunks(a);
+    int tot = total_chunks(a, stage_k(layout, a));
     a.chunks_per_split = cdiv(tot, a.nsplit);
     ICZ_REQUIRE(cdiv(tot, a.chunks_per_split) == a.nsplit, "gemm: nsplit %d leaves empty splits (chunks %d)", a.nsplit, tot);
     dim3 block(256);
@@ -530,10 +565,13 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
                 (void)hipEventRecord(e0, stream);
             }
         }
-        if (mt == 1) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<1, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<1, 1, false>), grid, block, 0, stream, a); }
-        else if (mt == 2) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<2, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<2, 1, false>), grid, block, 0, stream, a); }
-        else if (bn == 128) { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, 2, false>), grid, block, 0, stream, a); }
-        else { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, true>), grid, block, 0, stream, a); else hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false>), grid, block, 0, stream, a); }
+#define ICZ_NT(MT_, NTW_, BK_) do { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, true, BK_>), grid, block, 0, stream, a); \
+                                    else hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, false, BK_>), grid, block, 0, stream, a); } while (0)
+        if (mt == 1) ICZ_NT(1, 1, 64);
+        else if (mt == 2) ICZ_NT(2, 1, 64);
+        else if (nt_stage_k(a) == 128) ICZ_NT(4, 1, 128);
+        else ICZ_NT(4, 1, 64);
+#undef ICZ_NT
         if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
