@@ -65,6 +65,9 @@ int icz_butd_create(const icz_butd_dims* dims, icz_butd_t** out);
 int icz_butd_destroy(icz_butd_t* h);
 /* Bind the (caller-owned, device-resident) parameters; pointers must stay valid while the handle is used. */
 int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
+/* Options.  "graphs" = 1: greedy / sample / sample_backward are captured into hipGraphs on first use and replayed
+ * afterwards; the cache is keyed by every pointer and size in the call, so enable it only when buffers are reused. */
+int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
 /* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream);
 
@@ -134,6 +137,9 @@ int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* i
  * ---------------------------------------------------------------------------------------------------------- */
 int icz_adam_clamp_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
                         float lr, float clip, int32_t step, void* stream);
+/* The same update for `count` (<= 32) tensors in one launch; the pointer arrays are HOST arrays of device pointers. */
+int icz_adam_clamp_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, float lr, float clip, int32_t step, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * CIDEr-D reward (Utils.py:319-367 get_self_critical_reward -> ciderD.py:30-55 -> ciderD_scorer.py:127-206)

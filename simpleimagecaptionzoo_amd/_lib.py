@@ -68,6 +68,7 @@ def lib():
         "icz_butd_create": (C.c_int, [C.POINTER(ButdDims), C.POINTER(vp)]),
         "icz_butd_destroy": (C.c_int, [vp]),
         "icz_butd_bind_params": (C.c_int, [vp, C.POINTER(ButdParams)]),
+        "icz_butd_set_option": (C.c_int, [vp, C.c_char_p, i32]),
         "icz_butd_refresh_weights": (C.c_int, [vp, vp]),
         "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
@@ -85,6 +86,7 @@ def lib():
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
         "icz_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+        "icz_adam_clamp_multi": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, i32, vp]),
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
         "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),
     }

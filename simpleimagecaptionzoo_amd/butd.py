@@ -16,6 +16,8 @@ class ButdHandle:
         self.device = torch.device(device)
         self._h = C.c_void_p()
         self._params = None
+        self._persistent = False
+        self._bufs = {}
         dims = ButdDims(R, D, H, E, A, V, max_rows, max_len)
         with torch.cuda.device(self.device):
             check(lib().icz_butd_create(C.byref(dims), C.byref(self._h)))
@@ -30,6 +32,22 @@ class ButdHandle:
             self.close()
         except Exception:
             pass
+
+    def enable_graphs(self, on=True):
+        """Capture greedy / sample / sample_backward into hipGraphs and replay them.  Implies persistent output
+        buffers: the tensors returned by those calls are reused (overwritten) by the next call of the same shape."""
+        self._persistent = bool(on)
+        check(lib().icz_butd_set_option(self._h, b"graphs", 1 if on else 0))
+
+    def _buf(self, name, shape, dtype):
+        if not self._persistent:
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+        key = (name,) + tuple(shape)
+        t = self._bufs.get(key)
+        if t is None:
+            t = torch.zeros(shape, dtype=dtype, device=self.device)
+            self._bufs[key] = t
+        return t
 
     # ---- parameters ---------------------------------------------------------------------------
     def bind(self, tensors):
@@ -62,8 +80,8 @@ class ButdHandle:
         """DecoderRNN.sample (Models/BUTD_Model.py:153-189) -> ids (B,max_len) int64 [, alphas (B,max_len,R)]."""
         feats = self._check_feats(feats)
         B = feats.shape[0]
-        ids = torch.empty(B, max_len, dtype=torch.int64, device=feats.device)
-        alphas = torch.empty(B, max_len, self.R, dtype=torch.float32, device=feats.device) if want_alphas else None
+        ids = self._buf("greedy_ids", (B, max_len), torch.int64)
+        alphas = self._buf("greedy_alphas", (B, max_len, self.R), torch.float32) if want_alphas else None
         check(lib().icz_butd_greedy(self._h, ptr(feats), B, max_len, ptr(ids), ptr(alphas), stream_ptr()))
         return (ids, alphas) if want_alphas else ids
 
@@ -85,8 +103,8 @@ class ButdHandle:
         feats = self._check_feats(feats)
         B = feats.shape[0]
         rng = rng or make_rng(0)
-        seq = torch.zeros(B, max_len, dtype=torch.int64, device=feats.device)
-        lp = torch.zeros(B, max_len, dtype=torch.float32, device=feats.device)
+        seq = self._buf("sample_seq", (B, max_len), torch.int64)
+        lp = self._buf("sample_lp", (B, max_len), torch.float32)
         check(lib().icz_butd_sample(self._h, ptr(feats), B, max_len, C.byref(rng), ptr(seq), ptr(lp), stream_ptr()))
         self._live = (feats, rng, seq, lp)
         return seq, lp
@@ -100,8 +118,8 @@ class ButdHandle:
         """RewardCriterion + backward (Utils.py:295-317) for the last sample(); fills `grads`; returns
         (loss, local mask sum) as 1-element device tensors."""
         reward = reward.to(device=self.device, dtype=torch.float32).contiguous()
-        loss = torch.zeros(1, device=self.device)
-        msum = torch.zeros(1, device=self.device)
+        loss = self._buf("rl_loss", (1,), torch.float32)
+        msum = self._buf("rl_msum", (1,), torch.float32)
         gs = self._grad_struct(grads)
         check(lib().icz_butd_sample_backward(self._h, ptr(reward), C.byref(gs), ptr(loss), ptr(msum),
                                              float(mask_sum_global), stream_ptr()))

@@ -97,6 +97,8 @@ class CiderDReward:
         self._h = C.c_void_p()
         check(lib().icz_ciderd_create(ptr(self._keys), ptr(self._idf_t), cap, self.log_ref_len, ptr(self._pen),
                                       C.byref(self._h)))
+        self.persistent = False
+        self._out = {}
         self._cooked = {}                    # image id -> cooked reference arrays (host)
         self._batch_cache = {}
 
@@ -189,8 +191,15 @@ class CiderDReward:
         gen = gen.to(device=self.device, dtype=torch.int64).contiguous()
         greedy = greedy.to(device=self.device, dtype=torch.int64).contiguous()
         irp, rep, K, O, W, N, L = self._batch(list(img_ids), ground_truth)
-        reward = torch.empty(B, T, dtype=torch.float32, device=self.device)
-        scores = torch.empty(2 * B, dtype=torch.float64, device=self.device)
+        if self.persistent:       # stable addresses for hipGraph replay downstream (overwritten by the next call)
+            key = (B, T)
+            if key not in self._out:
+                self._out[key] = (torch.empty(B, T, dtype=torch.float32, device=self.device),
+                                  torch.empty(2 * B, dtype=torch.float64, device=self.device))
+            reward, scores = self._out[key]
+        else:
+            reward = torch.empty(B, T, dtype=torch.float32, device=self.device)
+            scores = torch.empty(2 * B, dtype=torch.float64, device=self.device)
         check(lib().icz_ciderd_reward(self._h, ptr(gen), ptr(greedy), B, T, ptr(irp), ptr(rep), ptr(K), ptr(O), ptr(W),
                                       ptr(N), ptr(L), ptr(reward), ptr(scores), stream_ptr()))
         return (reward, scores) if return_scores else reward

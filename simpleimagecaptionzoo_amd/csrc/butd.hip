@@ -56,6 +56,10 @@ int Butd::init(const icz_butd_dims& d) {
     ICZ_TRY(alloc((void**)&amax_val, sizeof(float) * rows * ARGMAX_PARTS));
     ICZ_TRY(alloc((void**)&amax_idx, sizeof(int) * rows * ARGMAX_PARTS));
     ICZ_TRY(alloc((void**)&it, sizeof(int64_t) * rows));
+    ICZ_TRY(alloc((void**)&d_seed, 16));
+    ICZ_TRY(alloc((void**)&d_msum_global, 16));
+    ICZ_CHECK_HIP(hipMemset(d_seed, 0, 16));
+    ICZ_CHECK_HIP(hipMemset(d_msum_global, 0, 16));
     size_t nmax = 4 * H;
     if (A > nmax) nmax = A;
     if (V > nmax) nmax = V;
@@ -65,6 +69,8 @@ int Butd::init(const icz_butd_dims& d) {
 }
 
 Butd::~Butd() {
+    for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
+    if (cap_st) (void)hipStreamDestroy(cap_st);
     for (void* p : allocs) (void)hipFree(p);
 }
 
@@ -134,7 +140,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
     const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A, V = dims.V;
     const int Vp = (V + 3) & ~3;
     const int rows = s.rows;
-    DropCfg off = {0, nullptr, 0, 0, 0};
+    DropCfg off = {0, nullptr, nullptr, 0, 0};
     // embedding -> relu -> dropout (greedy decode gets it from the previous step's fused argmax epilogue)
     if (!s.emb_ready)
         hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb_out ? s.emb_out : emb, rows, E, s.drop_emb);
@@ -207,6 +213,12 @@ int Butd::zero_state(int rows, int which, hipStream_t st) {
 
 int Butd::greedy(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
     ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && max_len > 0, "butd greedy: bad arguments");
+    ICZ_REQUIRE(fresh, "butd: call icz_butd_refresh_weights after binding/updating parameters");
+    const std::vector<uintptr_t> key = {1, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)max_len, (uintptr_t)ids_out, (uintptr_t)alphas_out};
+    return run_cached(key, st, [&](hipStream_t s) { return greedy_impl(feats, B, max_len, ids_out, alphas_out, s); });
+}
+
+int Butd::greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
     ICZ_TRY(prologue(feats, B, st));
     ICZ_TRY(zero_state(B, 0, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
@@ -265,6 +277,14 @@ int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* p) {
     b->bound = true;
     b->fresh = false;
     return ICZ_OK;
+}
+
+int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
+    ICZ_REQUIRE(h && name, "icz_butd_set_option: null argument");
+    Butd* b = reinterpret_cast<Butd*>(h);
+    if (strcmp(name, "graphs") == 0) { b->use_graphs = value != 0; return ICZ_OK; }
+    set_error("icz_butd_set_option: unknown option '%s'", name);
+    return ICZ_ERR_INVALID;
 }
 
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream) {

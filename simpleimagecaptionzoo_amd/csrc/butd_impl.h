@@ -1,6 +1,7 @@
 // Internal declarations of the BUTD decoder handle.
 #pragma once
 #include <vector>
+#include <stdint.h>
 
 #include "butd_kernels.h"
 #include "gemm_f32.h"
@@ -74,6 +75,8 @@ struct Butd {
     float *emb = nullptr, *ctx = nullptr, *scores = nullptr, *alpha = nullptr, *h2drop = nullptr, *logits = nullptr;
     int64_t* it = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
+    uint64_t* d_seed = nullptr;          // Philox seed of the current training-mode call (device resident)
+    float* d_msum_global = nullptr;      // data-parallel loss normaliser (0 = use the local one)
     float* ws = nullptr;
     size_t ws_floats = 0;
 
@@ -86,6 +89,19 @@ struct Butd {
     int step(const StepIO& s, hipStream_t st);
     int zero_state(int rows, int which, hipStream_t st);
     int greedy(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
+
+    // hipGraph cache: a whole rollout / backward is ~300-700 launches of 2-30 us kernels; replaying a captured graph
+    // removes the per-launch host cost and shrinks the inter-kernel gaps.  Keyed by every pointer / size baked into
+    // the captured kernel arguments, so it only pays when the caller reuses its buffers (the Engine does).
+    struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; uint64_t last_use; };
+    std::vector<GraphEntry> graphs;
+    bool use_graphs = false;
+    hipStream_t cap_st = nullptr;
+    uint64_t tick = 0;
+    template <class F> int run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn);
+    int greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
+    int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st);
 
     // beam search (butd_beam.hip)
     BeamBuf bm;
@@ -117,5 +133,41 @@ struct Butd {
     int colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st);
     int bptt(const icz_butd_params& G, hipStream_t st);
 };
+
+void gemm_set_capturing(bool on);     // gemm_f32.hip: no event timing inside a stream capture
+
+template <class F>
+int Butd::run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn) {
+    if (!use_graphs) return fn(st);
+    ++tick;
+    for (auto& e : graphs)
+        if (e.key == key) {
+            e.last_use = tick;
+            ICZ_CHECK_HIP(hipGraphLaunch(e.exec, st));
+            return ICZ_OK;
+        }
+    if (!cap_st) ICZ_CHECK_HIP(hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking));
+    ICZ_CHECK_HIP(hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal));
+    gemm_set_capturing(true);
+    const int status = fn(cap_st);
+    gemm_set_capturing(false);
+    hipGraph_t g = nullptr;
+    hipError_t ce = hipStreamEndCapture(cap_st, &g);
+    if (status != ICZ_OK) { if (g) (void)hipGraphDestroy(g); return status; }
+    if (ce != hipSuccess || !g) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return ICZ_ERR_HIP; }
+    hipGraphExec_t exec = nullptr;
+    hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+    (void)hipGraphDestroy(g);
+    if (ie != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return ICZ_ERR_HIP; }
+    if (graphs.size() >= 24) {      // evict the least recently used entry
+        size_t lru = 0;
+        for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i].last_use < graphs[lru].last_use) lru = i;
+        (void)hipGraphExecDestroy(graphs[lru].exec);
+        graphs.erase(graphs.begin() + lru);
+    }
+    graphs.push_back({key, exec, tick});
+    ICZ_CHECK_HIP(hipGraphLaunch(exec, st));
+    return ICZ_OK;
+}
 
 }  // namespace icz

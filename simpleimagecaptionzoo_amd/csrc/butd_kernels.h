@@ -282,6 +282,11 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
+__global__ void set_scalars_kernel(uint64_t* seed_p, uint64_t seed, float* f_p, float f) {
+    if (seed_p) *seed_p = seed;
+    if (f_p) *f_p = f;
+}
+
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -323,7 +328,7 @@ __device__ __forceinline__ float block_sum_256(float v, float* sm) {
 struct SampleSelArgs {
     const float* logits; int V; int ldl;
     const float* uniforms;        // [rows] for this step or null (Philox)
-    uint64_t seed; int t; int T;
+    const uint64_t* seed_p; int t; int T;
     uint8_t* unfinished;          // [rows] in/out
     int* n_unfinished;            // [T] counters (zeroed before the rollout)
     int64_t* seq_out; float* logp_out;   // [rows, T]
@@ -374,7 +379,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     }
     const double total = smd[255];
     const double prefix = smd[tid] - loc;
-    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(a.seed, (uint32_t)a.t, (uint64_t)row);
+    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
     const double target = (double)u * total;
     int cand = 0x7fffffff;
     {
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
 // (= d loss / d logp) for the gradient kernel.  denom = mask_sum_global if > 0 else the local mask sum.
 __global__ __launch_bounds__(256) void reinforce_loss_kernel(const float* __restrict__ logp, const int64_t* __restrict__ seq,
                                                              const float* __restrict__ reward, int B, int T,
-                                                             float mask_sum_global, float* __restrict__ coef,
+                                                             const float* __restrict__ mask_sum_global_p, float* __restrict__ coef,
                                                              float* __restrict__ loss_out, float* __restrict__ mask_sum_out) {
     __shared__ float smf[4];
     const int tid = threadIdx.x;
@@ -424,7 +429,8 @@ __global__ __launch_bounds__(256) void reinforce_loss_kernel(const float* __rest
     }
     ms = block_sum_256(ms, smf);
     ls = block_sum_256(ls, smf);
-    const float denom = mask_sum_global > 0.f ? mask_sum_global : ms;
+    const float msg = mask_sum_global_p ? mask_sum_global_p[0] : 0.f;
+    const float denom = msg > 0.f ? msg : ms;
     for (int i = tid; i < B * T; i += 256) {
         const int t = i % T;
         const float m = (t == 0) ? 1.f : (seq[i - 1] > 0 ? 1.f : 0.f);
@@ -525,49 +531,35 @@ __device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_
     for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * slab_stride + off);
     return s;
 }
+// grid (H/256, rows): one hidden unit per thread (see lstm_point_kernel)
 __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, DropCfg dc) {
     const int row = blockIdx.y;
-    const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.H) return;
     const int H = a.H, G = 4 * H;
     // a slab set only holds rows_x rows (XE: the batch shrinks with t); rows beyond contribute zero
-    f32x4 dh = {0.f, 0.f, 0.f, 0.f};
-    if (row < a.rows_a) dh += sum_slabs4(a.dh_a, a.ns_a, (size_t)a.rows_a * a.lda_a, (size_t)row * a.lda_a + j);
-    if (row < a.rows_b) dh += sum_slabs4(a.dh_b, a.ns_b, (size_t)a.rows_b * a.lda_b, (size_t)row * a.lda_b + j);
-    if (row < a.rows_c) dh += sum_slabs4(a.dh_c, a.ns_c, (size_t)a.rows_c * a.lda_c, (size_t)row * a.lda_c + j);
+    float dh = 0.f;
+    if (a.dh_a && row < a.rows_a) dh += sum_slabs1(a.dh_a, a.ns_a, (size_t)a.rows_a * a.lda_a, (size_t)row * a.lda_a + j);
+    if (a.dh_b && row < a.rows_b) dh += sum_slabs1(a.dh_b, a.ns_b, (size_t)a.rows_b * a.lda_b, (size_t)row * a.lda_b + j);
+    if (a.dh_c && row < a.rows_c) dh += sum_slabs1(a.dh_c, a.ns_c, (size_t)a.rows_c * a.lda_c, (size_t)row * a.lda_c + j);
     if (a.dhdrop) {
-        f32x4 d = *reinterpret_cast<const f32x4*>(a.dhdrop + (size_t)row * H + j);
-        if (dc.mode) {
-            uint32_t k = dc.keep4((uint64_t)row * H + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d[e] = ((k >> e) & 1u) ? d[e] * 2.0f : 0.f;
-        }
+        float d = a.dhdrop[(size_t)row * H + j];
+        if (dc.mode) d = dc.keep((uint64_t)row * H + j) ? d * 2.0f : 0.f;
         dh += d;
     }
     const float* g = a.gates + (size_t)row * G + j;
-    const f32x4 gi = *reinterpret_cast<const f32x4*>(g), gf = *reinterpret_cast<const f32x4*>(g + H);
-    const f32x4 gg = *reinterpret_cast<const f32x4*>(g + 2 * H), go = *reinterpret_cast<const f32x4*>(g + 3 * H);
-    const f32x4 cc = *reinterpret_cast<const f32x4*>(a.c_cur + (size_t)row * H + j);
-    f32x4 cp = {0.f, 0.f, 0.f, 0.f}, dcin = {0.f, 0.f, 0.f, 0.f};
-    if (a.c_prev) cp = *reinterpret_cast<const f32x4*>(a.c_prev + (size_t)row * H + j);
-    if (a.dc_in && row < a.dc_in_rows) dcin = *reinterpret_cast<const f32x4*>(a.dc_in + (size_t)row * H + j);
-    f32x4 dai, daf, dag, dao, dcp;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        const float tc = tanhf(cc[e]);
-        const float dcv = dcin[e] + dh[e] * go[e] * (1.f - tc * tc);
-        dao[e] = dh[e] * tc * go[e] * (1.f - go[e]);
-        dai[e] = dcv * gg[e] * gi[e] * (1.f - gi[e]);
-        daf[e] = dcv * cp[e] * gf[e] * (1.f - gf[e]);
-        dag[e] = dcv * gi[e] * (1.f - gg[e] * gg[e]);
-        dcp[e] = dcv * gf[e];
-    }
+    const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
+    const float cc = a.c_cur[(size_t)row * H + j];
+    const float cp = a.c_prev ? a.c_prev[(size_t)row * H + j] : 0.f;
+    const float dcin = (a.dc_in && row < a.dc_in_rows) ? a.dc_in[(size_t)row * H + j] : 0.f;
+    const float tc = tanhf(cc);
+    const float dcv = dcin + dh * go * (1.f - tc * tc);
     float* o = a.dgates + (size_t)row * G + j;
-    *reinterpret_cast<f32x4*>(o) = dai;
-    *reinterpret_cast<f32x4*>(o + H) = daf;
-    *reinterpret_cast<f32x4*>(o + 2 * H) = dag;
-    *reinterpret_cast<f32x4*>(o + 3 * H) = dao;
-    *reinterpret_cast<f32x4*>(a.dc_prev + (size_t)row * H + j) = dcp;
+    o[0] = dcv * gg * gi * (1.f - gi);
+    o[H] = dcv * cp * gf * (1.f - gf);
+    o[2 * H] = dcv * gi * (1.f - gg * gg);
+    o[3 * H] = dh * tc * go * (1.f - go);
+    a.dc_prev[(size_t)row * H + j] = dcv * gf;
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -576,14 +568,20 @@ __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, Drop
 __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __restrict__ dctx, int ns, int ldc, int rows,
                                                              const float* __restrict__ feats, int R, int D,
                                                              float* __restrict__ dalpha) {
-    const int row = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    // grid (rows, parts): the workgroup first sums the split-K slabs of its row's dctx into LDS (once, instead of
+    // once per region), then each wave dots it with whole feature rows
+    extern __shared__ __attribute__((aligned(16))) float sd[];      // D floats
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t ss = (size_t)rows * ldc;
+    for (int c = tid * 4; c < D; c += 1024)
+        *reinterpret_cast<f32x4*>(sd + c) = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+    __syncthreads();
     for (int r = blockIdx.y * 4 + wave; r < R; r += 4 * gridDim.y) {
         const float* f = feats + ((size_t)row * R + r) * D;
         float acc = 0.f;
         for (int c = lane * 4; c < D; c += 256) {
             f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
-            f32x4 g = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+            f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
             acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
         }
         acc = wave_sum(acc);
@@ -768,6 +766,44 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
 // (same as colsum; kept separate for clarity of the call sites)
 
 // ---------------------------------------------------------------------------------------------------------
+// clip_gradient + Adam over a table of tensors in ONE launch (21 parameter tensors per step otherwise cost 21 launches).
+struct AdamTensor { float* p; const float* g; float* m; float* v; size_t n; size_t block0; };
+constexpr int ADAM_MAX_TENSORS = 32;
+struct AdamTable { AdamTensor t[ADAM_MAX_TENSORS]; int count; };
+__global__ __launch_bounds__(256) void adam_clamp_multi_kernel(AdamTable tab, float lr, float clip, float bc1, float sqrt_bc2) {
+    // find the tensor of this block (blocks are laid out tensor after tensor)
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < tab.count; ++i)
+        if (blockIdx.x >= tab.t[i].block0) k = i;
+    const AdamTensor T = tab.t[k];
+    const size_t i = ((size_t)blockIdx.x - T.block0) * 1024 + threadIdx.x * 4;
+    if (i >= T.n) return;
+    const float b1 = 0.9f, b2 = 0.999f, eps = 1e-8f;
+    if (i + 4 <= T.n && (((uintptr_t)(T.p + i) | (uintptr_t)(T.g + i) | (uintptr_t)(T.m + i) | (uintptr_t)(T.v + i)) & 15) == 0) {
+        f32x4 g = *reinterpret_cast<const f32x4*>(T.g + i), m = *reinterpret_cast<f32x4*>(T.m + i);
+        f32x4 v = *reinterpret_cast<f32x4*>(T.v + i), p = *reinterpret_cast<f32x4*>(T.p + i);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const float gv = fminf(fmaxf(g[e], -clip), clip);
+            m[e] = m[e] * b1 + gv * (1.f - b1);
+            v[e] = v[e] * b2 + (gv * gv) * (1.f - b2);
+            p[e] = p[e] - (lr / bc1) * (m[e] / (sqrtf(v[e]) / sqrt_bc2 + eps));
+        }
+        *reinterpret_cast<f32x4*>(T.m + i) = m;
+        *reinterpret_cast<f32x4*>(T.v + i) = v;
+        *reinterpret_cast<f32x4*>(T.p + i) = p;
+    } else {
+        for (size_t e = i; e < T.n && e < i + 4; ++e) {
+            const float gv = fminf(fmaxf(T.g[e], -clip), clip);
+            const float mn = T.m[e] * b1 + gv * (1.f - b1);
+            const float vn = T.v[e] * b2 + (gv * gv) * (1.f - b2);
+            T.m[e] = mn; T.v[e] = vn;
+            T.p[e] = T.p[e] - (lr / bc1) * (mn / (sqrtf(vn) / sqrt_bc2 + eps));
+        }
+    }
+}
+
 // clip_gradient (Utils.py:241-250) + Adam (Utils.py:219-220) fused, elementwise.
 __global__ __launch_bounds__(256) void adam_clamp_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                          float* __restrict__ v, size_t n, float lr, float clip, float bc1,

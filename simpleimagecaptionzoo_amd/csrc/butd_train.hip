@@ -75,8 +75,8 @@ int Butd::ensure_train(int B, int T) {
     return ICZ_OK;
 }
 
-static DropCfg make_drop(const icz_rng& r, bool train, const uint8_t* base, size_t per_step, uint32_t stream, int t) {
-    DropCfg d = {0, nullptr, r.seed, stream, (uint32_t)t};
+static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base, size_t per_step, uint32_t stream, int t) {
+    DropCfg d = {0, nullptr, seed_p, stream, (uint32_t)t};
     if (!train) return d;
     if (base) { d.mode = 1; d.mask = base + per_step * t; }
     else d.mode = 2;
@@ -98,24 +98,33 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     s.gates_td_out = tb.gtd + slot * 4 * H; s.gates_lm_out = tb.glm + slot * 4 * H;
     s.dec_ctx_out = tb.dec + slot * A; s.alpha_out = tb.alpha + slot * R; s.ctx_out = tb.ctx + slot * D;
     s.h2drop_out = tb.h2d + slot * H; s.logits_out = tb.logit + slot * Vp; s.logits_ld = (int)Vp;
-    s.drop_emb = make_drop(rng, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
-    s.drop_att = make_drop(rng, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
-    s.drop_out = make_drop(rng, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
+    s.drop_emb = make_drop(d_seed, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
+    s.drop_att = make_drop(d_seed, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
+    s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
     return step(s, st);
 }
 
 int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
     ICZ_REQUIRE(feats && seq_out && logp_out && r, "butd sample: null argument");
     ICZ_REQUIRE(B > 0 && T > 0, "butd sample: bad B/T");
+    ICZ_REQUIRE(fresh, "butd: call icz_butd_refresh_weights after binding/updating parameters");
     ICZ_TRY(ensure_train(B, T));
     rng = *r;
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats;
     rows_t.assign(T, B);
+    cur_seq = seq_out; cur_logp = logp_out;
+    const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
+    if (explicit_rng || !use_graphs) return sample_impl(feats, B, T, seq_out, logp_out, st);
+    const std::vector<uintptr_t> key = {2, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)T, (uintptr_t)seq_out, (uintptr_t)logp_out};
+    return run_cached(key, st, [&](hipStream_t s) { return sample_impl(feats, B, T, seq_out, logp_out, s); });
+}
+
+int Butd::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st) {
     const size_t H = dims.H;
     const size_t Vp = round4(dims.V);
     ICZ_TRY(prologue(feats, B, st));
-    // slot 0 of the state buffers = zeros (they are only ever written from slot 1 on, but an XE call with a larger
-    // stride may have written there)
+    // slot 0 of the state buffers = zeros
     ICZ_CHECK_HIP(hipMemsetAsync(tb.h1, 0, sizeof(float) * B * H, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tb.c1, 0, sizeof(float) * B * H, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tb.h2, 0, sizeof(float) * B * H, st));
@@ -128,7 +137,7 @@ int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* se
         SampleSelArgs a = {};
         a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
         a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
-        a.seed = rng.seed; a.t = t; a.T = T;
+        a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = tb.unf; a.n_unfinished = tb.nunf;
         a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tb.tok + (size_t)(t + 1) * B;
@@ -136,7 +145,6 @@ int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* se
         hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), sizeof(float) * dims.V, st, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
-    cur_seq = seq_out; cur_logp = logp_out;
     return ICZ_OK;
 }
 
@@ -146,7 +154,7 @@ int Butd::sample_mask_sum(float* out, hipStream_t st) {
     // reuse the loss kernel with zero reward (coef scratch is overwritten later by backward)
     ICZ_CHECK_HIP(hipMemsetAsync(tb.loss_rows, 0, sizeof(float) * cur_B * cur_T, st));
     hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, tb.loss_rows, cur_B, cur_T,
-                       0.f, tb.coef, (float*)nullptr, out);
+                       (const float*)nullptr, tb.coef, (float*)nullptr, out);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -155,15 +163,27 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
                           float mask_sum_global, hipStream_t st) {
     ICZ_REQUIRE(mode == 1, "butd: no rollout stored (call icz_butd_sample first)");
     ICZ_REQUIRE(reward && G, "butd sample_backward: null argument");
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
+    mode = 0;   // the saved logits are consumed
+    const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
+    if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
+    std::vector<uintptr_t> key = {3, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)mask_sum_out, (uintptr_t)cur_B, (uintptr_t)cur_T,
+                                  (uintptr_t)cur_feats, (uintptr_t)cur_seq, (uintptr_t)cur_logp};
+    const float* const* gp = reinterpret_cast<const float* const*>(G);
+    for (size_t i = 0; i < sizeof(icz_butd_params) / sizeof(float*); ++i) key.push_back((uintptr_t)gp[i]);
+    const icz_butd_params Gc = *G;
+    return run_cached(key, st, [&](hipStream_t s) { return sample_backward_impl(reward, Gc, loss_out, mask_sum_out, s); });
+}
+
+int Butd::sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st) {
     const int B = cur_B, T = cur_T;
     const int Vp = round4(dims.V);
-    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, mask_sum_global,
+    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum_global,
                        tb.coef, loss_out, mask_sum_out);
     hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
                        tb.draw, tb.lse, tb.coef, B, T);
     ICZ_CHECK_HIP(hipGetLastError());
-    mode = 0;   // the saved logits are consumed
-    return bptt(*G, st);
+    return bptt(G, st);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -195,6 +215,7 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     ICZ_TRY(ensure_train(B, T));
     if (r) rng = *r; else { rng = {}; }
     ICZ_REQUIRE(!train || r, "butd xe_forward: training mode needs an icz_rng");
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 2; cur_B = B; cur_T = T; cur_train = train != 0; cur_feats = feats;
     rows_t.assign(T, 0);
     n_tokens = 0;
@@ -303,7 +324,7 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
 // helpers for the backward GEMMs
 int Butd::gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st) {
     // direct output (nsplit 1) if there are already enough tiles, else slabs
-    g.nsplit = gemm_pick_split(g, TARGET_WGS, layout);
+    g.nsplit = gemm_pick_split(g, g.M <= 64 ? STEP_WGS : TARGET_WGS, layout);
     if (g.nsplit > 1) {
         ICZ_REQUIRE(slab && gemm_slab_floats(g.M, g.N, g.nsplit) <= slab_floats, "butd: slab buffer too small (%d x %d x %d)", g.nsplit, g.M, g.N);
         g.out = slab; g.ldo = g.N; g.bias = nullptr; g.accumulate = 0;
@@ -370,9 +391,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     for (int t = T - 1; t >= 0; --t) {
         const int bt = rows_t[t];
         const size_t slot = (size_t)t * B;
-        DropCfg d_out = make_drop(rng, cur_train, rng.out_mask, (size_t)B * H, RNG_OUT, t);
-        DropCfg d_att = make_drop(rng, cur_train, rng.att_mask, (size_t)B * R * A, RNG_ATT, t);
-        DropCfg d_off = {0, nullptr, 0, 0, 0};
+        DropCfg d_out = make_drop(d_seed, cur_train, rng.out_mask, (size_t)B * H, RNG_OUT, t);
+        DropCfg d_att = make_drop(d_seed, cur_train, rng.att_mask, (size_t)B * R * A, RNG_ATT, t);
+        DropCfg d_off = {0, nullptr, nullptr, 0, 0};
         {   // language LSTM backward (pointwise)
             LstmBwdArgs a = {};
             a.dh_a = bnext ? tb.X[2] : nullptr; a.ns_a = ns3; a.lda_a = H; a.rows_a = bnext;
@@ -382,7 +403,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             a.c_prev = tb.c2 + slot * H; a.c_cur = tb.c2 + slot * H + sH;
             a.dgates = tb.dGlm + slot * 4 * H; a.dc_prev = tb.dc2[cur ^ 1];
             a.rows = bt; a.H = H;
-            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 1024), bt), dim3(256), 0, st, a, d_out);
+            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_out);
         }
         {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
             GemmArgs g = {};
@@ -392,7 +413,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
         }
         {   // attention backward
-            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, 3), dim3(256), 0, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
+            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, 3), dim3(256), sizeof(float) * D, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
             AttBwdArgs a = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dEnc, tb.ddec_part, tb.dwaff,
                             bt, R, A, 0};
             hipLaunchKernelGGL(att_bwd_kernel, dim3(bt, ATT_PARTS), dim3(256), sizeof(float) * 8 * A, st, a, d_att);
@@ -416,7 +437,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             a.c_prev = tb.c1 + slot * H; a.c_cur = tb.c1 + slot * H + sH;
             a.dgates = tb.dGtd + slot * 4 * H; a.dc_prev = tb.dc1[cur ^ 1];
             a.rows = bt; a.H = H;
-            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 1024), bt), dim3(256), 0, st, a, d_off);
+            hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_off);
         }
         if (t > 0) {
             {   // X3 = dG_lm . W_hh_lm + dG_td . W_ih_td[:, :H]   -> d h2_{t-1}
@@ -534,6 +555,26 @@ int icz_adam_clamp_step(float* param, const float* grad, float* exp_avg, float* 
     const float sbc2 = (float)sqrt(1.0 - pow(b2, (double)step));
     hipLaunchKernelGGL(adam_clamp_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, param, grad,
                        exp_avg, exp_avg_sq, (size_t)n, lr, clip, bc1, sbc2);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int icz_adam_clamp_multi(int32_t count, float* const* params, const float* const* grads, float* const* exp_avg,
+                         float* const* exp_avg_sq, const int64_t* numel, float lr, float clip, int32_t step, void* stream) {
+    ICZ_REQUIRE(count >= 1 && count <= ADAM_MAX_TENSORS, "icz_adam_clamp_multi: count %d out of range 1..%d", count, ADAM_MAX_TENSORS);
+    ICZ_REQUIRE(params && grads && exp_avg && exp_avg_sq && numel && step >= 1, "icz_adam_clamp_multi: bad arguments");
+    AdamTable tab;
+    tab.count = count;
+    size_t blocks = 0;
+    for (int i = 0; i < count; ++i) {
+        ICZ_REQUIRE(params[i] && grads[i] && exp_avg[i] && exp_avg_sq[i] && numel[i] > 0, "icz_adam_clamp_multi: tensor %d invalid", i);
+        tab.t[i] = {params[i], grads[i], exp_avg[i], exp_avg_sq[i], (size_t)numel[i], blocks};
+        blocks += ((size_t)numel[i] + 1023) / 1024;
+    }
+    const double b1 = 0.9, b2 = 0.999;
+    const float bc1 = (float)(1.0 - pow(b1, (double)step));
+    const float sbc2 = (float)sqrt(1.0 - pow(b2, (double)step));
+    hipLaunchKernelGGL(adam_clamp_multi_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, tab, lr, clip, bc1, sbc2);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }

@@ -466,6 +466,8 @@ struct GemmProf {
     double bytes = 0.0, flops = 0.0;
 };
 static GemmProf g_prof;
+static thread_local bool g_capturing = false;
+void gemm_set_capturing(bool on) { g_capturing = on; }
 
 static void prof_account(const GemmArgs& a) {
     double kb = 0.0, k = 0.0;
@@ -554,7 +556,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         const int bn = nt_tile_n(a);
         dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_prof.on && mt == 4) {
+        if (g_prof.on && mt == 4 && !g_capturing) {
             if (g_prof.used + 2 > g_prof.ev.size()) {
                 for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) g_prof.ev.push_back(e); }
             }

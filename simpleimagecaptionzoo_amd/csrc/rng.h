@@ -55,11 +55,11 @@ __host__ __device__ inline float rng_uniform(uint64_t seed, uint32_t step, uint6
 struct DropCfg {
     int mode;               // 0 = eval (no dropout), 1 = explicit mask array, 2 = Philox
     const uint8_t* mask;    // mode 1: keep flags for this step, element-indexed
-    uint64_t seed;
+    const uint64_t* seed_p; // mode 2: seed lives in device memory (a captured graph is replayed with new seeds)
     uint32_t stream, step;
     __device__ __forceinline__ bool keep(uint64_t idx) const {
         if (mode == 1) return mask[idx] != 0;
-        return rng_keep(seed, stream, step, idx);
+        return rng_keep(*seed_p, stream, step, idx);
     }
     // 4 consecutive elements starting at idx (idx % 4 == 0): bit j set = keep element idx + j
     __device__ __forceinline__ uint32_t keep4(uint64_t idx) const {
@@ -67,7 +67,7 @@ struct DropCfg {
             uint32_t m = *reinterpret_cast<const uint32_t*>(mask + idx);
             return ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) | ((m & 0xFF000000u) ? 8u : 0u);
         }
-        return (rng_group_bits(seed, stream, step, idx) >> (idx & 31)) & 0xFu;
+        return (rng_group_bits(*seed_p, stream, step, idx) >> (idx & 31)) & 0xFu;
     }
 };
 

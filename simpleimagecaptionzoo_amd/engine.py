@@ -40,19 +40,32 @@ class FusedAdam:
         pass
 
     def step_with(self, grads_by_param, clip):
-        """grads_by_param: {parameter: gradient tensor}."""
+        """grads_by_param: {parameter: gradient tensor}.  One multi-tensor launch per param group."""
+        import ctypes as C
         for group in self.param_groups:
-            for p in group["params"]:
-                g = grads_by_param.get(p)
-                if g is None:
-                    continue
+            ps = [p for p in group["params"] if grads_by_param.get(p) is not None]
+            if not ps:
+                continue
+            steps = set()
+            for p in ps:
                 st = self.state.get(p)
                 if st is None:
                     st = {"step": 0, "exp_avg": torch.zeros_like(p.data), "exp_avg_sq": torch.zeros_like(p.data)}
                     self.state[p] = st
                 st["step"] += 1
-                check(lib().icz_adam_clamp_step(ptr(p.data), ptr(g), ptr(st["exp_avg"]), ptr(st["exp_avg_sq"]),
-                                                p.numel(), float(group["lr"]), float(clip), st["step"], stream_ptr()))
+                steps.add(st["step"])
+            assert len(steps) == 1, "parameters of one group share the step count"
+            n = len(ps)
+            for lo in range(0, n, 32):
+                chunk = ps[lo:lo + 32]
+                m = len(chunk)
+                arr = lambda xs: (C.c_void_p * m)(*xs)
+                check(lib().icz_adam_clamp_multi(
+                    m, arr([p.data.data_ptr() for p in chunk]), arr([grads_by_param[p].data_ptr() for p in chunk]),
+                    arr([self.state[p]["exp_avg"].data_ptr() for p in chunk]),
+                    arr([self.state[p]["exp_avg_sq"].data_ptr() for p in chunk]),
+                    (C.c_int64 * m)(*[p.numel() for p in chunk]), float(group["lr"]), float(clip), steps.pop() if lo + 32 >= n else next(iter(steps)),
+                    stream_ptr()))
 
 
 def init_optimizer(optimizer_type, params, learning_rate):
@@ -85,6 +98,8 @@ class Engine(object):
         self._cider_df = cider_df
         self._scorer = None
         self._pinned = None
+        self._dev_feats = None
+        self.use_graphs = True      # replay captured hipGraphs in SCST / greedy evaluation (buffers are persistent)
 
     def model_construction(self, max_batch):
         raise NotImplementedError
@@ -124,7 +139,11 @@ class BUTDDetection_Eng(Engine):
                 hv[i, n:] = 0
             masks[i, :n] = 1
         bu_masks = None if masks.sum() == masks.size else torch.from_numpy(masks).float().to(self.device)
-        feats = host.to(self.device, non_blocking=True)
+        # copy into a persistent device buffer: a stable address lets the captured graphs be replayed
+        if self._dev_feats is None or self._dev_feats.shape[0] < B or tuple(self._dev_feats.shape[1:]) != (max_len, D):
+            self._dev_feats = torch.empty(max(B, 1), max_len, D, dtype=torch.float32, device=self.device)
+        feats = self._dev_feats[:B]
+        feats.copy_(host, non_blocking=True)
         return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": bu_masks}
 
     # ---- helpers ------------------------------------------------------------------------------------------
@@ -160,7 +179,14 @@ class BUTDDetection_Eng(Engine):
                 import pickle
                 df = pickle.load(open(df, "rb"), encoding="latin1")
             self._scorer = CiderDReward(df["document_frequency"], df["ref_len"], self.caption_vocab.word2ix, self.device)
+            self._scorer.persistent = True
         return self._scorer
+
+    def _hot_handle(self):
+        h = self.model._handle()
+        if self.use_graphs and not h._persistent:
+            h.enable_graphs(True)
+        return h
 
     # ---- E1 -------------------------------------------------------------------------------------------------
     def training_epoch(self, dataloader, optimizer, criterion, tqdm_visible=True, rngs=None):
@@ -199,7 +225,7 @@ class BUTDDetection_Eng(Engine):
         for batch_i, (img_ids, img_tensors, img_gts, supp_info_datas) in enumerate(monitor):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
             feats = visual_inputs["bu_feats"]
-            h = self.model._handle()
+            h = self._hot_handle()
             greedy_res = h.greedy(feats, 20)
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
             seq_gen, seq_logprobs = h.sample(feats, 20, rng)
@@ -227,7 +253,7 @@ class BUTDDetection_Eng(Engine):
         ix2word = self.caption_vocab.ix2word
         for batch_i, (image_ids, img_tensors, supp_info_datas) in enumerate(monitor):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
-            h = self.model._handle()
+            h = self._hot_handle()
             if eval_beam_size != -1:
                 seqs, lens = h.beam_search(visual_inputs["bu_feats"], eval_beam_size, 50)
                 seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
