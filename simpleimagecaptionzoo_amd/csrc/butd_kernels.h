@@ -229,6 +229,99 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
     if (valid) ctx[(size_t)row * D + d] = acc;
 }
 
+__device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_stride, size_t off) {
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (!p) return s;
+    s = *reinterpret_cast<const f32x4*>(p + off);
+    for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * slab_stride + off);
+    return s;
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused SoftAttention forward (:49-62), one 512-thread workgroup per decoder row:
+//   dec_ctx = sum_z slab[z,row,:] + b_dec                          (dec_att GEMM split-K partials summed here)
+//   score_r = w_aff . drop(relu(enc_ctx[img,r,:] + dec_ctx)) + b_aff      8 waves walk the R regions
+//   alpha   = softmax_R(score)                                      wave shuffles
+//   ctx     = sum_r alpha_r feats[img,r,:]                          512 threads x float4 = 2048 columns per pass
+// One launch instead of two (scores, context); the R x A block of enc_ctx and the R x D block of features of the row
+// are each read exactly once, with 16-byte loads.
+__global__ __launch_bounds__(512) void att_fwd_kernel(AttScoreArgs a, const float* __restrict__ feats, float* __restrict__ alpha_out,
+                                                      float* __restrict__ alpha_out2, int alpha2_stride, float* __restrict__ ctx,
+                                                      int D, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float sm_att[];   // [A] dec_ctx, [64] scores/alpha
+    float* sdec = sm_att;
+    float* sal = sm_att + a.A;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t MN = (size_t)a.rows * a.A;
+    for (int c = tid * 4; c < a.A; c += 2048) {
+        const size_t off = (size_t)row * a.A + c;
+        f32x4 s = sum_slabs4(a.dec_slab, a.nsplit, MN, off);
+        s += *reinterpret_cast<const f32x4*>(a.b_dec + c);
+        *reinterpret_cast<f32x4*>(sdec + c) = s;
+        if (a.dec_ctx_out) *reinterpret_cast<f32x4*>(a.dec_ctx_out + off) = s;
+    }
+    __syncthreads();
+    const int img = a.img_of_row ? a.img_of_row[row] : row;
+    const float baff = a.b_aff[0];
+    const float sc = dc.mode ? 2.0f : 1.0f;
+    for (int r = wave; r < a.R; r += 8) {
+        const float* e = a.enc_ctx + ((size_t)img * a.R + r) * a.A;
+        float acc = 0.f;
+        for (int c0 = lane * 4; c0 < a.A; c0 += 1024) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(e + min(c0 + 256 * u, a.A - 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < a.A) {
+                    f32x4 d = *reinterpret_cast<const f32x4*>(sdec + c);
+                    f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+                    uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        float zv = fmaxf(x[u][j] + d[j], 0.f);
+                        zv = ((k >> j) & 1u) ? zv * sc : 0.f;
+                        acc += zv * w[j];
+                    }
+                }
+            }
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sal[r] = acc + baff;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float v = lane < a.R ? sal[lane] : -INFINITY;
+        const float mx = wave_max(v);
+        const float ex = lane < a.R ? expf(v - mx) : 0.f;
+        const float sum = wave_sum(ex);
+        const float al = ex / sum;
+        if (lane < a.R) {
+            if (a.scores) a.scores[(size_t)row * a.R + lane] = v;
+            alpha_out[(size_t)row * a.R + lane] = al;
+            if (alpha_out2) alpha_out2[(size_t)row * alpha2_stride + lane] = al;
+        }
+        __builtin_amdgcn_s_waitcnt(0);      // LDS read of sal above completes before it is overwritten
+        if (lane < a.R) sal[lane] = al;
+    }
+    __syncthreads();
+    const float* f = feats + (size_t)img * a.R * D;
+    for (int d = tid * 4; d < D; d += 2048) {
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        constexpr int RB = 9;                // 9 independent 16-byte loads in flight per thread
+        for (int r0 = 0; r0 < a.R; r0 += RB) {
+            f32x4 x[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) x[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r0 + u, a.R - 1) * D + d);
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+                if (r0 + u < a.R) acc += x[u] * sal[r0 + u];
+        }
+        *reinterpret_cast<f32x4*>(ctx + (size_t)row * D + d) = acc;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // greedy epilogue (:183): id = argmax_v logits[row, v] (first maximum wins, as torch.max does), in two stages:
 //   argmax_part_kernel  grid (rows, P): block-wide (value, index) of its slice of the vocabulary -> part[row, p]
@@ -524,13 +617,6 @@ struct LstmBwdArgs {
     int rows_a, rows_b, rows_c;       // row counts of the slab sets (slab stride = rows_x * lda_x)
     int dc_in_rows;                   // valid rows of dc_in
 };
-__device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_stride, size_t off) {
-    f32x4 s = {0.f, 0.f, 0.f, 0.f};
-    if (!p) return s;
-    s = *reinterpret_cast<const f32x4*>(p + off);
-    for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * slab_stride + off);
-    return s;
-}
 // grid (H/256, rows): one hidden unit per thread (see lstm_point_kernel)
 __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, DropCfg dc) {
     const int row = blockIdx.y;
@@ -654,6 +740,95 @@ __global__ __launch_bounds__(256) void att_bwd_kernel(AttBwdArgs a, DropCfg dc) 
         *reinterpret_cast<f32x4*>(a.ddec_part + ((size_t)part * a.rows + row) * a.A + c) = dd;
         f32x4* wa = reinterpret_cast<f32x4*>(a.dwaff_acc + ((size_t)row * nparts + part) * a.A + c);
         *wa = a.first ? dw : (*wa + dw);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Fused SoftAttention backward, one 512-thread workgroup per decoder row (replaces dalpha + att_bwd + slab reduce):
+//   dctx    = sum_z slab[z,row,0:D]                                   -> LDS
+//   dalpha_r = dctx . feats[row,r,:]                                   8 waves walk the regions
+//   ds_r    = alpha_r (dalpha_r - sum_r' alpha_r' dalpha_r')           softmax backward
+//   per attention column a (each thread owns columns a, a+1 for ALL regions -> no cross-thread reduction):
+//     zpre = enc_ctx[row,r,a] + dec_ctx[row,a];  on = zpre > 0 && keep
+//     denc_acc[row,r,a] += on ? ds_r w_aff[a] scale : 0       (accumulated over time steps)
+//     ddec[row,a]        = sum_r of the same
+//     dwaff_acc[row,a]  += sum_r on ? ds_r zpre scale : 0     (reduced over rows at the end)
+struct AttBwdFusedArgs {
+    const float* dctx; int ns; int ldc; int rows;
+    const float* feats; const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha;
+    float* denc_acc; float* ddec; float* dwaff_acc;
+    int R, D, A;
+};
+__global__ __launch_bounds__(512) void att_bwd_fused_kernel(AttBwdFusedArgs a, DropCfg dc) {
+    extern __shared__ __attribute__((aligned(16))) float sm_ab[];    // [D] dctx, [64] dalpha / ds
+    float* sd = sm_ab;
+    float* sds = sm_ab + a.D;
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t ss = (size_t)a.rows * a.ldc;
+    for (int c = tid * 4; c < a.D; c += 2048)
+        *reinterpret_cast<f32x4*>(sd + c) = sum_slabs4(a.dctx, a.ns, ss, (size_t)row * a.ldc + c);
+    __syncthreads();
+    for (int r = wave; r < a.R; r += 8) {
+        const float* f = a.feats + ((size_t)row * a.R + r) * a.D;
+        float acc = 0.f;
+        for (int c = lane * 4; c < a.D; c += 256) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
+            f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
+            acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
+        }
+        acc = wave_sum(acc);
+        if (lane == 0) sds[r] = acc;
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
+        const float da = lane < a.R ? sds[lane] : 0.f;
+        const float dot = wave_sum(al * da);
+        if (lane < a.R) sds[lane] = al * (da - dot);
+    }
+    __syncthreads();
+    const float sc = dc.mode ? 2.0f : 1.0f;
+    const float* __restrict__ encp = a.enc_ctx;
+    float* __restrict__ dencp = a.denc_acc;
+    for (int c = tid * 2; c < a.A; c += 1024) {
+        const float d0 = a.dec_ctx[(size_t)row * a.A + c], d1 = a.dec_ctx[(size_t)row * a.A + c + 1];
+        const float w0 = a.w_aff[c], w1 = a.w_aff[c + 1];
+        float dd0 = 0.f, dd1 = 0.f, dw0 = 0.f, dw1 = 0.f;
+        // regions in batches of 6: all loads of a batch are issued before any dependent store (the read-modify-write of
+        // denc_acc would otherwise serialise one memory round trip per region)
+        constexpr int RB = 6;
+        for (int r0 = 0; r0 < a.R; r0 += RB) {
+            float2 x[RB], o[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = min(r0 + u, a.R - 1);
+                const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
+                x[u] = *reinterpret_cast<const float2*>(encp + eoff);
+                o[u] = *reinterpret_cast<const float2*>(dencp + eoff);
+            }
+#pragma unroll
+            for (int u = 0; u < RB; ++u) {
+                const int r = r0 + u;
+                if (r < a.R) {
+                    const float ds = sds[r];
+                    const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
+                    uint32_t k = 0x3u;
+                    if (dc.mode) k = (dc.keep4(eoff & ~(size_t)3) >> (eoff & 2)) & 0x3u;
+                    const float z0 = x[u].x + d0, z1 = x[u].y + d1;
+                    const bool on0 = (z0 > 0.f) && (k & 1u), on1 = (z1 > 0.f) && (k & 2u);
+                    const float g0 = on0 ? ds * w0 * sc : 0.f, g1 = on1 ? ds * w1 * sc : 0.f;
+                    *reinterpret_cast<float2*>(dencp + eoff) = make_float2(o[u].x + g0, o[u].y + g1);
+                    dd0 += g0; dd1 += g1;
+                    dw0 += on0 ? z0 * sc * ds : 0.f;
+                    dw1 += on1 ? z1 * sc * ds : 0.f;
+                }
+            }
+        }
+        *reinterpret_cast<float2*>(a.ddec + (size_t)row * a.A + c) = make_float2(dd0, dd1);
+        float2* wa = reinterpret_cast<float2*>(a.dwaff_acc + (size_t)row * a.A + c);
+        float2 ow = *wa;
+        ow.x += dw0; ow.y += dw1;
+        *wa = ow;
     }
 }
 

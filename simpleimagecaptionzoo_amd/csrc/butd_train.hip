@@ -413,13 +413,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
         }
         {   // attention backward
-            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, 3), dim3(256), sizeof(float) * D, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
-            AttBwdArgs a = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dEnc, tb.ddec_part, tb.dwaff,
-                            bt, R, A, 0};
-            hipLaunchKernelGGL(att_bwd_kernel, dim3(bt, ATT_PARTS), dim3(256), sizeof(float) * 8 * A, st, a, d_att);
-            size_t MN = (size_t)bt * A;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, tb.ddec_part, ATT_PARTS, MN, A,
-                               (const float*)nullptr, tb.dDec + slot * A);
+            AttBwdFusedArgs fa = {tb.X[0], ns1, D + H, bt, feats, enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R,
+                                  tb.dEnc, tb.dDec + slot * A, tb.dwaff, R, D, A};
+            hipLaunchKernelGGL(att_bwd_fused_kernel, dim3(bt), dim3(512), sizeof(float) * (D + 64), st, fa, d_att);
             // X2 = dDec . w_dec   [bt, H]
             GemmArgs g = {};
             g.nseg = 1;
@@ -494,7 +490,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lm_b_hh, G.lm_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     ICZ_TRY(colsum(tb.dDec, TB, A, A, G.dec_att_b, st));
     ICZ_TRY(colsum(tb.dEnc, B * R, A, A, G.enc_att_b, st));
-    ICZ_TRY(colsum(tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff, st));
+    ICZ_TRY(colsum(tb.dwaff, B, A, A, tb.dWaff, st));
     // d loss / d affine.bias is identically zero (softmax shift invariance)
     ICZ_CHECK_HIP(hipMemsetAsync(G.affine_b, 0, sizeof(float), st));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc,
