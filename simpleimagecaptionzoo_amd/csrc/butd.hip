@@ -201,11 +201,9 @@ int Butd::step(const StepIO& s, hipStream_t st) {
 }
 
 int Butd::zero_state(int rows, int which, hipStream_t st) {
-    const size_t n = sizeof(float) * rows * dims.H;
-    ICZ_CHECK_HIP(hipMemsetAsync(h1[which], 0, n, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(c1[which], 0, n, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(h2[which], 0, n, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(c2[which], 0, n, st));
+    ZeroList z = {{h1[which], c1[which], h2[which], c2[which]}, 4};
+    const size_t n = (size_t)rows * dims.H;
+    hipLaunchKernelGGL(zero_bufs_kernel, dim3(cdiv((int)(n / 4), 256)), dim3(256), 0, st, z, n);
     return ICZ_OK;
 }
 

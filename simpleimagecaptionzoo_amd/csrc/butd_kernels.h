@@ -380,6 +380,15 @@ __global__ void set_scalars_kernel(uint64_t* seed_p, uint64_t seed, float* f_p, 
     if (f_p) *f_p = f;
 }
 
+// zero up to 8 float buffers of n floats each (n % 4 == 0) in one launch (recurrent-state resets)
+struct ZeroList { float* p[8]; int count; };
+__global__ __launch_bounds__(256) void zero_bufs_kernel(ZeroList z, size_t n) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+    if (i >= n) return;
+    const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+    for (int k = 0; k < z.count; ++k) *reinterpret_cast<f32x4*>(z.p[k] + i) = zero;
+}
+
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -462,16 +471,19 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     const int v0 = tid * per, v1 = min(a.V, v0 + per);
     double loc = 0.0;
     for (int v = v0; v < v1; ++v) loc += (double)srow[v];
-    smd[tid] = loc;
-    __syncthreads();
-    for (int o = 1; o < 256; o <<= 1) {
-        double x = (tid >= o) ? smd[tid - o] : 0.0;
-        __syncthreads();
-        smd[tid] += x;
-        __syncthreads();
+    // exclusive prefix over the 256 slice sums: wave-level inclusive scan (shuffles) + the 4 wave totals
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += up;
     }
-    const double total = smd[255];
-    const double prefix = smd[tid] - loc;
+    if ((tid & 63) == 63) smd[tid >> 6] = inc;
+    __syncthreads();
+    double wave_off = 0.0;
+    for (int w = 0; w < (tid >> 6); ++w) wave_off += smd[w];
+    const double total = ((smd[0] + smd[1]) + smd[2]) + smd[3];
+    const double prefix = wave_off + inc - loc;
     const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
     const double target = (double)u * total;
     int cand = 0x7fffffff;
@@ -758,6 +770,7 @@ struct AttBwdFusedArgs {
     const float* feats; const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha;
     float* denc_acc; float* ddec; float* dwaff_acc;
     int R, D, A;
+    int first;       // overwrite the accumulators instead of adding (first processed time step: no memset needed)
 };
 __global__ __launch_bounds__(512) void att_bwd_fused_kernel(AttBwdFusedArgs a, DropCfg dc) {
     extern __shared__ __attribute__((aligned(16))) float sm_ab[];    // [D] dctx, [64] dalpha / ds
@@ -804,7 +817,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(AttBwdFusedArgs a, D
                 const int r = min(r0 + u, a.R - 1);
                 const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
                 x[u] = *reinterpret_cast<const float2*>(encp + eoff);
-                o[u] = *reinterpret_cast<const float2*>(dencp + eoff);
+                o[u] = a.first ? make_float2(0.f, 0.f) : *reinterpret_cast<const float2*>(dencp + eoff);
             }
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
@@ -826,7 +839,7 @@ __global__ __launch_bounds__(512) void att_bwd_fused_kernel(AttBwdFusedArgs a, D
         }
         *reinterpret_cast<float2*>(a.ddec + (size_t)row * a.A + c) = make_float2(dd0, dd1);
         float2* wa = reinterpret_cast<float2*>(a.dwaff_acc + (size_t)row * a.A + c);
-        float2 ow = *wa;
+        float2 ow = a.first ? make_float2(0.f, 0.f) : *wa;
         ow.x += dw0; ow.y += dw1;
         *wa = ow;
     }

@@ -9,6 +9,12 @@ namespace icz {
 
 static inline int round4(int x) { return (x + 3) & ~3; }
 
+__global__ void sample_init_kernel(uint8_t* unf, int* nunf, int64_t* tok, int B, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { unf[i] = 1; tok[i] = 1; }
+    if (i < T) nunf[i] = 0;
+}
+
 int Butd::ensure_train(int B, int T) {
     if (tb.B >= B && tb.T >= T) return ICZ_OK;
     ICZ_REQUIRE(B <= dims.max_rows, "butd: batch %d exceeds capacity %d", B, dims.max_rows);
@@ -124,14 +130,13 @@ int Butd::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float*
     const size_t H = dims.H;
     const size_t Vp = round4(dims.V);
     ICZ_TRY(prologue(feats, B, st));
-    // slot 0 of the state buffers = zeros
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.h1, 0, sizeof(float) * B * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.c1, 0, sizeof(float) * B * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.h2, 0, sizeof(float) * B * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.c2, 0, sizeof(float) * B * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.unf, 1, B, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.nunf, 0, sizeof(int) * T, st));
-    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, tb.tok, (int64_t)1, B);
+    // slot 0 of the state buffers = zeros; unfinished flags = 1, counters = 0, first token = <sta>
+    {
+        ZeroList z = {{tb.h1, tb.c1, tb.h2, tb.c2}, 4};
+        const size_t n = (size_t)B * H;
+        hipLaunchKernelGGL(zero_bufs_kernel, dim3(cdiv((int)(n / 4), 256)), dim3(256), 0, st, z, n);
+    }
+    hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok, B, T);
     for (int t = 0; t < T; ++t) {
         ICZ_TRY(train_step(feats, B, B, t, true, st));
         SampleSelArgs a = {};
@@ -377,12 +382,16 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
                            G.predict_v, G.predict_g, V, H);
     }
-    // ---- zero the accumulators / inactive rows
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.dGtd, 0, sizeof(float) * (size_t)TB * 4 * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.dGlm, 0, sizeof(float) * (size_t)TB * 4 * H, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.dDec, 0, sizeof(float) * (size_t)TB * A, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.dEnc, 0, sizeof(float) * (size_t)B * R * A, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(tb.dwaff, 0, sizeof(float) * (size_t)B * ATT_PARTS * A, st));
+    // ---- XE only: rows that dropped out of the batch must contribute zero (the sample path writes every row, and its
+    //      accumulators are initialised by the first processed step)
+    const bool ragged = rows_t[T - 1] < B;
+    if (ragged) {
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dGtd, 0, sizeof(float) * (size_t)TB * 4 * H, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dGlm, 0, sizeof(float) * (size_t)TB * 4 * H, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dDec, 0, sizeof(float) * (size_t)TB * A, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dEnc, 0, sizeof(float) * (size_t)B * R * A, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dwaff, 0, sizeof(float) * (size_t)B * ATT_PARTS * A, st));
+    }
 
     // ---- reverse-time loop
     int cur = 0;
@@ -414,7 +423,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         }
         {   // attention backward
             AttBwdFusedArgs fa = {tb.X[0], ns1, D + H, bt, feats, enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R,
-                                  tb.dEnc, tb.dDec + slot * A, tb.dwaff, R, D, A};
+                                  tb.dEnc, tb.dDec + slot * A, tb.dwaff, R, D, A, (!ragged && t == T - 1) ? 1 : 0};
             hipLaunchKernelGGL(att_bwd_fused_kernel, dim3(bt), dim3(512), sizeof(float) * (D + 64), st, fa, d_att);
             // X2 = dDec . w_dec   [bt, H]
             GemmArgs g = {};
