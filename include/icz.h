@@ -93,6 +93,12 @@ typedef struct {
 int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
                     int64_t* seq_out, float* logprobs_out, void* stream);
 
+/* Both rollouts of one SCST step (Engine.py:258-262: greedy baseline in eval mode + sampled rollout in train mode)
+ * in one call; the two decode chains share the per-image prologue and run concurrently on two streams.  Results are
+ * identical to icz_butd_greedy + icz_butd_sample. */
+int icz_butd_scst_rollouts(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
+                           int64_t* greedy_ids_out, int64_t* seq_out, float* logprobs_out, void* stream);
+
 /* RewardCriterion.forward + loss.backward() for the rollout kept by the last icz_butd_sample
  * (Utils.py:295-317, Engine.py:266-270).  reward [B,max_len]; grads receives d loss / d parameter (overwritten,
  * not accumulated); loss_out (1 float, device) receives the loss.

@@ -73,6 +73,7 @@ def lib():
         "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_butd_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(Rng), vp, vp, vp]),
+        "icz_butd_scst_rollouts": (C.c_int, [vp, vp, i32, i32, C.POINTER(Rng), vp, vp, vp, vp]),
         "icz_butd_sample_backward": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp, vp, f32, vp]),
         "icz_butd_sample_backward_dlogp": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp]),
         "icz_butd_xe_backward_dlogits": (C.c_int, [vp, vp, C.POINTER(ButdParams), vp]),

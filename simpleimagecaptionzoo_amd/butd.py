@@ -109,6 +109,20 @@ class ButdHandle:
         self._live = (feats, rng, seq, lp)
         return seq, lp
 
+    def rollouts(self, feats, max_len=20, rng=None):
+        """Greedy baseline + sampled rollout of one SCST step (Engine.py:258-262), run concurrently on the device.
+        Returns (greedy_ids, seq, logprobs); identical to greedy() followed by sample()."""
+        feats = self._check_feats(feats)
+        B = feats.shape[0]
+        rng = rng or make_rng(0)
+        ids = self._buf("greedy_ids", (B, max_len), torch.int64)
+        seq = self._buf("sample_seq", (B, max_len), torch.int64)
+        lp = self._buf("sample_lp", (B, max_len), torch.float32)
+        check(lib().icz_butd_scst_rollouts(self._h, ptr(feats), B, max_len, C.byref(rng), ptr(ids), ptr(seq), ptr(lp),
+                                           stream_ptr()))
+        self._live = (feats, rng, seq, lp)
+        return ids, seq, lp
+
     def sample_mask_sum(self):
         out = torch.zeros(1, device=self.device)
         check(lib().icz_butd_sample_mask_sum(self._h, ptr(out), stream_ptr()))

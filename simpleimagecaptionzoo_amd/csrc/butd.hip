@@ -69,6 +69,9 @@ int Butd::init(const icz_butd_dims& d) {
 }
 
 Butd::~Butd() {
+    if (side_st) (void)hipStreamDestroy(side_st);
+    if (ev_fork) (void)hipEventDestroy(ev_fork);
+    if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
     if (cap_st) (void)hipStreamDestroy(cap_st);
     for (void* p : allocs) (void)hipFree(p);
@@ -140,6 +143,8 @@ int Butd::step(const StepIO& s, hipStream_t st) {
     const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A, V = dims.V;
     const int Vp = (V + 3) & ~3;
     const int rows = s.rows;
+    float* const ws = s.ws_alt ? s.ws_alt : this->ws;
+    float* const scores = s.scores_alt ? s.scores_alt : this->scores;
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     // embedding -> relu -> dropout (greedy decode gets it from the previous step's fused argmax epilogue)
     if (!s.emb_ready)
@@ -216,6 +221,11 @@ int Butd::greedy(const float* feats, int B, int max_len, int64_t* ids_out, float
 
 int Butd::greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
     ICZ_TRY(prologue(feats, B, st));
+    return greedy_chain(feats, B, max_len, ids_out, alphas_out, st);
+}
+
+// the decode loop after the per-image prologue
+int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
     ICZ_TRY(zero_state(B, 0, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
     int cur = 0;

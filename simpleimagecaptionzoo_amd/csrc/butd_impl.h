@@ -27,6 +27,8 @@ struct StepIO {
     float* h2drop_out;               // [rows,H]
     float* logits_out;               // [rows,V]
     int logits_ld;                   // row stride of logits_out (0 = V)
+    float* ws_alt;                   // split-K slab workspace / attention scores of this chain (null = the handle's):
+    float* scores_alt;               // two decode chains running concurrently must not share them
     DropCfg drop_emb, drop_att, drop_out;
 };
 
@@ -101,6 +103,12 @@ struct Butd {
     template <class F> int run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn);
     int greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
     int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
+    int sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
+    hipStream_t side_st = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st);
 
     // beam search (butd_beam.hip)

@@ -104,6 +104,9 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     s.gates_td_out = tb.gtd + slot * 4 * H; s.gates_lm_out = tb.glm + slot * 4 * H;
     s.dec_ctx_out = tb.dec + slot * A; s.alpha_out = tb.alpha + slot * R; s.ctx_out = tb.ctx + slot * D;
     s.h2drop_out = tb.h2d + slot * H; s.logits_out = tb.logit + slot * Vp; s.logits_ld = (int)Vp;
+    // own slab workspace / score scratch (backward-only buffers, idle during the forward): the sampled rollout can
+    // then run concurrently with the greedy rollout, which uses the handle's
+    s.ws_alt = tb.X[0]; s.scores_alt = tb.dalpha;
     s.drop_emb = make_drop(d_seed, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
     s.drop_att = make_drop(d_seed, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
     s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
@@ -127,9 +130,50 @@ int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* se
 }
 
 int Butd::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_TRY(prologue(feats, B, st));
+    return sample_chain(feats, B, T, seq_out, logp_out, st);
+}
+
+// Greedy baseline and sampled rollout of one SCST step (Engine.py:258-262) as two concurrent chains: they share the
+// per-image prologue and the weights, nothing else, so they run on two streams (fork / join with events; inside a
+// capture this becomes two parallel branches of the graph) and fill each other's idle CUs -- a skinny decoder-step
+// GEMM occupies one workgroup per CU with its MFMA pipe about half busy.
+int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out,
+                   hipStream_t st) {
+    ICZ_REQUIRE(feats && ids_out && seq_out && logp_out && r, "butd rollouts: null argument");
+    ICZ_REQUIRE(B > 0 && T > 0 && B <= dims.max_rows, "butd rollouts: bad B/T");
+    ICZ_REQUIRE(fresh, "butd: call icz_butd_refresh_weights after binding/updating parameters");
+    ICZ_TRY(ensure_train(B, T));
+    if (!side_st) {
+        ICZ_CHECK_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    rng = *r;
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
+    mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats;
+    rows_t.assign(T, B);
+    cur_seq = seq_out; cur_logp = logp_out;
+    const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
+    if (explicit_rng || !use_graphs) return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, st);
+    const std::vector<uintptr_t> key = {4, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)T, (uintptr_t)ids_out, (uintptr_t)seq_out, (uintptr_t)logp_out};
+    return run_cached(key, st, [&](hipStream_t s) { return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, s); });
+}
+
+int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_TRY(prologue(feats, B, st));
+    ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
+    ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
+    const int sg = greedy_chain(feats, B, T, ids_out, nullptr, side_st);
+    const int ss = sample_chain(feats, B, T, seq_out, logp_out, st);
+    ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));       // always join, also on error (a capture must be closed)
+    ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    return sg != ICZ_OK ? sg : ss;
+}
+
+int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st) {
     const size_t H = dims.H;
     const size_t Vp = round4(dims.V);
-    ICZ_TRY(prologue(feats, B, st));
     // slot 0 of the state buffers = zeros; unfinished flags = 1, counters = 0, first token = <sta>
     {
         ZeroList z = {{tb.h1, tb.c1, tb.h2, tb.c2}, 4};
@@ -522,6 +566,11 @@ int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_le
                     int64_t* seq_out, float* logprobs_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Butd*>(h)->sample(feats, B, max_len, rng, seq_out, logprobs_out, (hipStream_t)stream);
+}
+int icz_butd_scst_rollouts(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
+                           int64_t* greedy_ids_out, int64_t* seq_out, float* logprobs_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Butd*>(h)->rollouts(feats, B, max_len, rng, greedy_ids_out, seq_out, logprobs_out, (hipStream_t)stream);
 }
 int icz_butd_sample_backward(icz_butd_t* h, const float* reward, const icz_butd_params* grads, float* loss_out,
                              float* mask_sum_out, float mask_sum_global, void* stream) {

@@ -226,9 +226,8 @@ class BUTDDetection_Eng(Engine):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
             feats = visual_inputs["bu_feats"]
             h = self._hot_handle()
-            greedy_res = h.greedy(feats, 20)
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
-            seq_gen, seq_logprobs = h.sample(feats, 20, rng)
+            greedy_res, seq_gen, seq_logprobs = h.rollouts(feats, 20, rng)
             rewards = scorer.reward(seq_gen, greedy_res, img_gts, img_ids)
             grads = self._grads()
             msum_glob = 0.0
