@@ -70,6 +70,9 @@ int Butd::init(const icz_butd_dims& d) {
 
 Butd::~Butd() {
     if (side_st) (void)hipStreamDestroy(side_st);
+    if (low_st) (void)hipStreamDestroy(low_st);
+    if (ev_fork2) (void)hipEventDestroy(ev_fork2);
+    if (ev_join2) (void)hipEventDestroy(ev_join2);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);

@@ -47,6 +47,7 @@ struct TrainBuf {
     float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;
     int* scalars_i = nullptr; int scalars_i_cap = 0;
     float* colsum_part = nullptr;
+    float* colsum_part2 = nullptr;     // for the predict-bias colsum on the side stream
 };
 
 struct BeamBuf {
@@ -109,6 +110,8 @@ struct Butd {
     int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t low_st = nullptr;        // lowest-priority stream for work overlapped with the BPTT chain
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st);
 
     // beam search (butd_beam.hip)

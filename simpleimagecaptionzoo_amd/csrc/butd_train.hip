@@ -74,6 +74,7 @@ int Butd::ensure_train(int B, int T) {
         size_t nmax = Vp > 4 * H ? Vp : 4 * H;
         if (A > nmax) nmax = A;
         ICZ_TRY(zalloc((void**)&tb.colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
+        ICZ_TRY(zalloc((void**)&tb.colsum_part2, sizeof(float) * COLSUM_PARTS * nmax));
     }
     (void)V;
     tb.B = B;
@@ -409,22 +410,46 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     const float* feats = cur_feats;
     const size_t sH = (size_t)B * H;
 
-    // ---- predict layer, all time steps at once
+    // ---- predict layer, all time steps at once.  d h2drop feeds the BPTT chain; the weight / bias gradients of
+    //      `predict` depend only on dlogits, so they run on the side stream concurrently with the (skinny,
+    //      latency-bound) BPTT chain and are joined at the end.
+    if (!low_st) {
+        int lo = 0, hi = 0;
+        ICZ_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));      // lo = least urgent
+        ICZ_CHECK_HIP(hipStreamCreateWithPriority(&low_st, hipStreamNonBlocking, lo));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+    }
+    hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
+    ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
+    ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
+    {
+        hipStream_t sb = low_st;      // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
+        int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb);
+        // colsum scratch is shared with the main chain's later colsums: use the tail of dWp's neighbour? no -- a private one
+        int KS = cdiv(TB, 16);
+        if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
+        const int rows_per = cdiv(TB, KS);
+        KS = cdiv(TB, rows_per);
+        hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(V, 256), KS), dim3(256), 0, sb, tb.logit, TB, V, Vp, rows_per, tb.colsum_part2);
+        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(V, 256)), dim3(256), 0, sb, tb.colsum_part2, KS, V, G.predict_b);
+        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, sb, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
+                           G.predict_v, G.predict_g, V, H);
+        ICZ_CHECK_HIP(hipEventRecord(ev_join, sb));
+        if (s1 != ICZ_OK) { (void)hipStreamWaitEvent(st, ev_join, 0); return s1; }
+    }
     {
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {tb.logit, w_pred, Vp, H, Vp, nullptr};
         g.M = TB; g.N = H; g.out = tb.dH2d; g.ldo = H;
         int ns;
-        ICZ_TRY(gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st));
+        const int sg = gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st);
+        if (sg != ICZ_OK) { (void)hipStreamWaitEvent(st, ev_join, 0); return sg; }
         if (ns > 1) {
             size_t MN = (size_t)TB * H;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, H, (const float*)nullptr, tb.dH2d);
         }
-        ICZ_TRY(wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, st));
-        ICZ_TRY(colsum(tb.logit, TB, V, Vp, G.predict_b, st));
-        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
-                           G.predict_v, G.predict_g, V, H);
     }
     // ---- XE only: rows that dropped out of the batch must contribute zero (the sample path writes every row, and its
     //      accumulators are initialised by the first processed step)
@@ -552,6 +577,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
                        G.dec_att_v, G.dec_att_g, A, H);
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(1), dim3(256), 0, st, tb.dWaff, A, P.affine_v, P.affine_g, n_aff,
                        G.affine_v, G.affine_g, 1, A);
+    ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
