@@ -124,7 +124,6 @@ def main():
     if world > 1:
         torch.distributed.barrier()
     torch.cuda.synchronize()
-    lib().icz_prof_begin()
     t0 = time.perf_counter()
     run(args.steps)
     torch.cuda.synchronize()
@@ -132,8 +131,20 @@ def main():
         torch.distributed.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    # Live kernel timing for the roofline line: the same steps are run once more right here with a HIP event pair around
+    # every launch of the dominant kernel on its launch stream -- eagerly (kernel nodes of a replayed graph cannot be
+    # bracketed one by one) and with the side streams switched off, so that a pair measures the kernel alone, which is
+    # also how rocprofv3 sees it (it serialises concurrent branches).
     avg_us, bpl, fpl, nl = C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
-    lib().icz_prof_end(C.byref(avg_us), C.byref(bpl), C.byref(fpl), C.byref(nl))
+    if rank == 0:
+        eng.use_graphs = False
+        eng._hot_handle().set_concurrent(False)
+        run(1)
+        torch.cuda.synchronize()
+        lib().icz_prof_begin()
+        run(3)
+        torch.cuda.synchronize()
+        lib().icz_prof_end(C.byref(avg_us), C.byref(bpl), C.byref(fpl), C.byref(nl))
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -155,6 +166,7 @@ def main():
                      "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
                      "avg_launch_us": avg_us.value, "launches": nl.value, "bytes_per_launch": bpl.value,
+                     "measured": "HIP event pair around every launch; eager single-stream re-run of the same steps right after the timed region",
                      "mfma_f32_tflops": ach_tf, "mfma_f32_frac": ach_tf / MFMA_F32_PEAK_TFLOPS},
     }
     if not args.no_cpu_baseline:

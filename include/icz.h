@@ -66,7 +66,9 @@ int icz_butd_destroy(icz_butd_t* h);
 /* Bind the (caller-owned, device-resident) parameters; pointers must stay valid while the handle is used. */
 int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
 /* Options.  "graphs" = 1: greedy / sample / sample_backward are captured into hipGraphs on first use and replayed
- * afterwards; the cache is keyed by every pointer and size in the call, so enable it only when buffers are reused. */
+ * afterwards; the cache is keyed by every pointer and size in the call, so enable it only when buffers are reused.
+ * "concurrent" = 0: independent chains (greedy vs sampled rollout, predict gradients vs BPTT) run on ONE stream instead
+ * of side streams (default 1); used by bench.py to time single kernels with events. */
 int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
 /* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream);

@@ -39,6 +39,9 @@ class ButdHandle:
         self._persistent = bool(on)
         check(lib().icz_butd_set_option(self._h, b"graphs", 1 if on else 0))
 
+    def set_concurrent(self, on=True):
+        check(lib().icz_butd_set_option(self._h, b"concurrent", 1 if on else 0))
+
     def _buf(self, name, shape, dtype):
         if not self._persistent:
             return torch.zeros(shape, dtype=dtype, device=self.device)

@@ -31,7 +31,7 @@ int Butd::init(const icz_butd_dims& d) {
     ICZ_TRY(alloc((void**)&w_enc, sizeof(float) * A * D));
     ICZ_TRY(alloc((void**)&w_dec, sizeof(float) * A * H));
     ICZ_TRY(alloc((void**)&w_aff, sizeof(float) * A));
-    const size_t Vp = (V + 3) & ~(size_t)3;     // padded rows stay zero: the dgrad GEMM reads K = Vp rows
+    const size_t Vp = pad_vocab(d.V);           // padded rows stay zero: the dgrad GEMM reads K = Vp rows
     ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * Vp * H));
     ICZ_CHECK_HIP(hipMemset(w_pred, 0, sizeof(float) * Vp * H));
     ICZ_TRY(alloc((void**)&n_enc, sizeof(float) * A));
@@ -144,7 +144,7 @@ int Butd::prologue(const float* feats, int n_img, hipStream_t st) {
 // One decoder step (:172-182) for `rows` decoder rows.  State is read from s.*_in and written to s.*_out.
 int Butd::step(const StepIO& s, hipStream_t st) {
     const int R = dims.R, D = dims.D, H = dims.H, E = dims.E, A = dims.A, V = dims.V;
-    const int Vp = (V + 3) & ~3;
+    const int Vp = pad_vocab(V);
     const int rows = s.rows;
     float* const ws = s.ws_alt ? s.ws_alt : this->ws;
     float* const scores = s.scores_alt ? s.scores_alt : this->scores;
@@ -232,7 +232,7 @@ int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out,
     ICZ_TRY(zero_state(B, 0, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
     int cur = 0;
-    const int Vp = (dims.V + 3) & ~3;
+    const int Vp = pad_vocab(dims.V);
     for (int t = 0; t < max_len; ++t) {
         StepIO s = {};
         s.rows = B; s.feats = feats; s.it = it;
@@ -292,6 +292,7 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
     ICZ_REQUIRE(h && name, "icz_butd_set_option: null argument");
     Butd* b = reinterpret_cast<Butd*>(h);
     if (strcmp(name, "graphs") == 0) { b->use_graphs = value != 0; return ICZ_OK; }
+    if (strcmp(name, "concurrent") == 0) { b->concurrent = value != 0; return ICZ_OK; }
     set_error("icz_butd_set_option: unknown option '%s'", name);
     return ICZ_ERR_INVALID;
 }

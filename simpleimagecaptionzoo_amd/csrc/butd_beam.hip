@@ -219,7 +219,7 @@ int Butd::beam_search(const float* feats, int n_img, int k, int max_steps, float
         s.h1_in = h1[0]; s.c1_in = c1[0]; s.h2_in = h2[0]; s.c2_in = c2[0];
         s.h1_out = h1[1]; s.c1_out = c1[1]; s.h2_out = h2[1]; s.c2_out = c2[1];
         ICZ_TRY(this->step(s, st));
-        BeamArgs a = {logits, dims.V, (dims.V + 3) & ~3, k, step, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
+        BeamArgs a = {logits, dims.V, pad_vocab(dims.V), k, step, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + step};
         hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(256), 0, st, a);
         hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h1[1], c1[1], h2[1], c2[1],

@@ -99,6 +99,7 @@ struct Butd {
     struct GraphEntry { std::vector<uintptr_t> key; hipGraphExec_t exec; uint64_t last_use; };
     std::vector<GraphEntry> graphs;
     bool use_graphs = false;
+    bool concurrent = true;      // run independent chains on side streams (off: one stream, for per-kernel timing)
     hipStream_t cap_st = nullptr;
     uint64_t tick = 0;
     template <class F> int run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn);
@@ -145,12 +146,16 @@ struct Butd {
     int bptt(const icz_butd_params& G, hipStream_t st);
 };
 
-void gemm_set_capturing(bool on);     // gemm_f32.hip: no event timing inside a stream capture
+void gemm_set_capturing(bool on);
+bool gemm_prof_on();                  // gemm_f32.hip: event timing active (graphs captured now contain event nodes)
 
 template <class F>
-int Butd::run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn) {
+int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& fn) {
     if (!use_graphs) return fn(st);
     ++tick;
+    std::vector<uintptr_t> key = key_in;
+    key.push_back(concurrent ? 1 : 0);          // flags that change the captured launch sequence
+    key.push_back(gemm_prof_on() ? 1 : 0);
     for (auto& e : graphs)
         if (e.key == key) {
             e.last_use = tick;

@@ -438,11 +438,31 @@ struct SampleSelArgs {
     int32_t* draw_out;            // [rows] raw draw (for backward)
     float* lse_out;               // [rows] max + log(sum exp) (for backward)
 };
-__global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
+constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS, every pass is LDS-bound
+__device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
+    v = wave_max(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int w = 1; w < nw; ++w) r = fmaxf(r, sm[w]);
+    __syncthreads();
+    return r;
+}
+__device__ __forceinline__ float block_sum_n(float v, float* sm, int nw) {
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
+    __syncthreads();
+    float r = sm[0];
+    for (int w = 1; w < nw; ++w) r += sm[w];
+    __syncthreads();
+    return r;
+}
+__global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the row, then its probabilities
-    __shared__ float smf[4];
-    __shared__ double smd[256];
-    __shared__ int smi[4];
+    __shared__ float smf[16];
+    __shared__ double smd[16];
+    __shared__ int smi[16];
+    constexpr int NW = SEL_THREADS / 64;
     const int row = blockIdx.x, tid = threadIdx.x;
     const bool dead = (a.t > 0) && (a.n_unfinished[a.t - 1] == 0);
     if (dead) {
@@ -458,20 +478,20 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     const float* l = a.logits + (size_t)row * a.ldl;
     // one coalesced pass over HBM/L2; every later pass (any access pattern) runs out of LDS
     float mx = -INFINITY;
-    for (int v = tid; v < a.V; v += 256) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
-    mx = block_max_256(mx, smf);
+    for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
+    mx = block_max_n(mx, smf, NW);
     float se = 0.f;
-    for (int v = tid; v < a.V; v += 256) se += expf(srow[v] - mx);
-    se = block_sum_256(se, smf);
+    for (int v = tid; v < a.V; v += SEL_THREADS) se += expf(srow[v] - mx);
+    se = block_sum_n(se, smf, NW);
     const float lse = logf(se);
-    for (int v = tid; v < a.V; v += 256) srow[v] = expf((srow[v] - mx) - lse);     // p = exp(log_softmax)
+    for (int v = tid; v < a.V; v += SEL_THREADS) srow[v] = expf((srow[v] - mx) - lse);     // p = exp(log_softmax)
     __syncthreads();
     // contiguous slice per thread -> the global "first index above target" is the minimum over threads
-    const int per = (a.V + 255) / 256;
-    const int v0 = tid * per, v1 = min(a.V, v0 + per);
+    const int per = (a.V + SEL_THREADS - 1) / SEL_THREADS;
+    const int v0 = min(a.V, tid * per), v1 = min(a.V, v0 + per);
     double loc = 0.0;
     for (int v = v0; v < v1; ++v) loc += (double)srow[v];
-    // exclusive prefix over the 256 slice sums: wave-level inclusive scan (shuffles) + the 4 wave totals
+    // exclusive prefix over the slice sums: wave-level inclusive scan (shuffles) + the wave totals
     double inc = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -480,9 +500,11 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     }
     if ((tid & 63) == 63) smd[tid >> 6] = inc;
     __syncthreads();
-    double wave_off = 0.0;
-    for (int w = 0; w < (tid >> 6); ++w) wave_off += smd[w];
-    const double total = ((smd[0] + smd[1]) + smd[2]) + smd[3];
+    double wave_off = 0.0, total = 0.0;
+    for (int w = 0; w < NW; ++w) {
+        if (w < (tid >> 6)) wave_off += smd[w];
+        total += smd[w];
+    }
     const double prefix = wave_off + inc - loc;
     const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
     const double target = (double)u * total;
@@ -499,7 +521,8 @@ __global__ __launch_bounds__(256) void sample_select_kernel(SampleSelArgs a) {
     if ((tid & 63) == 0) smi[tid >> 6] = cand;
     __syncthreads();
     if (tid == 0) {
-        int d = min(min(smi[0], smi[1]), min(smi[2], smi[3]));
+        int d = smi[0];
+        for (int w = 1; w < NW; ++w) d = min(d, smi[w]);
         if (d > a.V - 1) d = a.V - 1;
         const float lp = (l[d] - mx) - lse;
         bool unf = a.unfinished[row] != 0;

@@ -7,7 +7,7 @@
 
 namespace icz {
 
-static inline int round4(int x) { return (x + 3) & ~3; }
+static inline int round4(int x) { return pad_vocab(x); }   // (historic name) padded vocabulary size
 
 __global__ void sample_init_kernel(uint8_t* unf, int* nunf, int64_t* tok, int B, int T) {
     const int i = blockIdx.x * blockDim.x + threadIdx.x;
@@ -163,6 +163,10 @@ int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* 
 
 int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
     ICZ_TRY(prologue(feats, B, st));
+    if (!concurrent) {
+        ICZ_TRY(greedy_chain(feats, B, T, ids_out, nullptr, st));
+        return sample_chain(feats, B, T, seq_out, logp_out, st);
+    }
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
     const int sg = greedy_chain(feats, B, T, ids_out, nullptr, side_st);
@@ -192,7 +196,7 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
         a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tb.tok + (size_t)(t + 1) * B;
         a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
-        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(256), sizeof(float) * dims.V, st, a);
+        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
@@ -424,7 +428,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
     {
-        hipStream_t sb = low_st;      // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
+        hipStream_t sb = concurrent ? low_st : st;   // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
         int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb);
         // colsum scratch is shared with the main chain's later colsums: use the tail of dWp's neighbour? no -- a private one
         int KS = cdiv(TB, 16);

@@ -464,6 +464,7 @@ struct GemmProf {
     std::vector<hipEvent_t> ev;      // pairs
     size_t used = 0;
     double bytes = 0.0, flops = 0.0;
+    unsigned seen = 0, every = 1;     // bracket every `every`-th launch (ICZ_PROF_EVERY): fewer event packets in the stream
 };
 static GemmProf g_prof;
 static thread_local bool g_capturing = false;
@@ -556,10 +557,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         const int bn = nt_tile_n(a);
         dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        if (g_prof.on && mt == 4 && !g_capturing) {
-            if (g_prof.used + 2 > g_prof.ev.size()) {
-                for (int i = 0; i < 512; ++i) { hipEvent_t e; if (hipEventCreate(&e) == hipSuccess) g_prof.ev.push_back(e); }
-            }
+        // inside a stream capture the two records become event nodes of the graph: every replay refreshes them
+        if (g_prof.on && mt == 4 && (g_prof.seen++ % g_prof.every) == 0) {
             if (g_prof.used + 2 <= g_prof.ev.size()) {
                 e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
                 g_prof.used += 2;
@@ -588,8 +587,12 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     return ICZ_OK;
 }
 
+bool gemm_prof_on() { return g_prof.on; }
 void gemm_prof_begin() {
-    g_prof.on = true; g_prof.used = 0; g_prof.bytes = 0.0; g_prof.flops = 0.0;
+    g_prof.on = true; g_prof.used = 0; g_prof.bytes = 0.0; g_prof.flops = 0.0; g_prof.seen = 0;
+    // the whole pool is created here: events cannot be created while a stream capture is in progress
+    while (g_prof.ev.size() < 8192) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; g_prof.ev.push_back(e); }
+    { const char* e = getenv("ICZ_PROF_EVERY"); g_prof.every = e ? (unsigned)atoi(e) : 1; if (g_prof.every < 1) g_prof.every = 1; }
 }
 int gemm_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
     g_prof.on = false;

@@ -35,6 +35,9 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// padded vocabulary size (row stride of logits, rows of the materialised predict weight): a multiple of 64 so that
+// V can be the K dimension of a GEMM on the fast (tail-free) path; pad entries are kept at zero
+static inline int pad_vocab(int V) { return (V + 63) & ~63; }
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
