@@ -140,6 +140,39 @@ int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* i
                   float* h2, float* c2, float* ctx_out, float* alpha_out, float* logits_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * NIC decoder (Models/NIC_Model.py:39-212, DecoderRNN): plain embedding -> one LSTMCell -> predict; the image
+ * embedding `features` [B,E] (output of the CNN encoder, outside the hot path) enters through one LSTM step from the
+ * zero state (:52-56).  Same conventions as the BUTD entry points; of icz_rng only `uniforms` and `out_mask` are used.
+ * dfeatures_out [B,E] (may be NULL) receives d loss / d features for an upstream encoder.
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct icz_nic icz_nic_t;
+typedef struct { int32_t E, H, V, max_rows, max_len; } icz_nic_dims;
+typedef struct {
+    float* embed_weight;                  /* embed.weight   [V, E]                         */
+    float *w_ih, *w_hh, *b_ih, *b_hh;     /* lstm.*         [4H, E] [4H, H] [4H] [4H]      */
+    float *predict_v, *predict_g, *predict_b;   /* predict.weight_v [V,H], weight_g [V,1], bias [V] */
+} icz_nic_params;
+int icz_nic_create(const icz_nic_dims* dims, icz_nic_t** out);
+int icz_nic_destroy(icz_nic_t* h);
+int icz_nic_bind_params(icz_nic_t* h, const icz_nic_params* params);
+int icz_nic_refresh_weights(icz_nic_t* h, void* stream);
+/* DecoderRNN.sample, NIC_Model.py:100-119 */
+int icz_nic_greedy(icz_nic_t* h, const float* features, int32_t B, int32_t max_len, int64_t* ids_out, void* stream);
+/* DecoderRNN.sample_rl, NIC_Model.py:121-151, and RewardCriterion + backward (Utils.py:295-317) */
+int icz_nic_sample(icz_nic_t* h, const float* features, int32_t B, int32_t max_len, const icz_rng* rng, int64_t* seq_out,
+                   float* logprobs_out, void* stream);
+int icz_nic_sample_backward(icz_nic_t* h, const float* reward, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
+                            float* mask_sum_out, float mask_sum_global, void* stream);
+/* DecoderRNN.forward, NIC_Model.py:58-98, and LabelSmoothingLoss + backward (Utils.py:268-286) */
+int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,
+                       const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream);
+int icz_nic_xe_backward(icz_nic_t* h, float smoothing, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
+                        float n_tokens_global, void* stream);
+/* DecoderRNN.beam_search_sample, NIC_Model.py:153-212 (batched over images) */
+int icz_nic_beam_search(icz_nic_t* h, const float* features, int32_t n_img, int32_t beam, int32_t max_steps, float* seqs_out,
+                        int32_t* lens_out, void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Optimiser step: clip_gradient (Utils.py:241-250, value clamp) + torch.optim.Adam(betas=(0.9,0.999),
  * eps=1e-8, weight_decay=0) (Utils.py:219-220) fused, one call per parameter tensor.
  * ---------------------------------------------------------------------------------------------------------- */

@@ -40,6 +40,20 @@ BUTD_PARAM_KEYS = (
 )
 
 
+class NicDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("E", "H", "V", "max_rows", "max_len")]
+
+
+NIC_PARAM_FIELDS = ("embed_weight", "w_ih", "w_hh", "b_ih", "b_hh", "predict_v", "predict_g", "predict_b")
+# reference state_dict keys of Models/NIC_Model.py DecoderRNN (:47-49)
+NIC_PARAM_KEYS = ("embed.weight", "lstm.weight_ih", "lstm.weight_hh", "lstm.bias_ih", "lstm.bias_hh",
+                  "predict.weight_v", "predict.weight_g", "predict.bias")
+
+
+class NicParams(C.Structure):
+    _fields_ = [(n, C.c_void_p) for n in NIC_PARAM_FIELDS]
+
+
 class ButdParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in BUTD_PARAM_FIELDS]
 
@@ -82,6 +96,16 @@ def lib():
         "icz_butd_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_butd_xe_backward": (C.c_int, [vp, f32, C.POINTER(ButdParams), vp, f32, vp]),
         "icz_adam_clamp_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, i32, vp]),
+        "icz_nic_create": (C.c_int, [C.POINTER(NicDims), C.POINTER(vp)]),
+        "icz_nic_destroy": (C.c_int, [vp]),
+        "icz_nic_bind_params": (C.c_int, [vp, C.POINTER(NicParams)]),
+        "icz_nic_refresh_weights": (C.c_int, [vp, vp]),
+        "icz_nic_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "icz_nic_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(Rng), vp, vp, vp]),
+        "icz_nic_sample_backward": (C.c_int, [vp, vp, C.POINTER(NicParams), vp, vp, vp, f32, vp]),
+        "icz_nic_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
+        "icz_nic_xe_backward": (C.c_int, [vp, f32, C.POINTER(NicParams), vp, vp, f32, vp]),
+        "icz_nic_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "icz_ciderd_create": (C.c_int, [vp, vp, i64, C.c_double, vp, C.POINTER(vp)]),
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -55,6 +55,7 @@ struct BeamBuf {
     int* n_act = nullptr; float* run = nullptr; int32_t* seqs[2] = {nullptr, nullptr};
     int32_t *src_row = nullptr, *img_of_row = nullptr, *best_seq = nullptr;
     float* best_score = nullptr; int *best_len = nullptr, *has_complete = nullptr, *n_live = nullptr, *n_live_host = nullptr;
+    float* feat_rows = nullptr;       // NIC: image embedding replicated per beam row
 };
 
 struct Butd {

@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // Embedding -> ReLU -> Dropout (:77-81):  emb[row,:] = relu(E[it[row],:]) * keep * 2
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ table, const int64_t* __restrict__ it,
-                                                    float* __restrict__ emb, int rows, int E, DropCfg dc) {
+                                                    float* __restrict__ emb, int rows, int E, DropCfg dc, int relu = 1) {
     const int row = blockIdx.y;
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= E) return;
@@ -74,7 +74,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
     uint32_t k = dc.mode ? dc.keep4((uint64_t)row * E + e) : 0xFu;
     const float sc = dc.mode ? 2.0f : 1.0f;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
+    for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? (relu ? fmaxf(x[j], 0.f) : x[j]) * sc : 0.f;
     *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
@@ -358,7 +358,7 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restric
 __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restrict__ part_val, const int* __restrict__ part_idx, int P,
                                                            const float* __restrict__ table, int E, float* __restrict__ emb,
                                                            int64_t* __restrict__ it_next, int64_t* __restrict__ ids_out,
-                                                           int ids_stride, int t) {
+                                                           int ids_stride, int t, int relu = 1) {
     const int row = blockIdx.y;
     float best = part_val[row * P];
     int bi = part_idx[row * P];
@@ -371,7 +371,7 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
     if (e >= E) return;
     f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)bi * E + e);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+    for (int j = 0; j < 4; ++j) x[j] = relu ? fmaxf(x[j], 0.f) : x[j];
     *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ 
 __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, int n_tok,
                                                          const float* __restrict__ demb, int ns, size_t slab_stride,
                                                          const float* __restrict__ emb, float scale, int E,
-                                                         float* __restrict__ dE) {
+                                                         float* __restrict__ dE, int relu = 1) {
     extern __shared__ int hits[];     // indices of matching (t,b) entries, capacity n_tok
     __shared__ int nhit;
     const int v = blockIdx.x, tid = threadIdx.x;
@@ -935,9 +935,13 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restri
         for (int h = 0; h < nh; ++h) {
             const size_t off = (size_t)hits[h] * E + e;
             f32x4 g = sum_slabs4(demb, ns, slab_stride, off);
-            f32x4 x = *reinterpret_cast<const f32x4*>(emb + off);
+            if (relu) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(emb + off);
 #pragma unroll
-            for (int j = 0; j < 4; ++j) s[j] += x[j] > 0.f ? g[j] * scale : 0.f;
+                for (int j = 0; j < 4; ++j) s[j] += x[j] > 0.f ? g[j] * scale : 0.f;
+            } else {
+                s += g * scale;
+            }
         }
         *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e) = s;
     }

@@ -331,6 +331,105 @@ def gen_butd_decoder(tag, B, R, D, H, E, A, V, seed):
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_nic_decoder(tag, B, H, E, V, seed):
+    """NIC single-LSTM decoder (Models/NIC_Model.py:39-212): greedy, beam, XE, sample_rl + REINFORCE."""
+    from Models.NIC_Model import DecoderRNN
+    from Utils import LabelSmoothingLoss, RewardCriterion
+    from torch.nn.utils.rnn import pack_padded_sequence
+    torch.manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    dec = DecoderRNN(embed_dim=E, hidden_dim=H, vocab_size=V)
+    with torch.no_grad():            # decisive outputs (see sharpen())
+        dec.embed.weight.mul_(4.0)
+        dec.lstm.weight_ih.mul_(4.0)
+        dec.lstm.weight_hh.mul_(0.5)
+        dec.predict.weight_g.mul_(20.0)
+        dec.predict.bias.copy_(torch.randn(V) * 0.3)
+    feats = torch.randn(B, E)
+    out = {"feats": feats.numpy(), "dims": np.array([B, H, E, V], dtype=np.int64)}
+    out.update({"sd." + k: v for k, v in sd_to_np(dec.state_dict()).items()})
+    dec.eval()
+    rec = []
+    hk = dec.predict.register_forward_hook(lambda m, i, o: rec.append(o.detach().clone()))
+    with torch.no_grad():
+        ids = dec.sample(feats, max_len=20)
+    hk.remove()
+    out.update(greedy_ids=ids.numpy(), greedy_logits=torch.stack(rec, 1).numpy())
+    base_bias = dec.predict.bias.detach().clone()
+    base_v2 = dec.predict.weight_v.detach()[2].clone()
+    base_g2 = dec.predict.weight_g.detach()[2].clone()
+    tok = int(np.bincount(ids.numpy().ravel()).argmax())
+    out["beam_track_tok"] = np.int64(tok)
+    for regime, end_bias in (("nat", None), ("early", 4.0), ("never", -1e4), ("track", None)):
+        with torch.no_grad():
+            dec.predict.bias.copy_(base_bias)
+            if end_bias is not None:
+                dec.predict.bias[2] = end_bias
+            if regime == "track":
+                dec.predict.weight_v[2] = dec.predict.weight_v[tok]
+                dec.predict.weight_g[2] = dec.predict.weight_g[tok]
+                dec.predict.bias[2] = dec.predict.bias[tok] - 0.2
+        for k in (1, 3, 5):
+            for img in range(min(B, 3)):
+                with torch.no_grad(), legacy_int_div():
+                    seq = dec.beam_search_sample(feats[img:img + 1], beam_size=k)
+                out["beam_%s_k%d_i%d" % (regime, k, img)] = np.asarray(seq.numpy(), dtype=np.float32)
+    with torch.no_grad():
+        dec.predict.bias.copy_(base_bias)
+        dec.predict.weight_v[2] = base_v2
+        dec.predict.weight_g[2] = base_g2
+    # XE
+    lengths_full = sorted(rng.randint(6, 13, size=B).tolist(), reverse=True)
+    L = max(lengths_full)
+    caps = np.zeros((B, L), dtype=np.int64)
+    for b, l in enumerate(lengths_full):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = rng.randint(4, V, size=l - 2)
+        caps[b, l - 1] = 2
+    captions = torch.from_numpy(caps)
+    lengths = [l - 1 for l in lengths_full]
+    T = max(lengths)
+    xe_out_mask = (rng.rand(T, B, H) < 0.5).astype(np.uint8)
+    dec.train()
+    dec.zero_grad()
+    f_xe = feats.clone().requires_grad_(True)
+    INJ.set([xe_out_mask], None)
+    with injected():
+        packed = dec(f_xe, captions, lengths)
+    targets = pack_padded_sequence(captions[:, 1:], lengths, batch_first=True)
+    loss = LabelSmoothingLoss(smoothing=0.1)(packed[0], targets[0])
+    loss.backward()
+    out.update(xe_captions=caps, xe_lengths=np.array(lengths), xe_out_mask=xe_out_mask,
+               xe_packed_logits=packed[0].detach().numpy(), xe_loss=np.float32(loss.item()),
+               xe_dfeats=f_xe.grad.numpy().copy())
+    for n_, p in dec.named_parameters():
+        out["xe_grad." + n_] = p.grad.detach().numpy().copy()
+    # sample_rl
+    T = 20
+    rl_out_mask = (rng.rand(T, B, H) < 0.5).astype(np.uint8)
+    rl_u = rng.rand(T, B)
+    with torch.no_grad():
+        dec.predict.bias[2] = 2.5
+    out["rl_end_bias"] = np.float32(2.5)
+    dec.train()
+    dec.zero_grad()
+    f_rl = feats.clone().requires_grad_(True)
+    INJ.set([rl_out_mask], rl_u)
+    with injected():
+        seq, slp = dec.sample_rl(f_rl, max_len=T)
+    reward = torch.from_numpy(rng.randn(B, 1).astype(np.float32)).repeat(1, T)
+    rl_loss = RewardCriterion()(slp, seq, reward)
+    rl_loss.backward()
+    out.update(rl_out_mask=rl_out_mask, rl_u=rl_u, rl_seq=seq.numpy(), rl_logprobs=slp.detach().numpy(),
+               rl_reward=reward.numpy(), rl_loss=np.float32(rl_loss.item()), rl_dfeats=f_rl.grad.numpy().copy())
+    for n_, p in dec.named_parameters():
+        out["rl_grad." + n_] = p.grad.detach().numpy().copy()
+    with torch.no_grad():
+        dec.predict.bias.copy_(base_bias)
+    save(tag, **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_cider(tag, seed):
     """G-cider: CiderD.compute_score (ciderD.py:30-55) on hand-made edge cases + abstract48S sample."""
     from cider.pyciderevalcap.ciderD.ciderD import CiderD
@@ -593,10 +692,13 @@ def gen_engine(tag, seed, B=6, V=53, H=16, E=16, A=16):
 if __name__ == "__main__":
     bootstrap()
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["butd", "cider", "engine"]
+    which = sys.argv[1:] or ["butd", "nic", "cider", "engine"]
     if "butd" in which:
         gen_butd_decoder("butd_dec_tiny", B=5, R=36, D=64, H=32, E=32, A=32, V=53, seed=11)
         gen_butd_decoder("butd_dec_odd", B=3, R=36, D=96, H=48, E=16, A=64, V=70, seed=12)
+    if "nic" in which:
+        gen_nic_decoder("nic_dec_tiny", B=5, H=32, E=32, V=53, seed=31)
+        gen_nic_decoder("nic_dec_odd", B=3, H=48, E=16, V=70, seed=32)
     if "cider" in which:
         gen_cider("ciderd_cases", seed=5)
     if "engine" in which:

@@ -1,0 +1,103 @@
+"""GPU parity of the NIC decoder (csrc/nic.hip) against the reference goldens."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def load(golden_dir, name):
+    return dict(np.load(os.path.join(golden_dir, name + ".npz")))
+
+
+def make(g, sd=None, max_rows=16):
+    from simpleimagecaptionzoo_amd.nic import NicHandle
+    B, H, E, V = [int(x) for x in g["dims"]]
+    sd = sd if sd is not None else {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    params = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device="cuda") for k, v in sd.items()}
+    h = NicHandle(E, H, V, max_rows, 20)
+    h.bind(params)
+    return h
+
+
+def regime_sd(g, regime):
+    sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
+    if regime == "early":
+        sd["predict.bias"][2] = 4.0
+    elif regime == "never":
+        sd["predict.bias"][2] = -1e4
+    elif regime == "track":
+        tok = int(g["beam_track_tok"])
+        sd["predict.weight_v"][2] = sd["predict.weight_v"][tok]
+        sd["predict.weight_g"][2] = sd["predict.weight_g"][tok]
+        sd["predict.bias"][2] = sd["predict.bias"][tok] - 0.2
+    return sd
+
+
+def check_grads(grads, g, prefix):
+    for k, v in grads.items():
+        want = g[prefix + k]
+        got = v.cpu().numpy()
+        scale = max(1e-3, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 2e-4 * scale + 2e-6, (k, np.abs(got - want).max(), scale)
+
+
+@pytest.mark.parametrize("name", ["nic_dec_tiny", "nic_dec_odd"])
+def test_nic_greedy_and_beam_token_exact(golden_dir, name):
+    g = load(golden_dir, name)
+    feats = torch.tensor(g["feats"], device="cuda")
+    h = make(g)
+    assert np.array_equal(h.greedy(feats, 20).cpu().numpy(), g["greedy_ids"])
+    n = min(feats.shape[0], 3)
+    for regime in ("nat", "early", "never", "track"):
+        h = make(g, regime_sd(g, regime))
+        for k in (1, 3, 5):
+            seqs, lens = h.beam_search(feats[:n], k, 50)
+            seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+            for i in range(n):
+                want = g["beam_%s_k%d_i%d" % (regime, k, i)].ravel()
+                assert lens[i] == want.shape[0] and np.array_equal(seqs[i, :lens[i]], want), (regime, k, i)
+
+
+@pytest.mark.parametrize("name", ["nic_dec_tiny", "nic_dec_odd"])
+def test_nic_xe_and_reinforce_gradients(golden_dir, name):
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    g = load(golden_dir, name)
+    feats = torch.tensor(g["feats"], device="cuda")
+    h = make(g)
+    rng = make_rng(0, None, None, None, torch.tensor(g["xe_out_mask"], device="cuda"))
+    logits = h.xe_forward(feats, torch.tensor(g["xe_captions"], device="cuda"), g["xe_lengths"].tolist(), rng, True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+    grads = h.new_grads()
+    loss, dfe = h.xe_backward(grads, 0.1, want_dfeats=True)
+    assert abs(loss.item() - float(g["xe_loss"])) < 1e-4
+    check_grads(grads, g, "xe_grad.")
+    np.testing.assert_allclose(dfe.cpu().numpy(), g["xe_dfeats"], atol=2e-5, rtol=2e-4)
+    # sample_rl + REINFORCE
+    sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
+    sd["predict.bias"][2] = float(g["rl_end_bias"])
+    h = make(g, sd)
+    rng = make_rng(0, torch.tensor(g["rl_u"], dtype=torch.float32, device="cuda"), None, None, torch.tensor(g["rl_out_mask"], device="cuda"))
+    seq, lp = h.sample(feats, 20, rng)
+    assert np.array_equal(seq.cpu().numpy(), g["rl_seq"])
+    np.testing.assert_allclose(lp.cpu().numpy(), g["rl_logprobs"], atol=1e-4)
+    grads = h.new_grads()
+    loss, msum, dfe = h.sample_backward(torch.tensor(g["rl_reward"], device="cuda"), grads, want_dfeats=True)
+    assert abs(loss.item() - float(g["rl_loss"])) < 1e-4
+    check_grads(grads, g, "rl_grad.")
+    np.testing.assert_allclose(dfe.cpu().numpy(), g["rl_dfeats"], atol=2e-5, rtol=2e-4)
+
+
+def test_nic_captioner_state_dict_keys(golden_dir):
+    from simpleimagecaptionzoo_amd.nic import NICDecoder_Captioner
+    g = load(golden_dir, "nic_dec_tiny")
+    B, H, E, V = [int(x) for x in g["dims"]]
+    cap = NICDecoder_Captioner(E, H, V, max_batch=8).cuda()
+    want = sorted("decoder." + k[3:] for k in g if k.startswith("sd."))
+    assert sorted(cap.state_dict().keys()) == want
+    cap.load_state_dict({"decoder." + k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")})
+    cap.eval()
+    ids = cap.sampler({"img_feats": torch.tensor(g["feats"], device="cuda")}, 20)
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])

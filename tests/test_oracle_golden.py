@@ -228,3 +228,54 @@ def test_engine_xe_then_scst_steps(eng):
         grads = dict(zip(p.keys(), torch.autograd.grad(loss, list(p.values()))))
         opt.step(grads, 0.25)
         check_pinned(g, pre + "sd.", p, slack=8e-4 + 2e-5 * (s + 1))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module", params=["nic_dec_tiny", "nic_dec_odd"])
+def nic(request, golden_dir):
+    from oracle import nic as on_
+    g = load(golden_dir, request.param)
+    return on_, g, ob.to_params(sd_of(g)), torch.from_numpy(g["feats"])
+
+
+def test_nic_greedy_and_beam(nic):
+    on_, g, p, feats = nic
+    ids, logits = on_.greedy(feats, p, 20)
+    assert np.array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(logits.numpy(), g["greedy_logits"], atol=1e-4)
+    for regime, k, img in BEAM_CASES:
+        q = beam_regime_params(p, g, regime)
+        want = g["beam_%s_k%d_i%d" % (regime, k, img)]
+        got = on_.beam_search(feats[img:img + 1], q, k).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img)
+
+
+def test_nic_xe_and_rl_grads(nic):
+    on_, g, _, feats = nic
+    B, H, E, V = g["dims"]
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    f = feats.clone().requires_grad_(True)
+    lengths = g["xe_lengths"].tolist()
+    logits = on_.forward_xe(f, torch.from_numpy(g["xe_captions"]), lengths, p, g["xe_out_mask"])
+    np.testing.assert_allclose(logits.detach().numpy(), g["xe_packed_logits"], atol=1e-4)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["xe_loss"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["xe_grad." + k], atol=2e-5, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(f.grad.numpy(), g["xe_dfeats"], atol=2e-5, rtol=1e-4)
+    # REINFORCE
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    with torch.no_grad():
+        p["predict.bias"][2] = float(g["rl_end_bias"])
+    f = feats.clone().requires_grad_(True)
+    seq, lp = on_.sample_rl(f, p, g["rl_u"], g["rl_out_mask"], 20)
+    assert np.array_equal(seq.numpy(), g["rl_seq"])
+    np.testing.assert_allclose(lp.detach().numpy(), g["rl_logprobs"], atol=1e-5)
+    loss = ob.reward_criterion(lp, seq, torch.from_numpy(g["rl_reward"]))
+    assert abs(loss.item() - float(g["rl_loss"])) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["rl_grad." + k], atol=2e-6, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(f.grad.numpy(), g["rl_dfeats"], atol=2e-6, rtol=1e-4)
