@@ -92,9 +92,21 @@ class Injector:
         self.uniforms = uniforms
         self.reset()
 
+    def set_sequential(self, seed, uniforms=None):
+        """Masks are drawn on the fly (keep-probability 1-p, seeded) in call order and recorded in self.rec."""
+        self.seq_rng = np.random.RandomState(seed)
+        self.rec = []
+        self.masks = None
+        self.uniforms = uniforms
+        self.reset()
+
     def dropout(self, inp, p=0.5, training=True, inplace=False):
         if not training or p == 0.0:
             return inp
+        if self.masks is None:
+            m = (self.seq_rng.rand(*inp.shape) < (1.0 - p)).astype(np.uint8)
+            self.rec.append((float(p), m))
+            return inp * torch.from_numpy(m.astype(np.float32)) * (1.0 / (1.0 - p))
         n = len(self.masks)
         t, kind = divmod(self.d_calls, n)
         self.d_calls += 1
@@ -430,6 +442,148 @@ def gen_nic_decoder(tag, B, H, E, V, seed):
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_aoa(tag, B, Hd, E, V, seed):
+    """AoADetection_Captioner (Models/AoA_Model.py:657-753): feature projection + 6-layer AoA refiner (eval and train
+    mode), decoder greedy / beam / XE / sample_rl with REINFORCE gradients of the decoder parameters (the only ones the
+    reference optimises, AoA_Model.py:669-674)."""
+    from Models.AoA_Model import AoADetection_Captioner
+    from Utils import LabelSmoothingLoss, RewardCriterion
+    from torch.nn.utils.rnn import pack_padded_sequence
+    torch.manual_seed(seed)
+    rng = np.random.RandomState(seed)
+    R, D, NH = 36, 2048, 8
+    m = AoADetection_Captioner(vocab_size=V, num_heads=NH, hidden_dim=Hd, embed_dim=E)
+    dec = m.decoder
+    with torch.no_grad():
+        dec.embed[0].weight.mul_(30.0)
+        dec.lstm.weight_ih.mul_(3.0)
+        dec.lstm.weight_hh.mul_(0.5)
+        dec.predict.weight_g.mul_(15.0)
+        dec.predict.bias.copy_(torch.randn(V) * 0.3)
+        for name, prm in m.named_parameters():          # non-trivial LayerNorm gains / biases
+            if name.endswith("norm.gain") or name.endswith("h_norm.gain"):
+                prm.add_(torch.randn_like(prm) * 0.2)
+            if name.endswith("norm.bias") or name.endswith("h_norm.bias"):
+                prm.add_(torch.randn_like(prm) * 0.1)
+    fseed = seed * 1000 + 1
+    feats = torch.from_numpy(feats_from_seed(fseed, B, R, D))
+    out = {"dims": np.array([B, R, D, Hd, E, V, NH], dtype=np.int64), "feats_seed": np.int64(fseed)}
+    out.update({"sd." + k: v for k, v in sd_to_np(m.state_dict()).items()})
+    vi = {"bu_feats": feats, "bu_bboxes": None, "bu_masks": None}
+    m.eval()
+    with torch.no_grad():
+        refined = m.aoa_refine(m.img_feats_porjection(feats))
+    out["refined_eval"] = refined.numpy()
+    rec = []
+    hk = dec.predict.register_forward_hook(lambda mod, i, o: rec.append(o.detach().clone()))
+    with torch.no_grad():
+        ids = m.sampler(vi, max_len=20)
+    hk.remove()
+    out.update(greedy_ids=ids.numpy(), greedy_logits=torch.stack(rec, 1).numpy())
+    base_bias = dec.predict.bias.detach().clone()
+    base_v2 = dec.predict.weight_v.detach()[2].clone()
+    base_g2 = dec.predict.weight_g.detach()[2].clone()
+    tok = int(np.bincount(ids.numpy().ravel()).argmax())
+    out["beam_track_tok"] = np.int64(tok)
+    for regime, end_bias in (("nat", None), ("early", 4.0), ("never", -1e4), ("track", None)):
+        with torch.no_grad():
+            dec.predict.bias.copy_(base_bias)
+            if end_bias is not None:
+                dec.predict.bias[2] = end_bias
+            if regime == "track":
+                dec.predict.weight_v[2] = dec.predict.weight_v[tok]
+                dec.predict.weight_g[2] = dec.predict.weight_g[tok]
+                dec.predict.bias[2] = dec.predict.bias[tok] - 0.2
+        for k in (1, 3, 5):
+            for img in range(min(B, 3)):
+                one = {"bu_feats": feats[img:img + 1], "bu_bboxes": None, "bu_masks": None}
+                with torch.no_grad(), legacy_int_div():
+                    seq = m.beam_search_sampler(one, beam_size=k)
+                out["beam_%s_k%d_i%d" % (regime, k, img)] = np.asarray(seq.numpy(), dtype=np.float32)
+    with torch.no_grad():
+        dec.predict.bias.copy_(base_bias)
+        dec.predict.weight_v[2] = base_v2
+        dec.predict.weight_g[2] = base_g2
+
+    def split_masks(recs, T):
+        """recorded (p, mask) list in call order -> named arrays (bit-packed along the last axis)."""
+        it = iter(recs)
+        d = {"proj": next(it)[1]}
+        ra, rg, rs = [], [], []
+        for _ in range(6):
+            ra.append(next(it)[1]); rg.append(next(it)[1]); rs.append(next(it)[1])
+        d["ref_att"], d["ref_aoa"], d["ref_sc"] = np.stack(ra), np.stack(rg), np.stack(rs)
+        e, c, a, o = [], [], [], []
+        for _ in range(T):
+            e.append(next(it)[1]); c.append(next(it)[1]); a.append(next(it)[1]); o.append(next(it)[1])
+        def pad(lst):      # XE: the batch shrinks with t -> pad rows to B
+            full = np.zeros((T,) + (B,) + lst[0].shape[1:], dtype=np.uint8)
+            for t_, x in enumerate(lst):
+                full[t_, :x.shape[0]] = x
+            return full
+        d["emb"], d["ctx"], d["att"], d["out"] = pad([x.reshape(x.shape[0], -1) for x in e]), pad(c), pad(a), pad(o)
+        assert next(it, None) is None
+        return {k: np.packbits(v, axis=-1) for k, v in d.items()}, {k: v.shape[-1] for k, v in d.items()}
+
+    # ---- XE (train mode, every dropout site injected)
+    lengths_full = sorted(rng.randint(6, 13, size=B).tolist(), reverse=True)
+    L = max(lengths_full)
+    caps = np.zeros((B, L), dtype=np.int64)
+    for b, l in enumerate(lengths_full):
+        caps[b, 0] = 1
+        caps[b, 1:l - 1] = rng.randint(4, V, size=l - 2)
+        caps[b, l - 1] = 2
+    captions = torch.from_numpy(caps)
+    lengths = [l - 1 for l in lengths_full]
+    m.train()
+    m.zero_grad()
+    INJ.set_sequential(seed * 7 + 1)
+    with injected():
+        packed = m(vi, captions, lengths)
+    targets = pack_padded_sequence(captions[:, 1:], lengths, batch_first=True)
+    loss = LabelSmoothingLoss(smoothing=0.1)(packed[0], targets[0])
+    loss.backward()
+    mk, widths = split_masks(INJ.rec, max(lengths))
+    out.update({"xe_mask." + k: v for k, v in mk.items()})
+    out["mask_widths"] = np.array([widths[k] for k in ("proj", "ref_att", "ref_aoa", "ref_sc", "emb", "ctx", "att", "out")])
+    out.update(xe_captions=caps, xe_lengths=np.array(lengths), xe_packed_logits=packed[0].detach().numpy(),
+               xe_loss=np.float32(loss.item()))
+    for n_, p_ in dec.named_parameters():
+        out["xe_grad." + n_] = p_.grad.detach().numpy().copy()
+    # ---- sample_rl + REINFORCE
+    T = 20
+    rl_u = rng.rand(T, B)
+    with torch.no_grad():
+        dec.predict.bias[2] = 2.5
+    out["rl_end_bias"] = np.float32(2.5)
+    m.train()
+    m.zero_grad()
+    INJ.set_sequential(seed * 7 + 2, rl_u)
+    rec = []
+    hk = dec.predict.register_forward_hook(lambda mod, i, o: rec.append(o.detach().clone()))
+    with injected():
+        seq, slp = m.sampler_rl(vi, max_len=T)
+    hk.remove()
+    steps_run = len(rec)
+    # the rollout may stop early (all finished): pad the recorded per-step masks with zeros up to T
+    recs = list(INJ.rec)
+    while len(recs) < 19 + 4 * T:
+        recs.append((0.5, np.zeros_like(recs[19 + (len(recs) - 19) % 4][1])))
+    mk, _ = split_masks(recs, T)
+    out.update({"rl_mask." + k: v for k, v in mk.items()})
+    reward = torch.from_numpy(rng.randn(B, 1).astype(np.float32)).repeat(1, T)
+    rl_loss = RewardCriterion()(slp, seq, reward)
+    rl_loss.backward()
+    out.update(rl_u=rl_u, rl_seq=seq.numpy(), rl_logprobs=slp.detach().numpy(), rl_steps_run=np.int64(steps_run),
+               rl_reward=reward.numpy(), rl_loss=np.float32(rl_loss.item()))
+    for n_, p_ in dec.named_parameters():
+        out["rl_grad." + n_] = p_.grad.detach().numpy().copy()
+    with torch.no_grad():
+        dec.predict.bias.copy_(base_bias)
+    save(tag, **out)
+
+
+# ------------------------------------------------------------------------------------------------
 def gen_cider(tag, seed):
     """G-cider: CiderD.compute_score (ciderD.py:30-55) on hand-made edge cases + abstract48S sample."""
     from cider.pyciderevalcap.ciderD.ciderD import CiderD
@@ -692,13 +846,15 @@ def gen_engine(tag, seed, B=6, V=53, H=16, E=16, A=16):
 if __name__ == "__main__":
     bootstrap()
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["butd", "nic", "cider", "engine"]
+    which = sys.argv[1:] or ["butd", "nic", "aoa", "cider", "engine"]
     if "butd" in which:
         gen_butd_decoder("butd_dec_tiny", B=5, R=36, D=64, H=32, E=32, A=32, V=53, seed=11)
         gen_butd_decoder("butd_dec_odd", B=3, R=36, D=96, H=48, E=16, A=64, V=70, seed=12)
     if "nic" in which:
         gen_nic_decoder("nic_dec_tiny", B=5, H=32, E=32, V=53, seed=31)
         gen_nic_decoder("nic_dec_odd", B=3, H=48, E=16, V=70, seed=32)
+    if "aoa" in which:
+        gen_aoa("aoa_tiny", B=4, Hd=32, E=16, V=53, seed=41)
     if "cider" in which:
         gen_cider("ciderd_cases", seed=5)
     if "engine" in which:

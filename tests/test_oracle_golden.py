@@ -279,3 +279,78 @@ def test_nic_xe_and_rl_grads(nic):
     for k, v in p.items():
         np.testing.assert_allclose(v.grad.numpy(), g["rl_grad." + k], atol=2e-6, rtol=1e-4, err_msg=k)
     np.testing.assert_allclose(f.grad.numpy(), g["rl_dfeats"], atol=2e-6, rtol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+def aoa_masks(g, prefix):
+    w = dict(zip(("proj", "ref_att", "ref_aoa", "ref_sc", "emb", "ctx", "att", "out"), [int(x) for x in g["mask_widths"]]))
+    return {k: np.unpackbits(g[prefix + k], axis=-1)[..., :w[k]] for k in w}
+
+
+@pytest.fixture(scope="module")
+def aoa(golden_dir):
+    from oracle import aoa as oa
+    g = load(golden_dir, "aoa_tiny")
+    B, R, D, Hd, E, V, NH = [int(x) for x in g["dims"]]
+    feats = torch.from_numpy(feats_from_seed(int(g["feats_seed"]), B, R, D))
+    return oa, g, feats
+
+
+def aoa_params(g, requires_grad=False):
+    p = {}
+    for k, v in g.items():
+        if k.startswith("sd."):
+            t = torch.tensor(v)
+            t.requires_grad_(requires_grad and k.startswith("sd.decoder."))
+            p[k[3:]] = t
+    return p
+
+
+def test_aoa_refiner_greedy_beam(aoa):
+    oa, g, feats = aoa
+    p = aoa_params(g)
+    np.testing.assert_allclose(oa.refine(feats, p).numpy(), g["refined_eval"], atol=2e-5, rtol=1e-5)
+    ids, logits = oa.greedy(feats, p, 20)
+    assert np.array_equal(ids.numpy(), g["greedy_ids"])
+    np.testing.assert_allclose(logits.numpy(), g["greedy_logits"], atol=1e-4)
+    for regime, k, img in BEAM_CASES:
+        q = {kk: v.clone() for kk, v in p.items()}
+        if regime == "early":
+            q["decoder.predict.bias"][2] = 4.0
+        elif regime == "never":
+            q["decoder.predict.bias"][2] = -1e4
+        elif regime == "track":
+            tok = int(g["beam_track_tok"])
+            q["decoder.predict.weight_v"][2] = q["decoder.predict.weight_v"][tok]
+            q["decoder.predict.weight_g"][2] = q["decoder.predict.weight_g"][tok]
+            q["decoder.predict.bias"][2] = q["decoder.predict.bias"][tok] - 0.2
+        want = g["beam_%s_k%d_i%d" % (regime, k, img)]
+        got = oa.beam_search(feats[img:img + 1], q, k).numpy()
+        assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img)
+
+
+def test_aoa_xe_and_rl_decoder_grads(aoa):
+    oa, g, feats = aoa
+    p = aoa_params(g, True)
+    lengths = g["xe_lengths"].tolist()
+    logits = oa.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p, aoa_masks(g, "xe_mask."))
+    np.testing.assert_allclose(logits.detach().numpy(), g["xe_packed_logits"], atol=1e-4)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["xe_loss"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        if k.startswith("decoder."):
+            np.testing.assert_allclose(v.grad.numpy(), g["xe_grad." + k[8:]], atol=2e-5, rtol=1e-4, err_msg=k)
+    p = aoa_params(g, True)
+    with torch.no_grad():
+        p["decoder.predict.bias"][2] = float(g["rl_end_bias"])
+    seq, lp = oa.sample_rl(feats, p, g["rl_u"], aoa_masks(g, "rl_mask."), 20)
+    assert np.array_equal(seq.numpy(), g["rl_seq"])
+    np.testing.assert_allclose(lp.detach().numpy(), g["rl_logprobs"], atol=1e-5)
+    loss = ob.reward_criterion(lp, seq, torch.from_numpy(g["rl_reward"]))
+    assert abs(loss.item() - float(g["rl_loss"])) < 1e-5
+    loss.backward()
+    for k, v in p.items():
+        if k.startswith("decoder."):
+            np.testing.assert_allclose(v.grad.numpy(), g["rl_grad." + k[8:]], atol=2e-6, rtol=1e-4, err_msg=k)
