@@ -173,6 +173,55 @@ int icz_nic_beam_search(icz_nic_t* h, const float* features, int32_t n_img, int3
                         int32_t* lens_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
+ * AoADetection captioner (Models/AoA_Model.py:657-753): img_feats_porjection (Linear 2048->Hd + ReLU + Dropout) ->
+ * AoA_Refine_Core (6 x {LayerNorm -> 8-head self-attention over the R regions -> GLU gate -> residual}, final LayerNorm;
+ * :122-162) once per image, then AoA_Decoder (:197-502) per step: embed -> LSTMCell([emb, mean + drop(ctx)]) -> LayerNorm
+ * -> 8-head attention over the refined regions + GLU -> predict.  Fixed-region path (bu_masks = None).
+ * Only decoder.* parameters receive gradients: they are the only ones in the reference's optimizer (:669-674).
+ * ---------------------------------------------------------------------------------------------------------- */
+typedef struct icz_aoa icz_aoa_t;
+typedef struct { int32_t R, D, Hd, E, V, NH, max_rows, max_len; } icz_aoa_dims;
+typedef struct {   /* one AoABlock + its LayerNorm: linear_Q/K/V [Hd,Hd]+[Hd], aoa_module.0 [2Hd,2Hd]+[2Hd], norm gain/bias [Hd] */
+    float *q_w, *q_b, *k_w, *k_b, *v_w, *v_b, *aoa_w, *aoa_b, *ln_g, *ln_b;
+} icz_aoa_block;
+typedef struct {
+    float *proj_w, *proj_b;                        /* img_feats_porjection.0.{weight [Hd,D], bias [Hd]}              */
+    icz_aoa_block layer[6];                        /* aoa_refine.aoa_layers.<l>.{aoa_block.*, sublayer.norm.*}        */
+    float *ref_ln_g, *ref_ln_b;                    /* aoa_refine.norm.{gain, bias}                                    */
+    float *lstm_w_ih, *lstm_w_hh, *lstm_b_ih, *lstm_b_hh;   /* decoder.lstm.*  [4Hd, E+Hd] [4Hd, Hd] [4Hd] [4Hd]      */
+    icz_aoa_block dec;                             /* decoder.aoa_block.* and decoder.h_norm.{gain,bias} (ln_g, ln_b) */
+    float* embed_weight;                           /* decoder.embed.0.weight [V, E]                                   */
+    float *predict_v, *predict_g, *predict_b;      /* decoder.predict.*                                               */
+} icz_aoa_params;
+/* Randomness of the training-mode paths (explicit arrays for parity tests, Philox from `seed` for NULL pointers).
+ * Keep-masks (1 = keep) with the reference's drop probabilities: proj 0.5 [B,R,Hd]; per refiner layer: ref_att 0.1
+ * [6,B,NH,R,R], ref_aoa 0.3 [6,B,R,2Hd], ref_sc 0.1 [6,B,R,Hd]; per step: emb 0.5 [T,B,E], ctx 0.5 [T,B,Hd], att 0.1
+ * [T,B,NH,R], out 0.5 [T,B,Hd]; uniforms [T,B]. */
+typedef struct {
+    uint64_t seed;
+    const float* uniforms;
+    const uint8_t *proj_mask, *ref_att_mask, *ref_aoa_mask, *ref_sc_mask, *emb_mask, *ctx_mask, *att_mask, *out_mask;
+} icz_aoa_rng;
+int icz_aoa_create(const icz_aoa_dims* dims, icz_aoa_t** out);
+int icz_aoa_destroy(icz_aoa_t* h);
+int icz_aoa_bind_params(icz_aoa_t* h, const icz_aoa_params* params);
+int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream);
+/* eval-mode refined features [B,R,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests */
+int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_out, void* stream);
+/* AoADetection_Captioner.sampler / beam_search_sampler / sampler_rl / forward (:698-753, :676-696) */
+int icz_aoa_greedy(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out, void* stream);
+int icz_aoa_beam_search(icz_aoa_t* h, const float* feats, int32_t n_img, int32_t beam, int32_t max_steps, float* seqs_out,
+                        int32_t* lens_out, void* stream);
+int icz_aoa_sample(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, const icz_aoa_rng* rng, int64_t* seq_out,
+                   float* logprobs_out, void* stream);
+int icz_aoa_sample_backward(icz_aoa_t* h, const float* reward, const icz_aoa_params* grads, float* loss_out, float* mask_sum_out,
+                            float mask_sum_global, void* stream);
+int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,
+                       const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream);
+int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global,
+                        void* stream);
+
+/* ------------------------------------------------------------------------------------------------------------
  * Optimiser step: clip_gradient (Utils.py:241-250, value clamp) + torch.optim.Adam(betas=(0.9,0.999),
  * eps=1e-8, weight_decay=0) (Utils.py:219-220) fused, one call per parameter tensor.
  * ---------------------------------------------------------------------------------------------------------- */

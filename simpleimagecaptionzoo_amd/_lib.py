@@ -50,6 +50,35 @@ NIC_PARAM_KEYS = ("embed.weight", "lstm.weight_ih", "lstm.weight_hh", "lstm.bias
                   "predict.weight_v", "predict.weight_g", "predict.bias")
 
 
+class AoaDims(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("R", "D", "Hd", "E", "V", "NH", "max_rows", "max_len")]
+
+
+def _aoa_block_keys(block, norm):
+    return tuple(block + n for n in ("linear_Q.weight", "linear_Q.bias", "linear_K.weight", "linear_K.bias", "linear_V.weight",
+                                     "linear_V.bias", "aoa_module.0.weight", "aoa_module.0.bias")) + (norm + "gain", norm + "bias")
+
+
+# reference state_dict keys of AoADetection_Captioner (Models/AoA_Model.py:657-667) in the pointer order of icz_aoa_params
+AOA_PARAM_KEYS = (("img_feats_porjection.0.weight", "img_feats_porjection.0.bias")
+                  + sum((_aoa_block_keys("aoa_refine.aoa_layers.%d.aoa_block." % l, "aoa_refine.aoa_layers.%d.sublayer.norm." % l)
+                         for l in range(6)), ())
+                  + ("aoa_refine.norm.gain", "aoa_refine.norm.bias",
+                     "decoder.lstm.weight_ih", "decoder.lstm.weight_hh", "decoder.lstm.bias_ih", "decoder.lstm.bias_hh")
+                  + _aoa_block_keys("decoder.aoa_block.", "decoder.h_norm.")
+                  + ("decoder.embed.0.weight", "decoder.predict.weight_v", "decoder.predict.weight_g", "decoder.predict.bias"))
+AOA_DECODER_KEYS = tuple(k for k in AOA_PARAM_KEYS if k.startswith("decoder."))
+
+
+class AoaParams(C.Structure):      # icz_aoa_params is 82 pointers with no padding: addressed here as a flat table
+    _fields_ = [("p%d" % i, C.c_void_p) for i in range(len(AOA_PARAM_KEYS))]
+
+
+class AoaRng(C.Structure):
+    _fields_ = [("seed", C.c_uint64), ("uniforms", C.c_void_p)] + [(n, C.c_void_p) for n in (
+        "proj_mask", "ref_att_mask", "ref_aoa_mask", "ref_sc_mask", "emb_mask", "ctx_mask", "att_mask", "out_mask")]
+
+
 class NicParams(C.Structure):
     _fields_ = [(n, C.c_void_p) for n in NIC_PARAM_FIELDS]
 
@@ -106,6 +135,17 @@ def lib():
         "icz_nic_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_nic_xe_backward": (C.c_int, [vp, f32, C.POINTER(NicParams), vp, vp, f32, vp]),
         "icz_nic_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "icz_aoa_create": (C.c_int, [C.POINTER(AoaDims), C.POINTER(vp)]),
+        "icz_aoa_destroy": (C.c_int, [vp]),
+        "icz_aoa_bind_params": (C.c_int, [vp, C.POINTER(AoaParams)]),
+        "icz_aoa_refresh_weights": (C.c_int, [vp, vp]),
+        "icz_aoa_refine": (C.c_int, [vp, vp, i32, vp, vp]),
+        "icz_aoa_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp]),
+        "icz_aoa_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
+        "icz_aoa_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(AoaRng), vp, vp, vp]),
+        "icz_aoa_sample_backward": (C.c_int, [vp, vp, C.POINTER(AoaParams), vp, vp, f32, vp]),
+        "icz_aoa_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(AoaRng), i32, vp, vp]),
+        "icz_aoa_xe_backward": (C.c_int, [vp, f32, C.POINTER(AoaParams), vp, f32, vp]),
         "icz_ciderd_create": (C.c_int, [vp, vp, i64, C.c_double, vp, C.POINTER(vp)]),
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -1,0 +1,316 @@
+// AoADetection captioner, inference paths: feature projection + AoA refiner, decoder step, greedy and beam decoding
+// (Models/AoA_Model.py:122-162, 319-336, 403-502, 698-753).  Training paths live in aoa_train.hip.
+#include "aoa_impl.h"
+
+namespace icz {
+
+int Aoa::init(const icz_aoa_dims& d) {
+    dims = d;
+    ICZ_REQUIRE(d.NH > 0 && d.Hd % d.NH == 0, "aoa: hidden size %d not divisible by %d heads", d.Hd, d.NH);
+    ICZ_REQUIRE(d.E % 4 == 0 && d.Hd % 4 == 0 && d.D % 4 == 0 && d.V > 3 && d.max_rows > 0 && d.max_len > 0, "aoa: bad dimensions");
+    ICZ_REQUIRE(d.R >= 1 && d.R <= 64, "aoa: %d regions per image (supported: 1..64)", d.R);
+    const size_t dh = d.Hd / d.NH;
+    ICZ_REQUIRE((3 * d.R * (dh + 1) + d.R * (d.R + 1)) * sizeof(float) <= 64 * 1024, "aoa: head tile does not fit the LDS budget");
+    Vp = pad_vocab(d.V);
+    const size_t rows = d.max_rows, Hd = d.Hd, E = d.E, RR = rows * d.R;
+    ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * Vp * Hd));
+    ICZ_TRY(alloc((void**)&n_pred, sizeof(float) * d.V));
+    ICZ_TRY(alloc((void**)&w_rec, sizeof(float) * 4 * Hd * 2 * Hd));
+    ICZ_TRY(alloc((void**)&zeros, sizeof(float) * rows * Hd));
+    float** ref[] = {&xa, &xb, &ln, &q, &k, &v, &o, &od, &nd, &refined, &Kd, &Vd};
+    for (float** p : ref) ICZ_TRY(alloc((void**)p, sizeof(float) * RR * Hd));
+    ICZ_TRY(alloc((void**)&z, sizeof(float) * RR * 2 * Hd));
+    ICZ_TRY(alloc((void**)&meanf, sizeof(float) * rows * Hd));
+    for (int i = 0; i < 2; ++i) {
+        ICZ_TRY(alloc((void**)&h[i], sizeof(float) * rows * Hd));
+        ICZ_TRY(alloc((void**)&m[i], sizeof(float) * rows * Hd));
+        ICZ_TRY(alloc((void**)&ctx[i], sizeof(float) * rows * Hd));
+    }
+    ICZ_TRY(alloc((void**)&emb, sizeof(float) * rows * E));
+    float** st[] = {&u, &qn, &Qp, &xatt, &ctxdrop};
+    for (float** p : st) ICZ_TRY(alloc((void**)p, sizeof(float) * rows * Hd));
+    ICZ_TRY(alloc((void**)&logits, sizeof(float) * rows * Vp));
+    ICZ_TRY(alloc((void**)&it, sizeof(int64_t) * rows));
+    ICZ_TRY(alloc((void**)&amax_val, sizeof(float) * rows * ARGMAX_PARTS));
+    ICZ_TRY(alloc((void**)&amax_idx, sizeof(int) * rows * ARGMAX_PARTS));
+    ICZ_TRY(alloc((void**)&d_seed, 16));
+    ICZ_TRY(alloc((void**)&d_msum, 16));
+    const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
+    ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
+    return ICZ_OK;
+}
+
+__global__ __launch_bounds__(256) void aoa_pack_rec_kernel(const float* __restrict__ w_ih, const float* __restrict__ w_hh, float* __restrict__ w_rec,
+                                                           int Hd, int E) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)4 * Hd * 2 * Hd) return;
+    const size_t row = i / (2 * Hd);
+    const int c = (int)(i % (2 * Hd));
+    w_rec[i] = c < Hd ? w_ih[row * (E + Hd) + E + c] : w_hh[row * Hd + (c - Hd)];
+}
+
+int Aoa::refresh(hipStream_t st) {
+    ICZ_REQUIRE(bound, "aoa: parameters not bound");
+    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(dims.V, 4)), dim3(256), 0, st, P.predict_v, P.predict_g, w_pred, n_pred, dims.V, dims.Hd);
+    const size_t n = (size_t)4 * dims.Hd * 2 * dims.Hd;
+    hipLaunchKernelGGL(aoa_pack_rec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.lstm_w_ih, P.lstm_w_hh, w_rec, dims.Hd, dims.E);
+    ICZ_CHECK_HIP(hipGetLastError());
+    fresh = true;
+    return ICZ_OK;
+}
+
+// C = sum_s A_s W_s^T + bias, dense [M,N]; split-K slabs through `ws` when one pass would leave most CUs idle
+static int aoa_linear(Aoa& a, GemmArgs& g, const float* bias, float* out, hipStream_t st) {
+    g.out = out; g.ldo = g.N;
+    g.nsplit = gemm_pick_split(g, Aoa::STEP_WGS);
+    if (g.nsplit == 1) {
+        g.bias = bias;
+        return gemm_f32(GEMM_NT, g, st);
+    }
+    ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= a.ws_floats, "aoa: workspace too small");
+    g.out = a.ws;
+    ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+    const size_t MN = (size_t)g.M * g.N;
+    hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, a.ws, g.nsplit, MN, g.N, bias, out);
+    return ICZ_OK;
+}
+
+int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, int N, float* out, hipStream_t st) {
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {A, W, K, K, K, nullptr};
+    g.M = M; g.N = N;
+    return aoa_linear(*this, g, bias, out, st);
+}
+
+// img_feats_porjection + AoA_Refine_Core (AoA_Model.py:661-665, 140-162) -> refined [n_img,R,Hd], its region mean, and the
+// decoder block's linear_K / linear_V of it (time-invariant, hoisted out of the decoding loop)
+int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
+    const int R = dims.R, Hd = dims.Hd, NH = dims.NH, dh = Hd / NH;
+    const int rows = n_img * R;
+    const size_t nel = (size_t)rows * Hd;
+    const unsigned eb = (unsigned)((nel + 255) / 256);
+    ICZ_TRY(lin(feats, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f));
+    const size_t lds = sizeof(float) * (3 * R * (dh + 1) + R * (R + 1));
+    float *cur = xa, *nxt = xb;
+    for (int l = 0; l < NL; ++l) {
+        const icz_aoa_block& b = P.layer[l];
+        hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, b.ln_g, b.ln_b, ln, rows, Hd, (float*)nullptr);
+        ICZ_TRY(lin(ln, rows, Hd, b.q_w, b.q_b, Hd, q, st));
+        ICZ_TRY(lin(ln, rows, Hd, b.k_w, b.k_b, Hd, k, st));
+        ICZ_TRY(lin(ln, rows, Hd, b.v_w, b.v_b, Hd, v, st));
+        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH,
+                           dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f));
+        const float *xo = o, *xn = ln;
+        if (train) {
+            hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, o, ln, od, nd, (size_t)rows, Hd,
+                               dropp(true, rng.ref_aoa_mask, (size_t)l * rows * 2 * Hd, AOA_RNG_REF_AOA, l, 0.3f));
+            xo = od; xn = nd;
+        }
+        GemmArgs g = {};
+        g.nseg = 2;
+        g.seg[0] = {xo, b.aoa_w, Hd, 2 * Hd, Hd, nullptr};
+        g.seg[1] = {xn, b.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
+        g.M = rows; g.N = 2 * Hd;
+        ICZ_TRY(aoa_linear(*this, g, b.aoa_b, z, st));
+        hipLaunchKernelGGL(glu_residual_kernel, dim3(eb), dim3(256), 0, st, z, cur, nxt, (size_t)rows, Hd,
+                           dropp(train, rng.ref_sc_mask, (size_t)l * rows * Hd, AOA_RNG_REF_SC, l, 0.1f));
+        float* t_ = cur; cur = nxt; nxt = t_;
+    }
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, P.ref_ln_g, P.ref_ln_b, refined, rows, Hd, (float*)nullptr);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, R, Hd);
+    ICZ_TRY(lin(refined, rows, Hd, P.dec.k_w, P.dec.k_b, Hd, Kd, st));
+    ICZ_TRY(lin(refined, rows, Hd, P.dec.v_w, P.dec.v_b, Hd, Vd, st));
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// One decoder step (AoA_Model.py:319-336)
+int Aoa::step(const AoaStepIO& s, hipStream_t st) {
+    const int rows = s.rows, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = dims.R, dh = Hd / NH;
+    const unsigned eb = (unsigned)(((size_t)rows * Hd + 255) / 256);
+    if (!s.emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb, rows, E, s.d_emb, 1);
+    hipLaunchKernelGGL(aoa_u_kernel, dim3(eb), dim3(256), 0, st, meanf, s.img_of_row, s.ctx_in, s.u, rows, Hd, s.d_ctx);
+    GemmArgs g = {};
+    g.nseg = 3;
+    g.seg[0] = {s.emb, P.lstm_w_ih, E, E + Hd, E, nullptr};
+    g.seg[1] = {s.u, P.lstm_w_ih + E, Hd, E + Hd, Hd, nullptr};
+    g.seg[2] = {s.h_in, P.lstm_w_hh, Hd, Hd, Hd, nullptr};
+    g.M = rows; g.N = 4 * Hd; g.out = ws; g.ldo = 4 * Hd;
+    g.nsplit = gemm_pick_split(g, STEP_WGS);
+    ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "aoa: workspace too small");
+    ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+    LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd};
+    DropCfg off = {0, nullptr, nullptr, 0, 0};
+    hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(Hd, 256), rows), dim3(256), 0, st, a, off);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
+    ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
+    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 64);
+    hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(64), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
+                       s.d_att);
+    GemmArgs zg = {};
+    zg.nseg = 2;
+    zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};
+    zg.seg[1] = {s.qn, P.dec.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
+    zg.M = rows; zg.N = 2 * Hd; zg.out = ws; zg.ldo = 2 * Hd;
+    zg.nsplit = gemm_pick_split(zg, STEP_WGS);
+    ICZ_REQUIRE(gemm_slab_floats(zg.M, zg.N, zg.nsplit) <= ws_floats, "aoa: workspace too small");
+    ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
+    hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out);
+    GemmArgs p = {};
+    p.nseg = 1;
+    p.seg[0] = {s.ctxdrop, w_pred, Hd, Hd, Hd, nullptr};
+    p.M = rows; p.N = dims.V; p.out = s.logits; p.ldo = Vp; p.bias = P.predict_b; p.nsplit = 1;
+    ICZ_TRY(gemm_f32(GEMM_NT, p, st));
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+static AoaStepIO scratch_io(Aoa& a, int rows, const int32_t* img_of_row, int cur) {
+    AoaStepIO s = {};
+    s.rows = rows; s.img_of_row = img_of_row; s.it = a.it;
+    s.h_in = a.h[cur]; s.m_in = a.m[cur]; s.ctx_in = a.ctx[cur];
+    s.h_out = a.h[cur ^ 1]; s.m_out = a.m[cur ^ 1]; s.ctx_out = a.ctx[cur ^ 1];
+    s.emb = a.emb; s.u = a.u; s.qn = a.qn; s.Qp = a.Qp; s.xatt = a.xatt; s.ctxdrop = a.ctxdrop; s.logits = a.logits;
+    s.d_emb = a.dropbits(false, nullptr, 0, 0, 0);
+    s.d_ctx = s.d_att = s.d_out = a.dropp(false, nullptr, 0, 0, 0, 0.5f);
+    return s;
+}
+
+static int zero_state(Aoa& a, int rows, hipStream_t st) {
+    ZeroList zl = {};
+    zl.p[0] = a.h[0]; zl.p[1] = a.m[0]; zl.p[2] = a.ctx[0]; zl.count = 3;
+    const size_t n = (size_t)rows * a.dims.Hd;
+    hipLaunchKernelGGL(zero_bufs_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, zl, n);
+    return ICZ_OK;
+}
+
+// AoA_Decoder.sample (AoA_Model.py:289-345) behind AoADetection_Captioner.sampler (:698-714)
+int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && T > 0, "aoa greedy: bad arguments");
+    ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    ICZ_TRY(refine(feats, B, false, st));
+    ICZ_TRY(zero_state(*this, B, st));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);
+    int cur = 0;
+    for (int t = 0; t < T; ++t) {
+        AoaStepIO s = scratch_io(*this, B, nullptr, cur);
+        s.emb_ready = t > 0;
+        ICZ_TRY(step(s, st));
+        hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
+        hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
+                           P.embed_weight, dims.E, emb, it, ids_out, T, t, 1);
+        cur ^= 1;
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// AoA_Decoder.beam_search_sample (AoA_Model.py:403-502), batched over images; state (h, m, ctx) re-gathered by source beam
+int Aoa::beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && seqs_out && lens_out, "aoa beam: null argument");
+    ICZ_REQUIRE(kb >= 1 && kb <= BEAM_MAX_K, "aoa beam: beam size %d out of range 1..%d", kb, BEAM_MAX_K);
+    ICZ_REQUIRE(n_img > 0 && (long)n_img * kb <= dims.max_rows, "aoa beam: %d images x %d beams exceed row capacity %d", n_img, kb, dims.max_rows);
+    ICZ_REQUIRE(max_steps >= 1 && max_steps <= 256, "aoa beam: max_steps out of range");
+    ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    const int rows = n_img * kb, L = max_steps + 1, Hd = dims.Hd;
+    if (bm.cap_rows < rows || bm.cap_L < L) {
+        const size_t R_ = dims.max_rows, L_ = L > 51 ? L : 51;
+        ICZ_TRY(alloc((void**)&bm.n_act, sizeof(int) * R_));
+        ICZ_TRY(alloc((void**)&bm.run, sizeof(float) * R_));
+        ICZ_TRY(alloc((void**)&bm.seqs[0], sizeof(int32_t) * R_ * L_));
+        ICZ_TRY(alloc((void**)&bm.seqs[1], sizeof(int32_t) * R_ * L_));
+        ICZ_TRY(alloc((void**)&bm.src_row, sizeof(int32_t) * R_));
+        ICZ_TRY(alloc((void**)&bm.img_of_row, sizeof(int32_t) * R_));
+        ICZ_TRY(alloc((void**)&bm.best_score, sizeof(float) * R_));
+        ICZ_TRY(alloc((void**)&bm.best_len, sizeof(int) * R_));
+        ICZ_TRY(alloc((void**)&bm.has_complete, sizeof(int) * R_));
+        ICZ_TRY(alloc((void**)&bm.best_seq, sizeof(int32_t) * R_ * L_));
+        ICZ_TRY(alloc((void**)&bm.n_live, sizeof(int) * 260));
+        ICZ_CHECK_HIP(hipHostMalloc((void**)&bm.n_live_host, sizeof(int) * 4, 0));
+        bm.cap_rows = (int)R_;
+        bm.cap_L = (int)L_;
+    }
+    ICZ_TRY(refine(feats, n_img, false, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(bm.n_live, 0, sizeof(int) * 260, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(bm.run, 0, sizeof(float) * rows, st));
+    hipLaunchKernelGGL(beam_init_kernel, dim3(cdiv(rows, 256)), dim3(256), 0, st, n_img, kb, L, bm.n_act, bm.seqs[0], bm.img_of_row, it,
+                       bm.has_complete, bm.best_score);
+    ICZ_TRY(zero_state(*this, rows, st));
+    int sb = 0, steps_done = 0;
+    for (int stp = 1; stp <= max_steps; ++stp) {
+        AoaStepIO s = scratch_io(*this, rows, bm.img_of_row, 0);
+        s.emb_ready = false;
+        ICZ_TRY(step(s, st));
+        BeamArgs a = {logits, dims.V, Vp, kb, stp, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
+                      bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + stp};
+        hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(Hd, 1024), rows), dim3(256), 0, st, bm.src_row, Hd, h[1], m[1], ctx[1], h[1],
+                           h[0], m[0], ctx[0], u);
+        sb ^= 1;
+        steps_done = stp;
+        if (stp >= 6 && (stp % 3) == 0 && stp < max_steps) {
+            ICZ_CHECK_HIP(hipMemcpyAsync(bm.n_live_host, bm.n_live + stp, sizeof(int), hipMemcpyDeviceToHost, st));
+            ICZ_CHECK_HIP(hipStreamSynchronize(st));
+            if (bm.n_live_host[0] == 0) break;
+        }
+    }
+    hipLaunchKernelGGL(beam_finalize_kernel, dim3(n_img), dim3(64), 0, st, kb, L, steps_done, bm.n_act, bm.run, bm.seqs[sb], bm.has_complete,
+                       bm.best_len, bm.best_seq, seqs_out, lens_out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // namespace icz
+
+// ================================================================================================
+using namespace icz;
+extern "C" {
+
+int icz_aoa_create(const icz_aoa_dims* dims, icz_aoa_t** out) {
+    ICZ_REQUIRE(dims && out, "icz_aoa_create: null argument");
+    Aoa* n = new Aoa();
+    int s = n->init(*dims);
+    if (s != ICZ_OK) { delete n; return s; }
+    *out = reinterpret_cast<icz_aoa_t*>(n);
+    return ICZ_OK;
+}
+int icz_aoa_destroy(icz_aoa_t* h) { delete reinterpret_cast<Aoa*>(h); return ICZ_OK; }
+int icz_aoa_bind_params(icz_aoa_t* h, const icz_aoa_params* p) {
+    ICZ_REQUIRE(h && p, "icz_aoa_bind_params: null argument");
+    const float* const* q = reinterpret_cast<const float* const*>(p);
+    for (size_t i = 0; i < sizeof(icz_aoa_params) / sizeof(float*); ++i) {
+        ICZ_REQUIRE(q[i] != nullptr, "icz_aoa_bind_params: parameter pointer %zu is null", i);
+        ICZ_REQUIRE(((uintptr_t)q[i] & 15) == 0, "icz_aoa_bind_params: parameter %zu not 16-byte aligned", i);
+    }
+    Aoa* n = reinterpret_cast<Aoa*>(h);
+    n->P = *p; n->bound = true; n->fresh = false;
+    return ICZ_OK;
+}
+int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->refresh((hipStream_t)stream);
+}
+int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_out, void* stream) {
+    ICZ_REQUIRE(h && feats && refined_out, "icz_aoa_refine: null argument");
+    Aoa* n = reinterpret_cast<Aoa*>(h);
+    ICZ_REQUIRE(B > 0 && B <= n->dims.max_rows, "icz_aoa_refine: B out of range");
+    ICZ_REQUIRE(n->fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    ICZ_TRY(n->refine(feats, B, false, (hipStream_t)stream));
+    ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, sizeof(float) * (size_t)B * n->dims.R * n->dims.Hd, hipMemcpyDeviceToDevice,
+                                 (hipStream_t)stream));
+    return ICZ_OK;
+}
+int icz_aoa_greedy(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->greedy(feats, B, max_len, ids_out, (hipStream_t)stream);
+}
+int icz_aoa_beam_search(icz_aoa_t* h, const float* feats, int32_t n_img, int32_t beam, int32_t max_steps, float* seqs_out,
+                        int32_t* lens_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->beam_search(feats, n_img, beam, max_steps, seqs_out, lens_out, (hipStream_t)stream);
+}
+
+}  // extern "C"

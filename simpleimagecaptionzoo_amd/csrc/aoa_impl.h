@@ -1,0 +1,111 @@
+// AoADetection captioner (Models/AoA_Model.py:657-753): feature projection + 6-layer AoA refiner (once per image) and
+// the AoA decoder (LSTM + LayerNorm + 8-head attention over the 36 refined regions + GLU gate) -- greedy / sampled /
+// beam decoding and teacher-forced XE, with BPTT for the decoder parameters (the only ones the reference optimises,
+// AoA_Model.py:669-674).  linear_K / linear_V of the decoder block are hoisted out of the time loop (the reference
+// recomputes them every step, :114-115).
+#pragma once
+#include <math.h>
+
+#include <vector>
+
+#include "aoa_kernels.h"
+#include "beam_kernels.h"
+#include "butd_impl.h"
+
+namespace icz {
+
+enum AoaRngStream : uint32_t { AOA_RNG_PROJ = 10, AOA_RNG_REF_ATT = 11, AOA_RNG_REF_AOA = 12, AOA_RNG_REF_SC = 13,
+                               AOA_RNG_CTX = 20, AOA_RNG_ATT = 21, AOA_RNG_OUT = 22 };
+
+struct AoaStepIO {
+    int rows;
+    const int32_t* img_of_row;      // null = identity (row b decodes image b)
+    const int64_t* it;
+    bool emb_ready;
+    const float *h_in, *m_in, *ctx_in;
+    float *h_out, *m_out, *ctx_out;
+    // per-step tensors; training passes slots of the saved [T,B,...] buffers, inference the scratch ones
+    float *emb, *u, *gates_out, *ln_stats, *qn, *Qp, *P_out, *Pd_out, *xatt, *z_out, *ctxdrop, *logits;
+    DropCfg d_emb;                   // embedding dropout (p = 0.5) through the BUTD embedding kernel
+    DropP d_ctx, d_att, d_out;
+};
+
+struct Aoa {
+    static constexpr int STEP_WGS = 256, TARGET_WGS = 512, ARGMAX_PARTS = 8, COLSUM_PARTS = 64, NL = 6;
+    icz_aoa_dims dims;
+    icz_aoa_params P;
+    bool bound = false, fresh = false;
+    std::vector<void*> allocs;
+    int Vp = 0;
+    float *w_pred = nullptr, *n_pred = nullptr, *zeros = nullptr;
+    float* w_rec = nullptr;          // [4Hd, 2Hd] = [W_ih[:, E:] | W_hh]: one dgrad GEMM per BPTT step for (du, dh_prev)
+    // refiner scratch / per-image tensors (rows = max_rows * R)
+    float *xa = nullptr, *xb = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
+          *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;
+    // decoder state + scratch
+    float *h[2], *m[2], *ctx[2];
+    float *emb = nullptr, *u = nullptr, *qn = nullptr, *Qp = nullptr, *xatt = nullptr, *ctxdrop = nullptr, *logits = nullptr, *ws = nullptr;
+    size_t ws_floats = 0;
+    int64_t* it = nullptr;
+    float* amax_val = nullptr; int* amax_idx = nullptr;
+    uint64_t* d_seed = nullptr; float* d_msum = nullptr;
+    BeamBuf bm;
+    // training buffers (aoa_train.hip), slot stride = max_rows: th/tm/tctx slot 0 = zeros, slot t+1 = after step t
+    bool tready = false;
+    int64_t* tok = nullptr;
+    float *th = nullptr, *tm = nullptr, *tctx = nullptr, *temb = nullptr, *tu = nullptr, *tg = nullptr, *tstats = nullptr, *tqn = nullptr,
+          *tQp = nullptr, *tP = nullptr, *tPd = nullptr, *txatt = nullptr, *tz = nullptr, *tcd = nullptr, *tlogit = nullptr;
+    float *dCd = nullptr, *dZ = nullptr, *dQp = nullptr, *dQn = nullptr, *dHln = nullptr, *dG = nullptr, *dEmb = nullptr, *dKd = nullptr,
+          *dVd = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *X2 = nullptr, *dWp = nullptr, *prod = nullptr;
+    float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr, *colsum_part = nullptr;
+    int32_t* draw = nullptr; uint8_t* unf = nullptr; int* nunf = nullptr; int* pack_idx = nullptr;
+    size_t xfloats = 0;
+    icz_aoa_rng rng = {};
+    int mode = 0, cur_B = 0, cur_T = 0, cur_L = 0, n_tokens = 0;
+    bool cur_train = false;
+    const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr;
+    const int64_t* cur_captions = nullptr;
+    std::vector<int> rows_t;
+
+    ~Aoa() { for (void* p : allocs) (void)hipFree(p); }
+    int alloc(void** p, size_t bytes) {
+        ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
+        ICZ_CHECK_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
+        allocs.push_back(*p);
+        return ICZ_OK;
+    }
+    int init(const icz_aoa_dims& d);
+    int refresh(hipStream_t st);
+    // out[M,N] = A[M,K] W[N,K]^T + bias  (split-K through `ws` when the launch would be too small)
+    int lin(const float* A, int M, int K, const float* W, const float* bias, int N, float* out, hipStream_t st);
+    int refine(const float* feats, int n_img, bool train, hipStream_t st);
+    int step(const AoaStepIO& s, hipStream_t st);
+    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
+    int beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
+    DropP dropp(bool train, const uint8_t* mask, size_t off, uint32_t stream, int step, float p) const {
+        DropP d = {0, nullptr, d_seed, stream, (uint32_t)step, (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p)};
+        if (!train) return d;
+        if (mask) { d.mode = 1; d.mask = mask + off; } else d.mode = 2;
+        return d;
+    }
+    DropCfg dropbits(bool train, const uint8_t* mask, size_t off, uint32_t stream, int step) const {
+        DropCfg d = {0, nullptr, d_seed, stream, (uint32_t)step};
+        if (!train) return d;
+        if (mask) { d.mode = 1; d.mask = mask + off; } else d.mode = 2;
+        return d;
+    }
+    // training paths (aoa_train.hip)
+    int ensure_train();
+    AoaStepIO train_io(int rows, int t, bool train);
+    int sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st);
+    int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_aoa_rng* r, int train,
+                   float* packed_out, hipStream_t st);
+    int xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
+    int bptt(const icz_aoa_params& G, hipStream_t st);
+    int colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st);
+    int nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* slab_out, size_t cap, int* ns, int target, hipStream_t st);
+    int tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st);
+};
+
+}  // namespace icz

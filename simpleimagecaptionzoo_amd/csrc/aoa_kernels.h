@@ -1,0 +1,218 @@
+// Kernels specific to the AoA model family (Models/AoA_Model.py): custom LayerNorm, multi-head dot-product attention
+// (36 x 36 self-attention in the refiner, 1 x 36 in the decoder), GLU gate, general-p dropout.
+#pragma once
+#include "butd_kernels.h"
+
+namespace icz {
+namespace {
+
+// Dropout with an arbitrary drop probability p (AoA uses 0.1 / 0.3 / 0.5): explicit keep-mask or Philox word >= p*2^32.
+struct DropP {
+    int mode;                 // 0 off, 1 explicit, 2 Philox
+    const uint8_t* mask;
+    const uint64_t* seed_p;
+    uint32_t stream, step;
+    uint32_t thresh;          // floor(p * 2^32)
+    float scale;              // 1 / (1 - p)
+    __device__ __forceinline__ float apply(float x, uint64_t idx) const {
+        if (mode == 0) return x;
+        bool keep;
+        if (mode == 1) keep = mask[idx] != 0;
+        else {
+            const uint64_t g = idx >> 2;
+            uint4_ c = {(uint32_t)g, (uint32_t)(g >> 32), step, stream};
+            const uint64_t seed = *seed_p;
+            uint4_ r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+            const uint32_t w = (idx & 3) == 0 ? r.x : ((idx & 3) == 1 ? r.y : ((idx & 3) == 2 ? r.z : r.w));
+            keep = w >= thresh;
+        }
+        return keep ? x * scale : 0.f;
+    }
+};
+
+// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665)
+__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    x[i] = dp.apply(fmaxf(x[i], 0.f), i);
+}
+
+// Custom LayerNorm (AoA_Model.py:14-25): y = gain * (x - mean) / (std_unbiased + eps) + bias.  One wave per row.
+// Optionally stores (mean, 1/(std+eps)) per row for the backward pass.
+__global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gain,
+                                                         const float* __restrict__ bias, float* __restrict__ y, int rows, int n,
+                                                         float* __restrict__ stats) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float* xr = x + (size_t)row * n;
+    float s = 0.f;
+    for (int c = lane; c < n; c += 64) s += xr[c];
+    const float mean = wave_sum(s) / (float)n;
+    float v = 0.f;
+    for (int c = lane; c < n; c += 64) { const float d = xr[c] - mean; v += d * d; }
+    const float stdv = sqrtf(wave_sum(v) / (float)(n - 1));
+    const float inv = 1.0f / (stdv + 1e-6f);
+    float* yr = y + (size_t)row * n;
+    for (int c = lane; c < n; c += 64) yr[c] = gain[c] * (xr[c] - mean) * inv + bias[c];
+    if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = inv; }
+}
+
+// Refiner self-attention (AoA_Model.py:41-69,113-117), one workgroup per (image, head):
+//   S = Q_h K_h^T / sqrt(d);  P = softmax_rows(S);  P = drop(P, 0.1);  O_h = P V_h
+// Q, K, V: [n_img, R, Hd] with head h in columns [h*d, (h+1)*d).  R <= 64.
+__global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                       float* __restrict__ O, int R, int Hd, int NH, DropP dp) {
+    extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // Q,K,V tiles [R][d+1], P [R][R+1]
+    const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
+    const int d = Hd / NH, ld = d + 1, lp = R + 1;
+    float* sq = sm_mha;
+    float* sk = sq + R * ld;
+    float* sv = sk + R * ld;
+    float* sp = sv + R * ld;
+    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    for (int i = tid; i < R * d; i += 256) {
+        const int r = i / d, j = i % d;
+        const size_t g = base + (size_t)r * Hd + j;
+        sq[r * ld + j] = Q[g]; sk[r * ld + j] = K[g]; sv[r * ld + j] = V[g];
+    }
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)d);
+    for (int i = tid; i < R * R; i += 256) {
+        const int q = i / R, r = i % R;
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) acc += sq[q * ld + j] * sk[r * ld + j];
+        sp[q * lp + r] = acc * scale;
+    }
+    __syncthreads();
+    // softmax per query row: one wave per row (R <= 64)
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int q = wave; q < R; q += 4) {
+        const float v = lane < R ? sp[q * lp + lane] : -INFINITY;
+        const float mx = wave_max(v);
+        const float ex = lane < R ? expf(v - mx) : 0.f;
+        const float sum = wave_sum(ex);
+        if (lane < R) {
+            const uint64_t idx = (((uint64_t)img * NH + hd) * R + q) * R + lane;
+            sp[q * lp + lane] = dp.apply(ex / sum, idx);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < R * d; i += 256) {
+        const int q = i / d, j = i % d;
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sp[q * lp + r] * sv[r * ld + j];
+        O[base + (size_t)q * Hd + j] = acc;
+    }
+}
+
+// dropout over the concatenation [a | b] (each [rows, Hd]) with one mask of width 2*Hd (dropout_aoa, AoA_Model.py:118)
+__global__ __launch_bounds__(256) void drop_concat_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ ad,
+                                                          float* __restrict__ bd, size_t rows, int Hd, DropP dp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Hd) return;
+    const size_t row = i / Hd;
+    const int c = (int)(i % Hd);
+    ad[i] = dp.apply(a[i], row * 2 * Hd + c);
+    bd[i] = dp.apply(b[i], row * 2 * Hd + Hd + c);
+}
+
+// GLU gate + sublayer residual (AoA_Model.py:83,39): x_out = x + drop(z[:, :Hd] * sigmoid(z[:, Hd:]), p)
+__global__ __launch_bounds__(256) void glu_residual_kernel(const float* __restrict__ z, const float* __restrict__ x, float* __restrict__ out,
+                                                           size_t rows, int Hd, DropP dp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * Hd) return;
+    const size_t row = i / Hd;
+    const int c = (int)(i % Hd);
+    const float y = z[row * 2 * Hd + c] * sigmoidf_(z[row * 2 * Hd + Hd + c]);
+    out[i] = x[i] + dp.apply(y, i);
+}
+
+// Decoder: u = mean_feat[img] + drop(ctx_prev, 0.5)   (AoA_Model.py:321-323)
+__global__ __launch_bounds__(256) void aoa_u_kernel(const float* __restrict__ meanf, const int32_t* __restrict__ img_of_row,
+                                                    const float* __restrict__ ctx_prev, float* __restrict__ u, int rows, int Hd, DropP dp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * Hd) return;
+    const int row = (int)(i / Hd), c = (int)(i % Hd);
+    const int img = img_of_row ? img_of_row[row] : row;
+    u[i] = meanf[(size_t)img * Hd + c] + dp.apply(ctx_prev[i], i);
+}
+
+// Decoder attention, one query per row (AoA_Model.py:329-334 -> :90-120), one wave per (row, head):
+//   s_r = Qp_h . Kd_h[r] / sqrt(d);  P = softmax_R(s);  Pd = drop(P, 0.1);  x_h = sum_r Pd_r Vd_h[r]
+// Kd / Vd: [n_img, R, Hd] (linear_K / linear_V of the refined features, hoisted: time-invariant).
+// Saves P and Pd ([rows, NH, R]) when requested (backward).
+__global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
+                                                          const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
+                                                          float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
+                                                          int R, int Hd, int NH, DropP dp) {
+    extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [64]
+    const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+    const int d = Hd / NH, ld = d + 1;
+    float* sk = sm_da;
+    float* sv = sk + R * ld;
+    float* sq = sv + R * ld;
+    float* sp = sq + d;
+    const int img = img_of_row ? img_of_row[row] : row;
+    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    for (int i = lane; i < R * d; i += 64) {
+        const int r = i / d, j = i % d;
+        sk[r * ld + j] = Kd[base + (size_t)r * Hd + j];
+        sv[r * ld + j] = Vd[base + (size_t)r * Hd + j];
+    }
+    for (int j = lane; j < d; j += 64) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
+    __syncthreads();
+    float s = -INFINITY;
+    if (lane < R) {
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) acc += sq[j] * sk[lane * ld + j];
+        s = acc / sqrtf((float)d);
+    }
+    const float mx = wave_max(s);
+    const float ex = lane < R ? expf(s - mx) : 0.f;
+    const float sum = wave_sum(ex);
+    const float p = ex / sum;
+    const uint64_t pidx = ((uint64_t)row * NH + hd) * R + lane;
+    const float pd = lane < R ? dp.apply(p, pidx) : 0.f;
+    if (lane < R) {
+        sp[lane] = pd;
+        if (P_out) P_out[pidx] = p;
+        if (Pd_out) Pd_out[pidx] = pd;
+    }
+    __syncthreads();
+    for (int j = lane; j < d; j += 64) {
+        float acc = 0.f;
+        for (int r = 0; r < R; ++r) acc += sp[r] * sv[r * ld + j];
+        xatt[(size_t)row * Hd + (size_t)hd * d + j] = acc;
+    }
+}
+
+// Decoder GLU (no residual): ctx = z[:, :Hd] * sigmoid(z[:, Hd:]);  ctxdrop = drop(ctx, 0.5) for `predict`
+__global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ zslab, int ns, const float* __restrict__ zbias,
+                                                      float* __restrict__ z_out, float* __restrict__ ctx, float* __restrict__ ctxdrop,
+                                                      int rows, int Hd, DropP dp) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * Hd) return;
+    const size_t row = i / Hd;
+    const int c = (int)(i % Hd);
+    const size_t MN = (size_t)rows * 2 * Hd;
+    const float a = sum_slabs1(zslab, ns, MN, row * 2 * Hd + c) + zbias[c];
+    const float b = sum_slabs1(zslab, ns, MN, row * 2 * Hd + Hd + c) + zbias[Hd + c];
+    if (z_out) { z_out[row * 2 * Hd + c] = a; z_out[row * 2 * Hd + Hd + c] = b; }
+    const float y = a * sigmoidf_(b);
+    ctx[i] = y;
+    ctxdrop[i] = dp.apply(y, i);
+}
+
+// mean over regions of [n_img, R, Hd]
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ m, int R, int Hd) {
+    const int img = blockIdx.y;
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= Hd) return;
+    float s = 0.f;
+    for (int r = 0; r < R; ++r) s += x[((size_t)img * R + r) * Hd + c];
+    m[(size_t)img * Hd + c] = s / (float)R;
+}
+
+}  // namespace
+}  // namespace icz

@@ -1,0 +1,454 @@
+// AoADetection captioner, training paths: sampled rollout (sampler_rl, AoA_Model.py:716-734 -> AoA_Decoder.sample_rl :347-401),
+// teacher-forced forward (:676-696 -> AoA_Decoder.forward :231-287) and BPTT for the decoder parameters.
+//
+// Backward layout (same scheme as the BUTD decoder): the reverse-time loop only runs what is truly sequential -- per step
+// three NN dgrad GEMMs (GLU input, attention query, LSTM recurrence) and four pointwise kernels; every weight gradient is
+// one TN GEMM over all (t, b) rows after the loop.  The gradients of the hoisted linear_K / linear_V outputs are
+// accumulated per image over time by the one workgroup that owns the (image, head) slice (no atomics, fixed order).
+#include "aoa_impl.h"
+
+namespace icz {
+namespace {
+
+// GLU backward + the two dropouts that feed ctx_t:
+//   dctx = drop_out'(dCd) + drop_ctx'(du_{t+1})      (ctx_t is the predict input at t and the LSTM input at t+1)
+//   z = [a | b], ctx = a * sigmoid(b):  da = dctx * s,  db = dctx * a * s * (1 - s)
+__global__ __launch_bounds__(256) void aoa_glu_bwd_kernel(const float* __restrict__ dCd, DropP d_out, const float* __restrict__ du_next, int ns,
+                                                          int rows_next, DropP d_ctx_next, const float* __restrict__ z, float* __restrict__ dz,
+                                                          int rows, int Hd) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)rows * Hd) return;
+    const size_t row = i / Hd;
+    const int c = (int)(i % Hd);
+    float d = d_out.apply(dCd[i], i);
+    if (du_next && row < (size_t)rows_next) {
+        const float g = sum_slabs1(du_next, ns, (size_t)rows_next * 2 * Hd, row * 2 * Hd + c);
+        d += d_ctx_next.apply(g, i);
+    }
+    const float a = z[row * 2 * Hd + c], b = z[row * 2 * Hd + Hd + c];
+    const float s = sigmoidf_(b);
+    dz[row * 2 * Hd + c] = d * s;
+    dz[row * 2 * Hd + Hd + c] = d * a * s * (1.f - s);
+}
+
+// Decoder attention backward, one wave per (row, head); row b attends image b (training paths have no beams).
+//   dPd_r = dx_h . V_h[r];  dP = keep/(1-p) * dPd;  dS = P (dP - sum P dP);  dQ_h = sum_r dS_r K_h[r] / sqrt(d)
+//   dK_h[r] += dS_r Q_h / sqrt(d);  dV_h[r] += Pd_r dx_h      (accumulated over time steps in launch order)
+// dx = columns [0, Hd) of the GLU-input gradient slabs [ns][rows][2Hd].
+__global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __restrict__ dxq, int ns, int rows, const float* __restrict__ Pm,
+                                                              const float* __restrict__ Pdm, const float* __restrict__ Qp,
+                                                              const float* __restrict__ Kd, const float* __restrict__ Vd,
+                                                              float* __restrict__ dQp, float* __restrict__ dKd, float* __restrict__ dVd, int R, int Hd,
+                                                              int NH, float keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [64], Pd [64]
+    const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+    const int d = Hd / NH, ld = d + 1;
+    float* sk = sm_db;
+    float* sv = sk + R * ld;
+    float* sq = sv + R * ld;
+    float* sdx = sq + d;
+    float* sds = sdx + d;
+    float* spd = sds + 64;
+    const size_t base = (size_t)row * R * Hd + (size_t)hd * d;
+    for (int i = lane; i < R * d; i += 64) {
+        const int r = i / d, j = i % d;
+        sk[r * ld + j] = Kd[base + (size_t)r * Hd + j];
+        sv[r * ld + j] = Vd[base + (size_t)r * Hd + j];
+    }
+    const size_t MN = (size_t)rows * 2 * Hd;
+    for (int j = lane; j < d; j += 64) {
+        sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
+        sdx[j] = sum_slabs1(dxq, ns, MN, (size_t)row * 2 * Hd + (size_t)hd * d + j);
+    }
+    __syncthreads();
+    const size_t pidx = ((size_t)row * NH + hd) * R + lane;
+    float p = 0.f, pd = 0.f, dP = 0.f;
+    if (lane < R) {
+        p = Pm[pidx]; pd = Pdm[pidx];
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) acc += sdx[j] * sv[lane * ld + j];
+        dP = pd != 0.f ? acc * keep_scale : 0.f;
+    }
+    const float dot = wave_sum(p * dP);
+    const float dS = p * (dP - dot) / sqrtf((float)d);
+    sds[lane] = lane < R ? dS : 0.f;
+    spd[lane] = pd;
+    __syncthreads();
+    for (int j = lane; j < d; j += 64) {
+        float acc = 0.f;
+        const float qj = sq[j], dxj = sdx[j];
+        for (int r = 0; r < R; ++r) {
+            acc += sds[r] * sk[r * ld + j];
+            const size_t g = base + (size_t)r * Hd + j;
+            dKd[g] += sds[r] * qj;
+            dVd[g] += spd[r] * dxj;
+        }
+        dQp[(size_t)row * Hd + (size_t)hd * d + j] = acc;
+    }
+}
+
+// Custom LayerNorm backward (AoA_Model.py:14-25: unbiased std, eps outside the sqrt), one wave per row.
+//   dq = dq_a (slabs [ns_a][rows][Hd], linear_Q dgrad) + dq_b (slabs [ns_b][rows][2Hd] at column offset Hd, GLU-input dgrad)
+//   y = g (x - mean) inv + b, inv = 1/(std + eps):  dy = dq g;  dstd = -inv^2 sum(dy xh);
+//   dxh = dy inv + dstd xh / (std (n-1));  dx = dxh - mean(dxh)
+__global__ __launch_bounds__(256) void aoa_ln_bwd_kernel(const float* __restrict__ dq_a, int ns_a, const float* __restrict__ dq_b, int ns_b, int rows,
+                                                         const float* __restrict__ x, const float* __restrict__ stats,
+                                                         const float* __restrict__ gain, float* __restrict__ dq_tot, float* __restrict__ dx, int n) {
+    const int lane = threadIdx.x & 63;
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const float mean = stats[2 * row], inv = stats[2 * row + 1];
+    const float stdv = 1.0f / inv - 1e-6f;
+    const float* xr = x + (size_t)row * n;
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = lane; c < n; c += 64) {
+        const float dq = sum_slabs1(dq_a, ns_a, (size_t)rows * n, (size_t)row * n + c) +
+                         sum_slabs1(dq_b, ns_b, (size_t)rows * 2 * n, (size_t)row * 2 * n + n + c);
+        dq_tot[(size_t)row * n + c] = dq;
+        const float dy = dq * gain[c];
+        s1 += dy;
+        s2 += dy * (xr[c] - mean);
+    }
+    s1 = wave_sum(s1);
+    s2 = wave_sum(s2);
+    const float dstd = -inv * inv * s2;
+    const float kx = dstd / (stdv * (float)(n - 1));
+    const float mdx = inv * s1 / (float)n;
+    for (int c = lane; c < n; c += 64) {
+        const float dy = dq_tot[(size_t)row * n + c] * gain[c];
+        dx[(size_t)row * n + c] = dy * inv + kx * (xr[c] - mean) - mdx;
+    }
+}
+
+// prod[row, c] = dq[row, c] * (x[row, c] - mean) * inv     (column sums of it = d gain)
+__global__ __launch_bounds__(256) void aoa_ln_prod_kernel(const float* __restrict__ dq, const float* __restrict__ x, const float* __restrict__ stats,
+                                                          float* __restrict__ prod, size_t rows, int n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= rows * n) return;
+    const size_t row = i / n;
+    prod[i] = dq[i] * (x[i] - stats[2 * row]) * stats[2 * row + 1];
+}
+
+__global__ void aoa_captions_to_tok_kernel(const int64_t* __restrict__ cap, int B, int L, int T, int64_t* __restrict__ tok) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= T * B) return;
+    tok[i] = cap[(size_t)(i % B) * L + i / B];
+}
+__global__ void aoa_gather_packed_kernel(const float* __restrict__ logit, int V, int ldl, int B, const int* __restrict__ row_off,
+                                         const int* __restrict__ rows_t, float* __restrict__ out) {
+    const int tb_ = blockIdx.y, t = tb_ / B, b = tb_ % B;
+    if (b >= rows_t[t]) return;
+    const int v = blockIdx.x * 256 + threadIdx.x;
+    if (v < V) out[(size_t)(row_off[t] + b) * V + v] = logit[(size_t)tb_ * ldl + v];
+}
+
+}  // namespace
+
+int Aoa::ensure_train() {
+    if (tready) return ICZ_OK;
+    const size_t B = dims.max_rows, T = dims.max_len, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
+    const size_t TB = T * B;
+    ICZ_TRY(alloc((void**)&tok, sizeof(int64_t) * (TB + B)));
+    float** st1[] = {&th, &tm, &tctx};
+    for (float** p : st1) ICZ_TRY(alloc((void**)p, sizeof(float) * (TB + B) * Hd));
+    ICZ_TRY(alloc((void**)&temb, sizeof(float) * TB * E));
+    float** sth[] = {&tu, &tqn, &tQp, &txatt, &tcd, &dCd, &dQp, &dQn, &prod};
+    for (float** p : sth) ICZ_TRY(alloc((void**)p, sizeof(float) * TB * Hd));
+    ICZ_TRY(alloc((void**)&tg, sizeof(float) * TB * 4 * Hd));
+    ICZ_TRY(alloc((void**)&dG, sizeof(float) * TB * 4 * Hd));
+    ICZ_TRY(alloc((void**)&tz, sizeof(float) * TB * 2 * Hd));
+    ICZ_TRY(alloc((void**)&dZ, sizeof(float) * TB * 2 * Hd));
+    ICZ_TRY(alloc((void**)&tstats, sizeof(float) * TB * 2));
+    ICZ_TRY(alloc((void**)&tP, sizeof(float) * TB * NH * R));
+    ICZ_TRY(alloc((void**)&tPd, sizeof(float) * TB * NH * R));
+    ICZ_TRY(alloc((void**)&tlogit, sizeof(float) * TB * Vp));
+    ICZ_TRY(alloc((void**)&dEmb, sizeof(float) * TB * E));
+    ICZ_TRY(alloc((void**)&dKd, sizeof(float) * B * R * Hd));
+    ICZ_TRY(alloc((void**)&dVd, sizeof(float) * B * R * Hd));
+    ICZ_TRY(alloc((void**)&dHln, sizeof(float) * B * Hd));
+    ICZ_TRY(alloc((void**)&dcb[0], sizeof(float) * B * Hd));
+    ICZ_TRY(alloc((void**)&dcb[1], sizeof(float) * B * Hd));
+    const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
+    xfloats = (size_t)TARGET_WGS * 4096 * 2 + TB * (Hd > E ? Hd : E) + B * 4 * Hd;
+    ICZ_TRY(alloc((void**)&X, sizeof(float) * xfloats));
+    ICZ_TRY(alloc((void**)&X2, sizeof(float) * xfloats));
+    ICZ_TRY(alloc((void**)&dWp, sizeof(float) * (size_t)Vp * Hd));
+    ICZ_TRY(alloc((void**)&coef, sizeof(float) * TB));
+    ICZ_TRY(alloc((void**)&lse, sizeof(float) * TB));
+    ICZ_TRY(alloc((void**)&loss_rows, sizeof(float) * TB));
+    ICZ_TRY(alloc((void**)&draw, sizeof(int32_t) * TB));
+    ICZ_TRY(alloc((void**)&unf, B));
+    ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
+    ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
+    ICZ_TRY(alloc((void**)&colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
+    tready = true;
+    return ICZ_OK;
+}
+
+// step t of a training-mode pass over cur_B rows: inputs / outputs are slots of the saved [T, B, ...] tensors
+AoaStepIO Aoa::train_io(int rows, int t, bool train) {
+    const size_t B = cur_B, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = dims.R;
+    const size_t s0 = (size_t)t * B, s1 = s0 + B;
+    AoaStepIO s = {};
+    s.rows = rows; s.img_of_row = nullptr; s.it = tok + s0; s.emb_ready = false;
+    s.h_in = th + s0 * Hd; s.m_in = tm + s0 * Hd; s.ctx_in = tctx + s0 * Hd;
+    s.h_out = th + s1 * Hd; s.m_out = tm + s1 * Hd; s.ctx_out = tctx + s1 * Hd;
+    s.emb = temb + s0 * E; s.u = tu + s0 * Hd; s.gates_out = tg + s0 * 4 * Hd; s.ln_stats = tstats + s0 * 2;
+    s.qn = tqn + s0 * Hd; s.Qp = tQp + s0 * Hd; s.P_out = tP + s0 * NH * R; s.Pd_out = tPd + s0 * NH * R;
+    s.xatt = txatt + s0 * Hd; s.z_out = tz + s0 * 2 * Hd; s.ctxdrop = tcd + s0 * Hd; s.logits = tlogit + s0 * Vp;
+    s.d_emb = dropbits(train, rng.emb_mask, s0 * E, RNG_EMB, t);
+    s.d_ctx = dropp(train, rng.ctx_mask, s0 * Hd, AOA_RNG_CTX, t, 0.5f);
+    s.d_att = dropp(train, rng.att_mask, s0 * NH * R, AOA_RNG_ATT, t, 0.1f);
+    s.d_out = dropp(train, rng.out_mask, s0 * Hd, AOA_RNG_OUT, t, 0.5f);
+    return s;
+}
+
+int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0 && T <= dims.max_len, "aoa sample: bad arguments");
+    ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    ICZ_TRY(ensure_train());
+    rng = *r;
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
+    mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_seq = seq_out; cur_logp = logp_out;
+    rows_t.assign(T, B);
+    ICZ_TRY(refine(feats, B, true, st));
+    const size_t sH = (size_t)B * dims.Hd;
+    ICZ_CHECK_HIP(hipMemsetAsync(th, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tm, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tctx, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(unf, 1, B, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(nunf, 0, sizeof(int) * T, st));
+    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, tok, (int64_t)1, B);
+    for (int t = 0; t < T; ++t) {
+        const size_t slot = (size_t)t * B;
+        ICZ_TRY(step(train_io(B, t, true), st));
+        SampleSelArgs a = {};
+        a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
+        a.uniforms = rng.uniforms ? rng.uniforms + slot : nullptr;
+        a.seed_p = d_seed; a.t = t; a.T = T;
+        a.unfinished = unf; a.n_unfinished = nunf; a.seq_out = seq_out; a.logp_out = logp_out;
+        a.it_next = tok + slot + B; a.draw_out = draw + slot; a.lse_out = lse + slot;
+        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st) {
+    ICZ_REQUIRE(mode == 1, "aoa: no rollout stored (call icz_aoa_sample first)");
+    ICZ_REQUIRE(reward && G, "aoa sample_backward: null argument");
+    const int B = cur_B, T = cur_T;
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
+    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum, coef, loss_out, msum_out);
+    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, draw, lse, coef, B, T);
+    mode = 0;
+    return bptt(*G, st);
+}
+
+int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_aoa_rng* r, int train,
+                    float* packed_out, hipStream_t st) {
+    ICZ_REQUIRE(feats && captions && lengths && B > 0 && B <= dims.max_rows && L > 1, "aoa xe_forward: bad arguments");
+    ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    ICZ_REQUIRE(!train || r, "aoa xe_forward: training mode needs an icz_aoa_rng");
+    int T = 0;
+    for (int b = 0; b < B; ++b) {
+        ICZ_REQUIRE(lengths[b] >= 1 && lengths[b] <= L - 1, "aoa xe_forward: length %d out of range 1..%d", lengths[b], L - 1);
+        ICZ_REQUIRE(b == 0 || lengths[b] <= lengths[b - 1], "aoa xe_forward: lengths must be sorted in decreasing order");
+        if (lengths[b] > T) T = lengths[b];
+    }
+    ICZ_REQUIRE(T <= dims.max_len, "aoa xe_forward: %d steps exceed max_len %d", T, dims.max_len);
+    ICZ_TRY(ensure_train());
+    if (r) rng = *r; else rng = {};
+    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
+    mode = 2; cur_B = B; cur_T = T; cur_L = L; cur_train = train != 0; cur_captions = captions;
+    rows_t.assign(T, 0);
+    n_tokens = 0;
+    for (int t = 0; t < T; ++t) {
+        int cnt = 0;
+        for (int b = 0; b < B; ++b) cnt += lengths[b] > t;
+        rows_t[t] = cnt;
+        n_tokens += cnt;
+    }
+    ICZ_TRY(refine(feats, B, cur_train, st));
+    const size_t sH = (size_t)B * dims.Hd;
+    ICZ_CHECK_HIP(hipMemsetAsync(th, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tm, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tctx, 0, sizeof(float) * sH, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(tlogit, 0, sizeof(float) * (size_t)T * B * Vp, st));
+    hipLaunchKernelGGL(aoa_captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tok);
+    for (int t = 0; t < T; ++t) ICZ_TRY(step(train_io(rows_t[t], t, cur_train), st));
+    if (packed_out) {
+        std::vector<int> hostv(2 * T);
+        int acc = 0;
+        for (int t = 0; t < T; ++t) { hostv[t] = acc; hostv[T + t] = rows_t[t]; acc += rows_t[t]; }
+        ICZ_CHECK_HIP(hipMemcpyAsync(pack_idx, hostv.data(), sizeof(int) * 2 * T, hipMemcpyHostToDevice, st));
+        ICZ_CHECK_HIP(hipStreamSynchronize(st));
+        hipLaunchKernelGGL(aoa_gather_packed_kernel, dim3(cdiv(dims.V, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, B, pack_idx,
+                           pack_idx + T, packed_out);
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+int Aoa::xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, float n_tokens_global, hipStream_t st) {
+    ICZ_REQUIRE(mode == 2, "aoa: no XE forward stored (call icz_aoa_xe_forward first)");
+    ICZ_REQUIRE(G, "aoa xe_backward: null grads");
+    const int B = cur_B, T = cur_T;
+    const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
+    ICZ_CHECK_HIP(hipMemsetAsync(loss_rows, 0, sizeof(float) * T * B, st));
+    for (int t = 0; t < T; ++t)
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(rows_t[t]), dim3(256), 0, st, tlogit + (size_t)t * B * Vp, dims.V, Vp,
+                           cur_captions + (t + 1), cur_L, smoothing, 1.0f / n, loss_rows + (size_t)t * B);
+    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, loss_out);
+    mode = 0;
+    return bptt(*G, st);
+}
+
+int Aoa::colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st) {
+    int KS = cdiv(K, 16);
+    if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
+    const int rows_per = cdiv(K, KS);
+    KS = cdiv(K, rows_per);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), KS), dim3(256), 0, st, Xm, K, N, ldx, rows_per, colsum_part);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, colsum_part, KS, N, out);
+    return ICZ_OK;
+}
+
+// slabs [ns][M][N] = A[M,K] . B[K,N]  (ns == 1: the dense product); `cap` = capacity of slab_out in floats
+int Aoa::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* slab_out, size_t cap, int* ns_out, int target,
+            hipStream_t st) {
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {A, Bm, lda, ldb, K, nullptr};
+    g.M = M; g.N = N; g.out = slab_out; g.ldo = N;
+    g.nsplit = gemm_pick_split(g, target, GEMM_NN);
+    ICZ_REQUIRE(gemm_slab_floats(M, N, g.nsplit) <= cap, "aoa: slab buffer too small");
+    ICZ_TRY(gemm_f32(GEMM_NN, g, st));
+    *ns_out = g.nsplit;
+    return ICZ_OK;
+}
+
+int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st) {
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {dY, Xm, ldy, ldx, K, nullptr};
+    g.M = M; g.N = N; g.out = out; g.ldo = ldo; g.nsplit = 1; g.accumulate = accumulate;
+    return gemm_f32(GEMM_TN, g, st);
+}
+
+int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
+    const int B = cur_B, T = cur_T, Hd = dims.Hd, E = dims.E, V = dims.V, NH = dims.NH, R = dims.R, dh = Hd / NH;
+    const int TB = T * B;
+    const size_t sH = (size_t)B * Hd;
+    int ns = 1;
+    // ---- predict layer over all time steps: d(dropped ctx), weight-norm gradients
+    ICZ_TRY(nn(tlogit, Vp, TB, Vp, w_pred, Hd, Hd, X, xfloats, &ns, TARGET_WGS, st));
+    {
+        const size_t MN = (size_t)TB * Hd;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, Hd, (const float*)nullptr, dCd);
+    }
+    ICZ_TRY(tn(tlogit, Vp, Vp, tcd, Hd, Hd, TB, dWp, Hd, 0, st));
+    ICZ_TRY(colsum(tlogit, TB, V, Vp, G.predict_b, st));
+    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
+                       G.predict_g, V, Hd);
+    ICZ_CHECK_HIP(hipMemsetAsync(dKd, 0, sizeof(float) * sH * R, st));
+    ICZ_CHECK_HIP(hipMemsetAsync(dVd, 0, sizeof(float) * sH * R, st));
+    if (rows_t[T - 1] < B) {      // ragged batch: rows that are inactive at step t contribute exact zeros to the batched GEMMs
+        ICZ_CHECK_HIP(hipMemsetAsync(dZ, 0, sizeof(float) * (size_t)TB * 2 * Hd, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(dQp, 0, sizeof(float) * (size_t)TB * Hd, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(dQn, 0, sizeof(float) * (size_t)TB * Hd, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(dG, 0, sizeof(float) * (size_t)TB * 4 * Hd, st));
+    }
+    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
+    DropCfg off = {0, nullptr, nullptr, 0, 0};
+    int cur = 0, nsx = 1, bnext = 0;
+    for (int t = T - 1; t >= 0; --t) {
+        const int bt = rows_t[t];
+        const size_t s0 = (size_t)t * B;
+        const AoaStepIO io = train_io(bt, t, cur_train);
+        const AoaStepIO io_next = train_io(bnext, t + 1 < T ? t + 1 : t, cur_train);
+        const unsigned eb = (unsigned)(((size_t)bt * Hd + 255) / 256);
+        hipLaunchKernelGGL(aoa_glu_bwd_kernel, dim3(eb), dim3(256), 0, st, dCd + s0 * Hd, io.d_out, bnext ? (const float*)X : nullptr, nsx, bnext,
+                           io_next.d_ctx, tz + s0 * 2 * Hd, dZ + s0 * 2 * Hd, bt, Hd);
+        int ns2 = 1, nsq = 1;
+        ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
+        hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
+                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, dKd, dVd, R, Hd, NH, io.d_att.mode ? io.d_att.scale : 1.0f);
+        ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
+        hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(cdiv(bt, 4)), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
+                           P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
+        LstmBwdArgs a = {};
+        a.dh_a = bnext ? X + Hd : nullptr; a.ns_a = nsx; a.lda_a = 2 * Hd; a.rows_a = bnext;
+        a.dh_b = dHln; a.ns_b = 1; a.lda_b = Hd; a.rows_b = bt;
+        a.dc_in = bnext ? dcb[cur] : nullptr; a.dc_in_rows = bnext;
+        a.gates = tg + s0 * 4 * Hd;
+        a.c_prev = tm + s0 * Hd; a.c_cur = tm + (s0 + B) * Hd;
+        a.dgates = dG + s0 * 4 * Hd; a.dc_prev = dcb[cur ^ 1];
+        a.rows = bt; a.H = Hd;
+        hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(Hd, 256), bt), dim3(256), 0, st, a, off);
+        // [du_t | dh_{t-1}] = dgates_t . [W_ih[:, E:] | W_hh]
+        if (t > 0) ICZ_TRY(nn(dG + s0 * 4 * Hd, 4 * Hd, bt, 4 * Hd, w_rec, 2 * Hd, 2 * Hd, X, xfloats, &nsx, STEP_WGS, st));
+        bnext = bt;
+        cur ^= 1;
+    }
+    // ---- embedding gradient
+    ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st));
+    {
+        const size_t MN = (size_t)TB * E;
+        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, E, (const float*)nullptr, dEmb);
+    }
+    hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), sizeof(int) * TB, st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E,
+                       G.embed_weight, 1);
+    // ---- weight gradients: one TN GEMM each over all (t, b) rows
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st));
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st));
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st));
+    ICZ_TRY(colsum(dG, TB, 4 * Hd, 4 * Hd, G.lstm_b_ih, st));
+    ICZ_CHECK_HIP(hipMemcpyAsync(G.lstm_b_hh, G.lstm_b_ih, sizeof(float) * 4 * Hd, hipMemcpyDeviceToDevice, st));
+    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st));
+    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st));
+    ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
+    ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st));
+    ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));
+    ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.k_w, Hd, 0, st));
+    ICZ_TRY(colsum(dKd, B * R, Hd, Hd, G.dec.k_b, st));
+    ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.v_w, Hd, 0, st));
+    ICZ_TRY(colsum(dVd, B * R, Hd, Hd, G.dec.v_b, st));
+    // ---- h_norm gain / bias
+    {
+        const size_t n = (size_t)TB * Hd;
+        hipLaunchKernelGGL(aoa_ln_prod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dQn, th + sH, tstats, prod, (size_t)TB, Hd);
+        ICZ_TRY(colsum(prod, TB, Hd, Hd, G.dec.ln_g, st));
+        ICZ_TRY(colsum(dQn, TB, Hd, Hd, G.dec.ln_b, st));
+    }
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+}  // namespace icz
+
+// ================================================================================================
+using namespace icz;
+extern "C" {
+
+int icz_aoa_sample(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, const icz_aoa_rng* rng, int64_t* seq_out,
+                   float* logprobs_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->sample(feats, B, max_len, rng, seq_out, logprobs_out, (hipStream_t)stream);
+}
+int icz_aoa_sample_backward(icz_aoa_t* h, const float* reward, const icz_aoa_params* grads, float* loss_out, float* mask_sum_out,
+                            float mask_sum_global, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->sample_backward(reward, grads, loss_out, mask_sum_out, mask_sum_global, (hipStream_t)stream);
+}
+int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,
+                       const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->xe_forward(feats, captions, B, L, lengths_host, rng, train, packed_logits_out, (hipStream_t)stream);
+}
+int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->xe_backward(smoothing, grads, loss_out, n_tokens_global, (hipStream_t)stream);
+}
+
+}  // extern "C"

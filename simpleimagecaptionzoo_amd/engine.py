@@ -153,7 +153,7 @@ class BUTDDetection_Eng(Engine):
     def _grads(self):
         """Gradient buffers as views into ONE flat fp32 buffer (a single all-reduce over xGMI moves them all)."""
         if getattr(self, "_flat", None) is None:
-            named = self.model._named()
+            named = self._trainable()
             offs, total = {}, 0
             for k, p in named.items():
                 offs[k] = total
@@ -162,13 +162,17 @@ class BUTDDetection_Eng(Engine):
             self._gviews = {k: self._flat[o:o + named[k].numel()].view_as(named[k]) for k, o in offs.items()}
         return self._gviews
 
+    def _trainable(self):
+        """name -> parameter for everything the optimizer updates (AoA: the decoder only, AoA_Model.py:669-674)."""
+        return getattr(self.model, "_trainable", self.model._named)()
+
     def _apply(self, optimizer, clip):
-        named = self.model._named()
+        named = self._trainable()
         grads = self._gviews
         if isinstance(optimizer, FusedAdam):
-            optimizer.step_with({named[k]: grads[k] for k in BUTD_PARAM_KEYS}, clip)
+            optimizer.step_with({named[k]: grads[k] for k in grads}, clip)
         else:   # a torch optimizer handed in by unmodified reference code
-            for k in BUTD_PARAM_KEYS:
+            for k in grads:
                 named[k].grad = grads[k].clamp(-clip, clip)
             optimizer.step()
 
@@ -284,6 +288,18 @@ class BUTDDetection_Eng(Engine):
                         sampled_caption.append(word)
                 result.append({"image_id": int(image_ids[image_idx]), "caption": " ".join(sampled_caption)})
         return result
+
+
+class AoADetection_Eng(BUTDDetection_Eng):
+    """ModelEngines/AoA_Engine.py (same visual-input handling as the BUTD engine) + the three hot Engine methods."""
+
+    def model_construction(self, max_batch):
+        from .aoa import AoADetection_Captioner
+        s = self.settings
+        assert s["model_type"] in ("AoADetection", "AoASpatial")
+        return AoADetection_Captioner(vocab_size=len(self.caption_vocab), num_heads=s.get("num_heads", 8), hidden_dim=s["hidden_dim"],
+                                      embed_dim=s["embed_dim"], device=str(self.device), num_regions=s.get("num_regions", 36),
+                                      enc_dim=s.get("enc_dim", 2048), max_batch=max_batch)
 
 
 class BUTDSpatial_Eng(BUTDDetection_Eng):

@@ -1,0 +1,147 @@
+"""GPU parity of the AoA captioner (csrc/aoa.hip, aoa_train.hip) against the reference goldens (tests/golden/aoa_tiny.npz)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from synth import feats_from_seed
+
+pytestmark = pytest.mark.gpu
+
+MASKS = ("proj", "ref_att", "ref_aoa", "ref_sc", "emb", "ctx", "att", "out")
+
+
+@pytest.fixture(scope="module")
+def g(golden_dir):
+    return dict(np.load(os.path.join(golden_dir, "aoa_tiny.npz")))
+
+
+def dims(g):
+    return [int(x) for x in g["dims"]]      # B, R, D, Hd, E, V, NH
+
+
+def feats_of(g):
+    B, R, D = dims(g)[:3]
+    return torch.from_numpy(feats_from_seed(int(g["feats_seed"]), B, R, D)).cuda()
+
+
+def make(g, sd=None, max_rows=16):
+    from simpleimagecaptionzoo_amd.aoa import AoaHandle
+    B, R, D, Hd, E, V, NH = dims(g)
+    sd = sd if sd is not None else {k[3:]: v for k, v in g.items() if k.startswith("sd.")}
+    params = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device="cuda") for k, v in sd.items()}
+    h = AoaHandle(R, D, Hd, E, V, NH, max_rows, 20)
+    h.bind(params)
+    return h
+
+
+def rng_of(g, prefix, uniforms=None):
+    from simpleimagecaptionzoo_amd.aoa import make_aoa_rng
+    w = dict(zip(MASKS, [int(x) for x in g["mask_widths"]]))
+    masks = {k: torch.from_numpy(np.ascontiguousarray(np.unpackbits(g[prefix + k], axis=-1)[..., :w[k]])).cuda() for k in MASKS}
+    return make_aoa_rng(0, uniforms, masks)
+
+
+def regime_sd(g, regime):
+    sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
+    if regime == "early":
+        sd["decoder.predict.bias"][2] = 4.0
+    elif regime == "never":
+        sd["decoder.predict.bias"][2] = -1e4
+    elif regime == "track":
+        tok = int(g["beam_track_tok"])
+        sd["decoder.predict.weight_v"][2] = sd["decoder.predict.weight_v"][tok]
+        sd["decoder.predict.weight_g"][2] = sd["decoder.predict.weight_g"][tok]
+        sd["decoder.predict.bias"][2] = sd["decoder.predict.bias"][tok] - 0.2
+    return sd
+
+
+def check_grads(grads, g, prefix):
+    for k, v in grads.items():
+        want = g[prefix + k[len("decoder."):]]
+        got = v.cpu().numpy()
+        scale = max(1e-3, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 2e-4 * scale + 2e-6, (k, np.abs(got - want).max(), scale)
+
+
+def test_aoa_refiner_and_greedy(g):
+    h = make(g)
+    feats = feats_of(g)
+    np.testing.assert_allclose(h.refine(feats).cpu().numpy(), g["refined_eval"], atol=5e-5, rtol=1e-4)
+    assert np.array_equal(h.greedy(feats, 20).cpu().numpy(), g["greedy_ids"])
+
+
+def test_aoa_beam_token_exact(g):
+    feats = feats_of(g)
+    for regime in ("nat", "early", "never", "track"):
+        h = make(g, regime_sd(g, regime))
+        for k in (1, 3, 5):
+            seqs, lens = h.beam_search(feats[:3], k, 50)
+            seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+            for i in range(3):
+                want = g["beam_%s_k%d_i%d" % (regime, k, i)].ravel()
+                assert lens[i] == want.shape[0] and np.array_equal(seqs[i, :lens[i]], want), (regime, k, i)
+
+
+def test_aoa_xe_logits_loss_and_decoder_grads(g):
+    h = make(g)
+    feats = feats_of(g)
+    logits = h.xe_forward(feats, torch.tensor(g["xe_captions"], device="cuda"), g["xe_lengths"].tolist(), rng_of(g, "xe_mask."), True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+    grads = h.new_grads()
+    loss = h.xe_backward(grads, 0.1)
+    assert abs(loss.item() - float(g["xe_loss"])) < 1e-4
+    check_grads(grads, g, "xe_grad.")
+
+
+def test_aoa_sample_rl_and_reinforce_grads(g):
+    sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
+    sd["decoder.predict.bias"][2] = float(g["rl_end_bias"])
+    h = make(g, sd)
+    feats = feats_of(g)
+    rng = rng_of(g, "rl_mask.", torch.tensor(g["rl_u"], dtype=torch.float32, device="cuda"))
+    seq, lp = h.sample(feats, 20, rng)
+    assert np.array_equal(seq.cpu().numpy(), g["rl_seq"])
+    np.testing.assert_allclose(lp.cpu().numpy(), g["rl_logprobs"], atol=1e-4)
+    grads = h.new_grads()
+    loss, msum = h.sample_backward(torch.tensor(g["rl_reward"], device="cuda"), grads)
+    assert abs(loss.item() - float(g["rl_loss"])) < 1e-4
+    assert abs(msum.item() - h.sample_mask_sum()) < 0.5
+    check_grads(grads, g, "rl_grad.")
+
+
+def test_aoa_philox_paths_run_and_are_reproducible(g):
+    """No explicit masks: dropout / sampling bits come from the Philox streams; same seed -> same rollout and gradients."""
+    from simpleimagecaptionzoo_amd.aoa import make_aoa_rng
+    h = make(g)
+    feats = feats_of(g)
+    out = []
+    for _ in range(2):
+        seq, lp = h.sample(feats, 20, make_aoa_rng(1234))
+        grads = h.new_grads()
+        loss, _ = h.sample_backward(torch.ones(seq.shape, device="cuda"), grads)
+        out.append((seq.clone(), lp.clone(), loss.item(), {k: v.clone() for k, v in grads.items()}))
+    assert torch.equal(out[0][0], out[1][0]) and torch.equal(out[0][1], out[1][1]) and out[0][2] == out[1][2]
+    for k in out[0][3]:
+        assert torch.equal(out[0][3][k], out[1][3][k]), k
+        assert torch.isfinite(out[0][3][k]).all()
+    seq2, _ = h.sample(feats, 20, make_aoa_rng(99))
+    assert not torch.equal(seq2, out[0][0])
+
+
+def test_aoa_captioner_state_dict_and_engine(g):
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner
+    B, R, D, Hd, E, V, NH = dims(g)
+    cap = AoADetection_Captioner(V, NH, Hd, E, num_regions=R, enc_dim=D, max_batch=8).cuda()
+    want = sorted(k[3:] for k in g if k.startswith("sd."))
+    assert sorted(cap.state_dict().keys()) == want
+    for k, v in cap.state_dict().items():
+        assert tuple(v.shape) == g["sd." + k].shape, k
+    cap.load_state_dict({k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")})
+    cap.eval()
+    vi = {"bu_feats": feats_of(g), "bu_bboxes": None, "bu_masks": None}
+    assert np.array_equal(cap.sampler(vi, 20).cpu().numpy(), g["greedy_ids"])
+    one = {"bu_feats": feats_of(g)[1:2], "bu_bboxes": None, "bu_masks": None}
+    assert np.array_equal(cap.beam_search_sampler(one, 3).cpu().numpy(), g["beam_nat_k3_i1"])
+    assert len(cap.get_param_groups({"lr": 1e-4})[0]["params"]) == 18
