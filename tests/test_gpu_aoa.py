@@ -145,3 +145,53 @@ def test_aoa_captioner_state_dict_and_engine(g):
     one = {"bu_feats": feats_of(g)[1:2], "bu_bboxes": None, "bu_masks": None}
     assert np.array_equal(cap.beam_search_sampler(one, 3).cpu().numpy(), g["beam_nat_k3_i1"])
     assert len(cap.get_param_groups({"lr": 1e-4})[0]["params"]) == 18
+
+
+class _Crit:
+    smoothing = 0.1
+
+
+def _supp(feats):
+    return tuple({"bu_feat": feats[i], "bu_bbox": np.zeros((feats.shape[1], 4), np.float32)} for i in range(feats.shape[0]))
+
+
+def test_aoa_engine_xe_step_scst_step_and_eval(g):
+    """AoADetection_Eng: one training_epoch step = golden XE gradients -> clamp 0.1 -> Adam (oracle restatement) on the decoder
+    only; then one SCST step and the evaluation JSON run end to end on the device."""
+    from oracle.butd import Adam
+    from simpleimagecaptionzoo_amd.engine import AoADetection_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    B, R, D, Hd, E, V, NH = dims(g)
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    gts = synthetic_references(B, words, seed=5)
+    eng = AoADetection_Eng({"model_type": "AoADetection", "embed_dim": E, "hidden_dim": Hd, "num_heads": NH, "num_regions": R,
+                            "enc_dim": D}, "SYN", vocab, data_dir="/tmp/", use_bu="fixed", device="cuda:0",
+                           cider_df=document_frequency(gts), max_batch=8)
+    sd0 = {k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")}
+    eng.model.load_state_dict(sd0, strict=True)
+    feats = feats_from_seed(int(g["feats_seed"]), B, R, D)
+    lr = 4e-4
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": lr}), lr)
+    batch = (tuple(range(B)), None, torch.tensor(g["xe_captions"]), [int(x) + 1 for x in g["xe_lengths"]], _supp(feats))
+    losses = eng.training_epoch([batch], opt, _Crit(), tqdm_visible=False, rngs=[rng_of(g, "xe_mask.")])
+    assert abs(losses[0].item() - float(g["xe_loss"])) < 1e-4
+    dec = {k: v.clone() for k, v in sd0.items() if k.startswith("decoder.")}
+    Adam(dec, lr).step({k: torch.tensor(g["xe_grad." + k[len("decoder."):]]) for k in dec}, 0.1)
+    after = eng.model.state_dict()
+    for k, v in after.items():
+        want = dec[k] if k in dec else sd0[k]        # the refiner / projection are not in the optimizer
+        # linear_K.bias shifts every score of a softmax row equally: its gradient is identically zero, the reference feeds
+        # Adam rounding noise there (|update| <= lr), like BUTD's atten.affine.bias
+        tol = lr * 1.01 if k == "decoder.aoa_block.linear_K.bias" else 2e-5
+        np.testing.assert_allclose(v.cpu().numpy(), want.numpy(), atol=tol, rtol=0, err_msg=k)
+    before = {k: v.clone() for k, v in eng.model.state_dict().items()}
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    losses = eng.SCST_training_epoch([(tuple(range(B)), None, gts, _supp(feats))], opt, None, tqdm_visible=False)
+    assert np.isfinite(losses[0].item())
+    now = eng.model.state_dict()
+    assert any(not torch.equal(now[k], before[k]) for k in now if k.startswith("decoder."))
+    assert all(torch.equal(now[k], before[k]) for k in now if not k.startswith("decoder."))
+    res = eng.eval_captions_json_generation([(tuple(range(B)), None, _supp(feats))], eval_beam_size=3, tqdm_visible=False)
+    assert len(res) == B and all(isinstance(r["caption"], str) and r["image_id"] == i for i, r in enumerate(res))
