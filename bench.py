@@ -154,6 +154,14 @@ def main():
     value = world * B * args.steps / dt
     ach_gbs = bpl.value / (avg_us.value * 1e-6) / 1e9 if avg_us.value > 0 else 0.0
     ach_tf = fpl.value / (avg_us.value * 1e-6) / 1e12 if avg_us.value > 0 else 0.0
+    # HBM bytes per launch of the same kernel from the PMC passes of this command (FETCH_SIZE x2 + WRITE_SIZE, gfx950
+    # corrections applied by tools/pmc_summary.py); PMC counters cannot be read from inside the process
+    traffic = None
+    try:
+        pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
+        traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "gemm_nt_kernel" in k][0]
+    except Exception:
+        pass
     out = {
         "metric": "captions/sec (SCST step), BUTDDetection COCO14-size vocab",
         "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -164,7 +172,8 @@ def main():
                    "global_batch": world * B, "parallelism": "dp%d" % world},
         "roofline": {"kernel": "gemm_nt_kernel<4> (decoder-step forward GEMMs: LSTM gates, dec_att, predict, prologue)",
                      "bound": "hbm", "achieved": ach_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": None,
+                     "frac": ach_gbs / HBM_PEAK_GBS, "traffic": traffic,
+                     "traffic_source": "profiles/r01_pmc_traffic.json (rocprofv3 --pmc passes of this command)" if traffic else None,
                      "avg_launch_us": avg_us.value, "launches": nl.value, "bytes_per_launch": bpl.value,
                      "measured": "HIP event pair around every launch; eager single-stream re-run of the same steps right after the timed region",
                      "mfma_f32_tflops": ach_tf, "mfma_f32_frac": ach_tf / MFMA_F32_PEAK_TFLOPS},
