@@ -157,6 +157,9 @@ struct AttScoreArgs {
     float* scores;               // [rows, R]
     int rows, R, A;
 };
+// Grid (rows, parts), 256 threads.  Part p owns regions p, p + parts, p + 2 parts, ...; a wave takes up to three of them
+// at a time and issues all their loads (3 regions x 4 float4 per lane) before the first use: the kernel moves
+// R*A*4 bytes per row once and is bound by how many bytes each CU keeps in flight, not by arithmetic.
 __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg dc) {
     extern __shared__ __attribute__((aligned(16))) float sdec[];   // A floats
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
@@ -172,61 +175,102 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
     }
     __syncthreads();
     const int img = a.img_of_row ? a.img_of_row[row] : row;
-    const int per = (a.R + nparts - 1) / nparts;
-    const int r_end = min(a.R, (part + 1) * per);
     const float baff = a.b_aff[0];
-    for (int r = part * per + wave; r < r_end; r += 4) {
-        const float* e = a.enc_ctx + ((size_t)img * a.R + r) * a.A;
-        float acc = 0.f;
-        for (int c = lane * 4; c < a.A; c += 256) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(e + c);
-            f32x4 d = *reinterpret_cast<const f32x4*>(sdec + c);
-            f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
-            uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu;
-            const float sc = dc.mode ? 2.0f : 1.0f;
+    const float sc = dc.mode ? 2.0f : 1.0f;
+    constexpr int NB = 3;
+    for (int i0 = wave; part + nparts * i0 < a.R; i0 += 4 * NB) {
+        int rr[NB];
+        bool ok[NB];
+        const float* e[NB];
+        float acc[NB];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                float zv = fmaxf(x[j] + d[j], 0.f);
-                zv = ((k >> j) & 1u) ? zv * sc : 0.f;
-                acc += zv * w[j];
+        for (int b = 0; b < NB; ++b) {
+            const int r = part + nparts * (i0 + 4 * b);
+            ok[b] = r < a.R;
+            rr[b] = ok[b] ? r : part + nparts * i0;
+            e[b] = a.enc_ctx + ((size_t)img * a.R + rr[b]) * a.A;
+            acc[b] = 0.f;
+        }
+        for (int c0 = lane * 4; c0 < a.A; c0 += 1024) {
+            f32x4 x[NB][4];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < 4; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(e[b] + min(c0 + 256 * u, a.A - 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < a.A) {
+                    const f32x4 d = *reinterpret_cast<const f32x4*>(sdec + c);
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) {
+                        const uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + rr[b]) * a.A + c) : 0xFu;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            float zv = fmaxf(x[b][u][j] + d[j], 0.f);
+                            zv = ((k >> j) & 1u) ? zv * sc : 0.f;
+                            acc[b] += zv * w[j];
+                        }
+                    }
+                }
             }
         }
-        acc = wave_sum(acc);
-        if (lane == 0) a.scores[(size_t)row * a.R + r] = acc + baff;
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float v = wave_sum(acc[b]);
+            if (lane == 0 && ok[b]) a.scores[(size_t)row * a.R + rr[b]] = v + baff;
+        }
     }
 }
 
 // ---------------------------------------------------------------------------------------------------------
 // softmax over regions + attention-weighted feature sum (:60-61):
 //   alpha = softmax_r(score[row,:]);  ctx[row, d] = sum_r alpha[r] * feats[img, r, d]
-// Grid (rows, D/1024): each thread owns 4 consecutive d; a wave's loads are 1 KiB contiguous per region.
-// The R <= 64 scores are reduced with wave shuffles (lane r holds score r) by every wave (redundantly, R is tiny).
+// Grid (rows, D/512), 256 threads: thread (half, cg) sums one half of the regions for 4 consecutive d (16-byte loads,
+// 9 in flight per thread); the two halves meet in LDS.  Every wave recomputes the R <= 64 softmax (lane r holds score r).
 __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ feats, const int32_t* __restrict__ img_of_row,
                                                       const float* __restrict__ scores, float* __restrict__ alpha_out,
                                                       float* __restrict__ alpha_out2, int alpha2_stride,
                                                       float* __restrict__ ctx, int R, int D) {
-    // grid (rows, D/256): one feature column per thread, 36 independent coalesced loads (1 KiB per wave each)
-    const int row = blockIdx.x;
-    const int lane = threadIdx.x & 63;
-    const float sc = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
-    const float mx = wave_max(sc);
-    const float ex = lane < R ? expf(sc - mx) : 0.f;
+    __shared__ float sal[64];
+    __shared__ __attribute__((aligned(16))) float spart[128 * 4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const float scv = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
+    const float mx = wave_max(scv);
+    const float ex = lane < R ? expf(scv - mx) : 0.f;
     const float sum = wave_sum(ex);
     const float al = ex / sum;
-    if (blockIdx.y == 0 && threadIdx.x < R) {
-        alpha_out[(size_t)row * R + threadIdx.x] = al;
-        if (alpha_out2) alpha_out2[(size_t)row * alpha2_stride + threadIdx.x] = al;
+    if (tid < 64) {
+        sal[tid] = al;
+        if (blockIdx.y == 0 && tid < R) {
+            alpha_out[(size_t)row * R + tid] = al;
+            if (alpha_out2) alpha_out2[(size_t)row * alpha2_stride + tid] = al;
+        }
     }
-    const int d = blockIdx.y * 256 + threadIdx.x;
-    const bool valid = d < D;            // no early return: every lane must stay active for the shuffles
+    __syncthreads();
+    const int cg = tid & 127, half = tid >> 7;
+    const int d = blockIdx.y * 512 + cg * 4;
+    const bool valid = d < D;
     const int img = img_of_row ? img_of_row[row] : row;
+    const int Rh = (R + 1) / 2;
+    const int r_lo = half ? Rh : 0, r_hi = half ? R : Rh;
     const float* f = feats + (size_t)img * R * D + (valid ? d : 0);
-    float acc = 0.f;
-    for (int r = 0; r < R; ++r) {
-        const float w = __shfl(al, r, 64);
-        acc += f[(size_t)r * D] * w;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        constexpr int RB = 9;
+        for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
+            f32x4 x[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) x[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r0 + u, r_hi - 1) * D);
+#pragma unroll
+            for (int u = 0; u < RB; ++u)
+                if (r0 + u < r_hi) acc += x[u] * sal[r0 + u];
+        }
     }
-    if (valid) ctx[(size_t)row * D + d] = acc;
+    if (half) *reinterpret_cast<f32x4*>(spart + cg * 4) = acc;
+    __syncthreads();
+    if (!half && valid) *reinterpret_cast<f32x4*>(ctx + (size_t)row * D + d) = acc + *reinterpret_cast<const f32x4*>(spart + cg * 4);
 }
 
 __device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_stride, size_t off) {
@@ -235,91 +279,6 @@ __device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_
     s = *reinterpret_cast<const f32x4*>(p + off);
     for (int z = 1; z < ns; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * slab_stride + off);
     return s;
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused SoftAttention forward (:49-62), one 512-thread workgroup per decoder row:
-//   dec_ctx = sum_z slab[z,row,:] + b_dec                          (dec_att GEMM split-K partials summed here)
-//   score_r = w_aff . drop(relu(enc_ctx[img,r,:] + dec_ctx)) + b_aff      8 waves walk the R regions
-//   alpha   = softmax_R(score)                                      wave shuffles
-//   ctx     = sum_r alpha_r feats[img,r,:]                          512 threads x float4 = 2048 columns per pass
-// One launch instead of two (scores, context); the R x A block of enc_ctx and the R x D block of features of the row
-// are each read exactly once, with 16-byte loads.
-__global__ __launch_bounds__(512) void att_fwd_kernel(AttScoreArgs a, const float* __restrict__ feats, float* __restrict__ alpha_out,
-                                                      float* __restrict__ alpha_out2, int alpha2_stride, float* __restrict__ ctx,
-                                                      int D, DropCfg dc) {
-    extern __shared__ __attribute__((aligned(16))) float sm_att[];   // [A] dec_ctx, [64] scores/alpha
-    float* sdec = sm_att;
-    float* sal = sm_att + a.A;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t MN = (size_t)a.rows * a.A;
-    for (int c = tid * 4; c < a.A; c += 2048) {
-        const size_t off = (size_t)row * a.A + c;
-        f32x4 s = sum_slabs4(a.dec_slab, a.nsplit, MN, off);
-        s += *reinterpret_cast<const f32x4*>(a.b_dec + c);
-        *reinterpret_cast<f32x4*>(sdec + c) = s;
-        if (a.dec_ctx_out) *reinterpret_cast<f32x4*>(a.dec_ctx_out + off) = s;
-    }
-    __syncthreads();
-    const int img = a.img_of_row ? a.img_of_row[row] : row;
-    const float baff = a.b_aff[0];
-    const float sc = dc.mode ? 2.0f : 1.0f;
-    for (int r = wave; r < a.R; r += 8) {
-        const float* e = a.enc_ctx + ((size_t)img * a.R + r) * a.A;
-        float acc = 0.f;
-        for (int c0 = lane * 4; c0 < a.A; c0 += 1024) {
-            f32x4 x[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(e + min(c0 + 256 * u, a.A - 4));
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int c = c0 + 256 * u;
-                if (c < a.A) {
-                    f32x4 d = *reinterpret_cast<const f32x4*>(sdec + c);
-                    f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
-                    uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        float zv = fmaxf(x[u][j] + d[j], 0.f);
-                        zv = ((k >> j) & 1u) ? zv * sc : 0.f;
-                        acc += zv * w[j];
-                    }
-                }
-            }
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) sal[r] = acc + baff;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const float v = lane < a.R ? sal[lane] : -INFINITY;
-        const float mx = wave_max(v);
-        const float ex = lane < a.R ? expf(v - mx) : 0.f;
-        const float sum = wave_sum(ex);
-        const float al = ex / sum;
-        if (lane < a.R) {
-            if (a.scores) a.scores[(size_t)row * a.R + lane] = v;
-            alpha_out[(size_t)row * a.R + lane] = al;
-            if (alpha_out2) alpha_out2[(size_t)row * alpha2_stride + lane] = al;
-        }
-        __builtin_amdgcn_s_waitcnt(0);      // LDS read of sal above completes before it is overwritten
-        if (lane < a.R) sal[lane] = al;
-    }
-    __syncthreads();
-    const float* f = feats + (size_t)img * a.R * D;
-    for (int d = tid * 4; d < D; d += 2048) {
-        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        constexpr int RB = 9;                // 9 independent 16-byte loads in flight per thread
-        for (int r0 = 0; r0 < a.R; r0 += RB) {
-            f32x4 x[RB];
-#pragma unroll
-            for (int u = 0; u < RB; ++u) x[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r0 + u, a.R - 1) * D + d);
-#pragma unroll
-            for (int u = 0; u < RB; ++u)
-                if (r0 + u < a.R) acc += x[u] * sal[r0 + u];
-        }
-        *reinterpret_cast<f32x4*>(ctx + (size_t)row * D + d) = acc;
-    }
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -684,187 +643,182 @@ __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, Drop
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// SoftAttention backward, part 1:  dalpha[row,r] = dctx[row,:] . feats[img,r,:]   (one wave per (row, r))
-// dctx = sum of slabs [ns][rows][ldc] columns 0..D (the LM-LSTM dgrad GEMM output).
+// SoftAttention backward in three full-chip kernels (each moves its bytes once, with many loads in flight per lane):
+//   per step   att_bwd_dalpha_kernel   dalpha[row,r] = dctx[row,:] . feats[row,r,:]
+//   per step   att_bwd_ddec_kernel     ds = softmax'(alpha, dalpha);  ddec[row,a] = sum_r on(row,r,a) ds_r w_aff[a] scale
+//   once       att_bwd_denc_kernel     denc[row,r,a] = sum_t on_t ds_t w_aff scale;  dwaff partials   (after the time loop)
+// with zpre = enc_ctx[row,r,a] + dec_ctx_t[row,a] and on = zpre > 0 && keep-bit (relu + dropout).  enc_ctx is shared by all
+// time steps, so its gradient is a sum over t: accumulating it step by step would read-modify-write R*A floats per row
+// and step; instead the steps only record ds_t (R floats per row) and the sum over t is formed once, in registers.
+
+// dctx = sum of slabs [ns][rows][ldc] columns 0..D (the LM-LSTM dgrad GEMM output).  Grid (rows, parts), 256 threads.
 __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __restrict__ dctx, int ns, int ldc, int rows,
                                                              const float* __restrict__ feats, int R, int D,
                                                              float* __restrict__ dalpha) {
-    // grid (rows, parts): the workgroup first sums the split-K slabs of its row's dctx into LDS (once, instead of
-    // once per region), then each wave dots it with whole feature rows
     extern __shared__ __attribute__((aligned(16))) float sd[];      // D floats
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t ss = (size_t)rows * ldc;
     for (int c = tid * 4; c < D; c += 1024)
         *reinterpret_cast<f32x4*>(sd + c) = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
     __syncthreads();
-    for (int r = blockIdx.y * 4 + wave; r < R; r += 4 * gridDim.y) {
-        const float* f = feats + ((size_t)row * R + r) * D;
-        float acc = 0.f;
-        for (int c = lane * 4; c < D; c += 256) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
-            f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
-            acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
+    constexpr int NB = 2, NU = 8;          // 2 regions x 8 float4 per lane in flight
+    for (int i0 = wave; part + nparts * i0 < R; i0 += 4 * NB) {
+        int rr[NB];
+        bool ok[NB];
+        const float* f[NB];
+        float acc[NB];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int r = part + nparts * (i0 + 4 * b);
+            ok[b] = r < R;
+            rr[b] = ok[b] ? r : part + nparts * i0;
+            f[b] = feats + ((size_t)row * R + rr[b]) * D;
+            acc[b] = 0.f;
         }
-        acc = wave_sum(acc);
-        if (lane == 0) dalpha[(size_t)row * R + r] = acc;
+        for (int c0 = lane * 4; c0 < D; c0 += 256 * NU) {
+            f32x4 x[NB][NU];
+#pragma unroll
+            for (int b = 0; b < NB; ++b)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(f[b] + min(c0 + 256 * u, D - 4));
+#pragma unroll
+            for (int u = 0; u < NU; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < D) {
+                    const f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
+#pragma unroll
+                    for (int b = 0; b < NB; ++b) acc[b] += x[b][u][0] * g[0] + x[b][u][1] * g[1] + x[b][u][2] * g[2] + x[b][u][3] * g[3];
+                }
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const float v = wave_sum(acc[b]);
+            if (lane == 0 && ok[b]) dalpha[(size_t)row * R + rr[b]] = v;
+        }
     }
 }
 
-// SoftAttention backward, part 2 (grid (rows, parts)):
-//   ds_r = alpha_r (dalpha_r - sum_r' alpha_r' dalpha_r')                       softmax backward
-//   zpre = enc_ctx[row,r,a] + dec_ctx[row,a];  keep = dropout keep-bit
-//   dz   = (zpre > 0 && keep) ? ds_r * w_aff[a] * scale : 0                     relu + dropout + affine backward
-//   denc_acc[row,r,a] += dz                     (accumulated over time steps: enc_ctx is shared by all steps)
-//   ddec_part[part,row,a] = sum_{r in part} dz  (slabs over parts; summed by the consumer)
-//   dwaff_acc[row,part,a] += sum_{r in part} ds_r * relu(zpre)*keep*scale      (reduced over rows/parts at the end)
-struct AttBwdArgs {
-    const float* enc_ctx; const float* dec_ctx; const float* w_aff;
-    const float* alpha; const float* dalpha;
-    float* denc_acc; float* ddec_part; float* dwaff_acc;
-    int rows, R, A; int first;     // first != 0: dwaff_acc / denc_acc are overwritten instead of accumulated
+// Grid (rows, A/256), 256 threads: thread (wq = wave, cg) sums regions wq, wq+4, ... for 4 consecutive attention columns;
+// the four waves meet in LDS.  ds_out (block y = 0) keeps ds for att_bwd_denc_kernel.
+struct AttBwdDdecArgs {
+    const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha; const float* dalpha;
+    float* ddec; float* ds_out;
+    int R, A;
 };
-__global__ __launch_bounds__(256) void att_bwd_kernel(AttBwdArgs a, DropCfg dc) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];   // [4][A] dd partials, [4][A] dw partials
-    const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    // softmax backward scalars (every wave redundantly; R <= 64)
+__global__ __launch_bounds__(256) void att_bwd_ddec_kernel(AttBwdDdecArgs a, DropCfg dc) {
+    __shared__ float sds[64];
+    __shared__ __attribute__((aligned(16))) float spart[3 * 64 * 4];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
     const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
     const float da = lane < a.R ? a.dalpha[(size_t)row * a.R + lane] : 0.f;
     const float dot = wave_sum(al * da);
     const float ds_l = al * (da - dot);
-    float* sdd = sm + (size_t)wave * a.A;
-    float* sdw = sm + (size_t)(4 + wave) * a.A;
-    for (int c = lane * 4; c < a.A; c += 256) {
-        *reinterpret_cast<f32x4*>(sdd + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
-        *reinterpret_cast<f32x4*>(sdw + c) = (f32x4){0.f, 0.f, 0.f, 0.f};
-    }
-    const int per = (a.R + nparts - 1) / nparts;
-    const int r_end = min(a.R, (part + 1) * per);
-    const float sc = dc.mode ? 2.0f : 1.0f;
-    for (int r = part * per + wave; r < r_end; r += 4) {
-        const float ds = __shfl(ds_l, r, 64);
-        const size_t eoff = ((size_t)row * a.R + r) * a.A;
-        for (int c = lane * 4; c < a.A; c += 256) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(a.enc_ctx + eoff + c);
-            f32x4 d = *reinterpret_cast<const f32x4*>(a.dec_ctx + (size_t)row * a.A + c);
-            f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
-            uint32_t k = dc.mode ? dc.keep4(eoff + c) : 0xFu;
-            f32x4 dz, zz;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float zp = x[j] + d[j];
-                const bool on = (zp > 0.f) && ((k >> j) & 1u);
-                dz[j] = on ? ds * w[j] * sc : 0.f;
-                zz[j] = on ? zp * sc * ds : 0.f;
-            }
-            f32x4* de = reinterpret_cast<f32x4*>(a.denc_acc + eoff + c);
-            *de = a.first ? dz : (*de + dz);
-            *reinterpret_cast<f32x4*>(sdd + c) += dz;
-            *reinterpret_cast<f32x4*>(sdw + c) += zz;
-        }
+    if (tid < 64) {
+        sds[tid] = ds_l;
+        if (blockIdx.y == 0 && tid < a.R) a.ds_out[(size_t)row * a.R + tid] = ds_l;
     }
     __syncthreads();
-    for (int c = tid * 4; c < a.A; c += 1024) {
-        f32x4 dd = *reinterpret_cast<f32x4*>(sm + c);
-        f32x4 dw = *reinterpret_cast<f32x4*>(sm + (size_t)4 * a.A + c);
-#pragma unroll
-        for (int w = 1; w < 4; ++w) {
-            dd += *reinterpret_cast<f32x4*>(sm + (size_t)w * a.A + c);
-            dw += *reinterpret_cast<f32x4*>(sm + (size_t)(4 + w) * a.A + c);
-        }
-        *reinterpret_cast<f32x4*>(a.ddec_part + ((size_t)part * a.rows + row) * a.A + c) = dd;
-        f32x4* wa = reinterpret_cast<f32x4*>(a.dwaff_acc + ((size_t)row * nparts + part) * a.A + c);
-        *wa = a.first ? dw : (*wa + dw);
-    }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Fused SoftAttention backward, one 512-thread workgroup per decoder row (replaces dalpha + att_bwd + slab reduce):
-//   dctx    = sum_z slab[z,row,0:D]                                   -> LDS
-//   dalpha_r = dctx . feats[row,r,:]                                   8 waves walk the regions
-//   ds_r    = alpha_r (dalpha_r - sum_r' alpha_r' dalpha_r')           softmax backward
-//   per attention column a (each thread owns columns a, a+1 for ALL regions -> no cross-thread reduction):
-//     zpre = enc_ctx[row,r,a] + dec_ctx[row,a];  on = zpre > 0 && keep
-//     denc_acc[row,r,a] += on ? ds_r w_aff[a] scale : 0       (accumulated over time steps)
-//     ddec[row,a]        = sum_r of the same
-//     dwaff_acc[row,a]  += sum_r on ? ds_r zpre scale : 0     (reduced over rows at the end)
-struct AttBwdFusedArgs {
-    const float* dctx; int ns; int ldc; int rows;
-    const float* feats; const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha;
-    float* denc_acc; float* ddec; float* dwaff_acc;
-    int R, D, A;
-    int first;       // overwrite the accumulators instead of adding (first processed time step: no memset needed)
-};
-__global__ __launch_bounds__(512) void att_bwd_fused_kernel(AttBwdFusedArgs a, DropCfg dc) {
-    extern __shared__ __attribute__((aligned(16))) float sm_ab[];    // [D] dctx, [64] dalpha / ds
-    float* sd = sm_ab;
-    float* sds = sm_ab + a.D;
-    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const size_t ss = (size_t)a.rows * a.ldc;
-    for (int c = tid * 4; c < a.D; c += 2048)
-        *reinterpret_cast<f32x4*>(sd + c) = sum_slabs4(a.dctx, a.ns, ss, (size_t)row * a.ldc + c);
-    __syncthreads();
-    for (int r = wave; r < a.R; r += 8) {
-        const float* f = a.feats + ((size_t)row * a.R + r) * a.D;
-        float acc = 0.f;
-        for (int c = lane * 4; c < a.D; c += 256) {
-            f32x4 x = *reinterpret_cast<const f32x4*>(f + c);
-            f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
-            acc += x[0] * g[0] + x[1] * g[1] + x[2] * g[2] + x[3] * g[3];
-        }
-        acc = wave_sum(acc);
-        if (lane == 0) sds[r] = acc;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
-        const float da = lane < a.R ? sds[lane] : 0.f;
-        const float dot = wave_sum(al * da);
-        if (lane < a.R) sds[lane] = al * (da - dot);
-    }
-    __syncthreads();
-    const float sc = dc.mode ? 2.0f : 1.0f;
-    const float* __restrict__ encp = a.enc_ctx;
-    float* __restrict__ dencp = a.denc_acc;
-    for (int c = tid * 2; c < a.A; c += 1024) {
-        const float d0 = a.dec_ctx[(size_t)row * a.A + c], d1 = a.dec_ctx[(size_t)row * a.A + c + 1];
-        const float w0 = a.w_aff[c], w1 = a.w_aff[c + 1];
-        float dd0 = 0.f, dd1 = 0.f, dw0 = 0.f, dw1 = 0.f;
-        // regions in batches of 6: all loads of a batch are issued before any dependent store (the read-modify-write of
-        // denc_acc would otherwise serialise one memory round trip per region)
-        constexpr int RB = 6;
-        for (int r0 = 0; r0 < a.R; r0 += RB) {
-            float2 x[RB], o[RB];
+    const int c = blockIdx.y * 256 + lane * 4;
+    const bool valid = c < a.A;
+    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        const f32x4 d = *reinterpret_cast<const f32x4*>(a.dec_ctx + (size_t)row * a.A + c);
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+        const float sc = dc.mode ? 2.0f : 1.0f;
+        constexpr int RB = 9;
+        for (int r0 = wq; r0 < a.R; r0 += 4 * RB) {
+            f32x4 x[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-                const int r = min(r0 + u, a.R - 1);
-                const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
-                x[u] = *reinterpret_cast<const float2*>(encp + eoff);
-                o[u] = a.first ? make_float2(0.f, 0.f) : *reinterpret_cast<const float2*>(dencp + eoff);
+                const int r = min(r0 + 4 * u, a.R - 1);
+                x[u] = *reinterpret_cast<const f32x4*>(a.enc_ctx + ((size_t)row * a.R + r) * a.A + c);
             }
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
-                const int r = r0 + u;
+                const int r = r0 + 4 * u;
                 if (r < a.R) {
                     const float ds = sds[r];
-                    const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
-                    uint32_t k = 0x3u;
-                    if (dc.mode) k = (dc.keep4(eoff & ~(size_t)3) >> (eoff & 2)) & 0x3u;
-                    const float z0 = x[u].x + d0, z1 = x[u].y + d1;
-                    const bool on0 = (z0 > 0.f) && (k & 1u), on1 = (z1 > 0.f) && (k & 2u);
-                    const float g0 = on0 ? ds * w0 * sc : 0.f, g1 = on1 ? ds * w1 * sc : 0.f;
-                    *reinterpret_cast<float2*>(dencp + eoff) = make_float2(o[u].x + g0, o[u].y + g1);
-                    dd0 += g0; dd1 += g1;
-                    dw0 += on0 ? z0 * sc * ds : 0.f;
-                    dw1 += on1 ? z1 * sc * ds : 0.f;
+                    const uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool on = (x[u][j] + d[j] > 0.f) && ((k >> j) & 1u);
+                        acc[j] += on ? ds * w[j] * sc : 0.f;
+                    }
                 }
             }
         }
-        *reinterpret_cast<float2*>(a.ddec + (size_t)row * a.A + c) = make_float2(dd0, dd1);
-        float2* wa = reinterpret_cast<float2*>(a.dwaff_acc + (size_t)row * a.A + c);
-        float2 ow = a.first ? make_float2(0.f, 0.f) : *wa;
-        ow.x += dw0; ow.y += dw1;
-        *wa = ow;
+    }
+    if (wq > 0) *reinterpret_cast<f32x4*>(spart + ((wq - 1) * 64 + lane) * 4) = acc;
+    __syncthreads();
+    if (wq == 0 && valid) {
+#pragma unroll
+        for (int w = 0; w < 3; ++w) acc += *reinterpret_cast<const f32x4*>(spart + (w * 64 + lane) * 4);
+        *reinterpret_cast<f32x4*>(a.ddec + (size_t)row * a.A + c) = acc;
+    }
+}
+
+// Grid (B, parts), 256 threads.  Part p owns regions p, p + parts, ...; a thread owns 4 consecutive attention columns,
+// keeps dec_ctx_t of up to TT time steps in registers and walks its regions: one read of enc_ctx, one write of denc.
+//   denc[row,r,a]          = sum_t on_t ds_t[row,r] w_aff[a] scale
+//   dwaff_part[row,p,a]    = sum_{r in p} sum_t on_t ds_t[row,r] zpre scale        (column-summed over rows x parts afterwards)
+struct AttBwdDencArgs {
+    const float* enc_ctx; const float* dec_all; const float* ds_all; const float* w_aff;
+    float* denc; float* dwaff_part;
+    int B, R, A, T;
+    int mode; const uint8_t* mask; size_t mask_step; const uint64_t* seed_p; uint32_t stream;
+};
+template <int TT>
+__global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sds_t[];     // [T][R] ds of this row
+    const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, tid = threadIdx.x;
+    for (int i = tid; i < a.T * a.R; i += 256) {
+        const int t = i / a.R, r = i % a.R;
+        sds_t[i] = a.ds_all[((size_t)t * a.B + row) * a.R + r];
+    }
+    __syncthreads();
+    const float sc = a.mode ? 2.0f : 1.0f;
+    for (int c = tid * 4; c < a.A; c += 1024) {
+        const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+        f32x4 dw = {0.f, 0.f, 0.f, 0.f};
+        for (int t0 = 0; t0 < a.T; t0 += TT) {
+            f32x4 d[TT];
+#pragma unroll
+            for (int j = 0; j < TT; ++j) {
+                const int t = min(t0 + j, a.T - 1);
+                d[j] = *reinterpret_cast<const f32x4*>(a.dec_all + ((size_t)t * a.B + row) * a.A + c);
+            }
+            for (int r = part; r < a.R; r += nparts) {
+                const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
+                const f32x4 x = *reinterpret_cast<const f32x4*>(a.enc_ctx + eoff);
+                f32x4 de = {0.f, 0.f, 0.f, 0.f};
+                if (t0 > 0) de = *reinterpret_cast<const f32x4*>(a.denc + eoff);
+#pragma unroll
+                for (int j = 0; j < TT; ++j) {
+                    const int t = t0 + j;
+                    if (t < a.T) {
+                        const float ds = sds_t[t * a.R + r];
+                        uint32_t k = 0xFu;
+                        if (a.mode == 1) {
+                            const uint32_t m = *reinterpret_cast<const uint32_t*>(a.mask + (size_t)t * a.mask_step + eoff);
+                            k = ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) | ((m & 0xFF000000u) ? 8u : 0u);
+                        } else if (a.mode == 2) {
+                            k = (rng_group_bits(*a.seed_p, a.stream, (uint32_t)t, eoff) >> (eoff & 31)) & 0xFu;
+                        }
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float zp = x[q] + d[j][q];
+                            const bool on = (zp > 0.f) && ((k >> q) & 1u);
+                            de[q] += on ? ds * w[q] * sc : 0.f;
+                            dw[q] += on ? zp * sc * ds : 0.f;
+                        }
+                    }
+                }
+                *reinterpret_cast<f32x4*>(a.denc + eoff) = de;
+            }
+        }
+        *reinterpret_cast<f32x4*>(a.dwaff_part + ((size_t)row * nparts + part) * a.A + c) = dw;
     }
 }
 

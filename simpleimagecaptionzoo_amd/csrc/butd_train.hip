@@ -58,6 +58,7 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dwaff, sizeof(float) * (size_t)B * ATT_PARTS * A));
     ICZ_TRY(zalloc((void**)&tb.ddec_part, sizeof(float) * (size_t)B * ATT_PARTS * A));
     ICZ_TRY(zalloc((void**)&tb.dalpha, sizeof(float) * (size_t)B * R));
+    ICZ_TRY(zalloc((void**)&tb.dS, sizeof(float) * TB * R));
     ICZ_TRY(zalloc((void**)&tb.dGsum, sizeof(float) * (size_t)B * 4 * H));
     for (int i = 0; i < 2; ++i) {
         ICZ_TRY(zalloc((void**)&tb.dc1[i], sizeof(float) * (size_t)B * H));
@@ -462,8 +463,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dGtd, 0, sizeof(float) * (size_t)TB * 4 * H, st));
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dGlm, 0, sizeof(float) * (size_t)TB * 4 * H, st));
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dDec, 0, sizeof(float) * (size_t)TB * A, st));
-        ICZ_CHECK_HIP(hipMemsetAsync(tb.dEnc, 0, sizeof(float) * (size_t)B * R * A, st));
-        ICZ_CHECK_HIP(hipMemsetAsync(tb.dwaff, 0, sizeof(float) * (size_t)B * ATT_PARTS * A, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tb.dS, 0, sizeof(float) * (size_t)TB * R, st));
     }
 
     // ---- reverse-time loop
@@ -495,9 +495,10 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
         }
         {   // attention backward
-            AttBwdFusedArgs fa = {tb.X[0], ns1, D + H, bt, feats, enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R,
-                                  tb.dEnc, tb.dDec + slot * A, tb.dwaff, R, D, A, (!ragged && t == T - 1) ? 1 : 0};
-            hipLaunchKernelGGL(att_bwd_fused_kernel, dim3(bt), dim3(512), sizeof(float) * (D + 64), st, fa, d_att);
+            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, ATT_PARTS), dim3(256), sizeof(float) * D, st, tb.X[0], ns1, D + H, bt, feats, R, D,
+                               tb.dalpha);
+            AttBwdDdecArgs da = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dDec + slot * A, tb.dS + slot * R, R, A};
+            hipLaunchKernelGGL(att_bwd_ddec_kernel, dim3(bt, cdiv(A, 256)), dim3(256), 0, st, da, d_att);
             // X2 = dDec . w_dec   [bt, H]
             GemmArgs g = {};
             g.nseg = 1;
@@ -565,6 +566,11 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st));         // h1_t
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
+    {   // d enc_ctx (sum over time) and the affine-weight partials, from the ds_t recorded by the loop
+        AttBwdDencArgs ea = {enc_ctx, tb.dec, tb.dS, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
+                             cur_train ? (rng.att_mask ? 1 : 2) : 0, rng.att_mask, (size_t)B * R * A, d_seed, (uint32_t)RNG_ATT};
+        hipLaunchKernelGGL(att_bwd_denc_kernel<20>, dim3(B, ATT_PARTS), dim3(256), sizeof(float) * T * R, st, ea);
+    }
     ICZ_TRY(wgrad(tb.dEnc, A, A, feats, D, D, B * R, tb.dWenc, D, st));
     ICZ_TRY(colsum(tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih, st));
     ICZ_TRY(colsum(tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih, st));
@@ -572,7 +578,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lm_b_hh, G.lm_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
     ICZ_TRY(colsum(tb.dDec, TB, A, A, G.dec_att_b, st));
     ICZ_TRY(colsum(tb.dEnc, B * R, A, A, G.enc_att_b, st));
-    ICZ_TRY(colsum(tb.dwaff, B, A, A, tb.dWaff, st));
+    ICZ_TRY(colsum(tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff, st));
     // d loss / d affine.bias is identically zero (softmax shift invariance)
     ICZ_CHECK_HIP(hipMemsetAsync(G.affine_b, 0, sizeof(float), st));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc,

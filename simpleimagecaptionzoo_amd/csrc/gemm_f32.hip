@@ -79,9 +79,10 @@ __device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
 // overhead (barrier, waits, address arithmetic) per MFMA.
 // Rows beyond M / columns beyond N are read from a clamped (valid) row: they only feed accumulator rows /
 // columns that are never stored, so no zero-fill is needed; only the K tail must be zero (TAIL variant).
-template <int MT, int NTW, bool TAIL, int BKC>
-__global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
-    constexpr int BN = 64 * NTW;
+template <int MT, int NTW, bool TAIL, int BKC, int NW = 4>
+__global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
+    constexpr int BN = 16 * NW * NTW;
+    constexpr int NTHR = 64 * NW;
     constexpr int LDSS = BKC + 8;                 // dwords per staged A row; (LDSS/4) mod 16 == 2 -> conflict-free b128 reads
     constexpr int NS = BKC / 16;                  // k-groups (of 16) per stage
     __shared__ __attribute__((aligned(16))) float lds[2][MT * 16 * LDSS];
@@ -110,13 +111,13 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
         for (int nt = 0; nt < NTW; ++nt) acc[t][nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
     constexpr int C4 = BKC / 4;                              // float4 per staged row
-    constexpr int XL = (MT * 16 * C4 + 255) / 256;           // float4 staging loads per thread per stage
+    constexpr int XL = (MT * 16 * C4 + NTHR - 1) / NTHR;           // float4 staging loads per thread per stage
     f32x4 xr[XL];
     size_t xrow[XL];
     int xlds[XL], xkk[XL];
 #pragma unroll
     for (int j = 0; j < XL; ++j) {
-        const int idx = tid + 256 * j;
+        const int idx = tid + NTHR * j;
         int row = idx / C4;
         if (row > MT * 16 - 1) row = MT * 16 - 1;
         int m = m0 + row;
@@ -189,7 +190,7 @@ __global__ __launch_bounds__(256) void gemm_nt_kernel(GemmArgs a) {
     auto store_stage = [&](int buf) {
 #pragma unroll
         for (int j = 0; j < XL; ++j)
-            if ((MT * 16 * C4) % 256 == 0 || tid + 256 * j < MT * 16 * C4)
+            if ((MT * 16 * C4) % NTHR == 0 || tid + NTHR * j < MT * 16 * C4)
                 *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
     };
     // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer)
@@ -492,10 +493,15 @@ static int nt_stage_k(const GemmArgs& a) {
 static int stage_k(GemmLayout layout, const GemmArgs& a) { return layout == GEMM_NT ? nt_stage_k(a) : GEMM_BK; }
 
 // NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
-static int nt_tile_n(const GemmArgs& a) {
-    if (a.M <= 32) return 64;
-    return 64;   // the 64x128 tile needs 336 VGPRs with the 3-deep W ring (1 wave per SIMD) and measured slower
+static int nt_waves(const GemmArgs& a) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ICZ_GEMM_NW"); force = e ? atoi(e) : 0; }
+    if (force != 8) return 4;
+    if (a.M <= 32 || a.N < 1024 || nt_stage_k(a) != 128) return 4;
+    return 8;
 }
+// NT column-tile width: 16 columns per wave; 8-wave workgroups (two waves per SIMD sharing one staged A chunk) -> 128
+static int nt_tile_n(const GemmArgs& a) { return 16 * nt_waves(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
@@ -570,6 +576,9 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
                                     else hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, false, BK_>), grid, block, 0, stream, a); } while (0)
         if (mt == 1) ICZ_NT(1, 1, 64);
         else if (mt == 2) ICZ_NT(2, 1, 64);
+        else if (nt_stage_k(a) == 128 && nt_waves(a) == 8) {
+            hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 8>), grid, dim3(512), 0, stream, a);
+        }
         else if (nt_stage_k(a) == 128) ICZ_NT(4, 1, 128);
         else ICZ_NT(4, 1, 64);
 #undef ICZ_NT
