@@ -129,3 +129,27 @@ def captions_json(ids, image_ids, ix2word):
                 ws.append(word)
         out.append({"image_id": int(image_ids[b]), "caption": " ".join(ws)})
     return out
+
+
+def corpus_document_frequency(gts, n=4):
+    """compute_doc_freq(), coco_caption/pycocoevalcap/cider/cider_scorer.py:96-107: df[ngram] = number of images whose
+    references contain it."""
+    df = {}
+    for refs in gts.values():
+        seen = set()
+        for ref in refs:
+            seen.update(ngram_counts(ref.split(), n).keys())
+        for g in seen:
+            df[g] = df.get(g, 0.0) + 1.0
+    return df
+
+
+def corpus_cider(gts, res, n=4, sigma=6.0):
+    """Cider.compute_score(gts, res), cider.py:34-56 -> CiderScorer.compute_score, cider_scorer.py:185-195: the corpus
+    CIDEr of the evaluation path (eval.py:52-66).  df and log(ref_len) come from the evaluated references themselves
+    (cider_scorer.py:164); the per-image formula is the one of `ciderd_scores`.  Returns (mean, per-image scores)."""
+    ids = list(gts.keys())
+    assert list(res.keys()) == ids
+    docfreq = DocFreq(corpus_document_frequency(gts, n), len(ids))
+    scores = ciderd_scores([res[i][0] for i in ids], [gts[i] for i in ids], docfreq, n, sigma)
+    return float(np.mean(scores)), scores

@@ -671,6 +671,50 @@ def gen_cider(tag, seed):
 
 
 # ------------------------------------------------------------------------------------------------
+def gen_corpus_cider(tag, seed):
+    """Corpus-level CIDEr of the evaluation path (coco_caption/pycocoevalcap/cider/cider.py:34-56 ->
+    cider_scorer.py:96-195; called by COCOEvalCap.evaluate, eval.py:24-69): df and log(ref_len) come from the evaluated
+    references themselves.  Inputs are already tokenised strings (the Java PTB tokeniser is not runnable here)."""
+    from coco_caption.pycocoevalcap.cider.cider import Cider
+    rng = np.random.RandomState(seed)
+    words = ["w%d" % i for i in range(60)]
+    cases = {}
+    # synthetic corpus: Zipf references with OOV words, hypotheses of every length 0..20, duplicates, copies of references
+    gts = synth_refs(rng, words, 40)
+    res = {}
+    for i in range(40):
+        L = i % 21
+        z = np.minimum(rng.zipf(1.3, size=L), len(words)) - 1
+        res[i] = [" ".join(words[j] for j in z)]
+    res[3] = [gts[3][0]]
+    res[4] = [gts[4][1] + " " + gts[4][1]]
+    res[5] = ["never seen words here"]
+    cases["synthetic"] = (gts, res)
+    # one image only: log(ref_len) = 0 and every idf is 0
+    cases["single"] = ({7: ["w1 w2 w3 w4", "w2 w3 w4 w5"]}, {7: ["w1 w2 w3 w4"]})
+    # realistic sentences (abstract48S references / candidates, lower-cased, whitespace tokens), first 80 images with candidates
+    refs = json.load(open(os.path.join(REF, "cider/data/abstract48S.json")))
+    cands = json.load(open(os.path.join(REF, "cider/data/abstract_candsB.json")))
+    g2 = defaultdict(list)
+    for r in refs:
+        g2[r["image_id"]].append(r["caption"].lower())
+    r2 = {}
+    for c in cands:
+        if c["image_id"] in g2 and c["image_id"] not in r2 and len(r2) < 80:
+            r2[c["image_id"]] = [c["caption"].lower()]
+    cases["abstract80"] = ({k: g2[k][:5] for k in r2}, r2)
+    fx = {}
+    for name, (g, r) in cases.items():
+        score, scores = Cider().compute_score(g, r)
+        fx[name] = {"ids": [str(k) for k in g.keys()], "gts": {str(k): v for k, v in g.items()},
+                    "res": {str(k): v for k, v in r.items()}, "score": float(score).hex(),
+                    "scores": [float(x).hex() for x in scores]}
+        print(tag, name, "CIDEr %.4f over %d images" % (score, len(g)))
+    with open(os.path.join(OUT, tag + ".json"), "w") as f:
+        json.dump(fx, f)
+    print("wrote", tag + ".json", "%.1f KB" % (os.path.getsize(os.path.join(OUT, tag + ".json")) / 1024))
+
+
 def gen_engine(tag, seed, B=6, V=53, H=16, E=16, A=16):
     """Engine-level goldens for BUTDDetection_Eng (D is fixed at 2048 by BUTD_Model.py:449):
     E1 training_epoch (2 steps), E2 SCST_training_epoch (2 steps), E3 eval_captions_json_generation
@@ -846,7 +890,7 @@ def gen_engine(tag, seed, B=6, V=53, H=16, E=16, A=16):
 if __name__ == "__main__":
     bootstrap()
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["butd", "nic", "aoa", "cider", "engine"]
+    which = sys.argv[1:] or ["butd", "nic", "aoa", "cider", "corpus", "engine"]
     if "butd" in which:
         gen_butd_decoder("butd_dec_tiny", B=5, R=36, D=64, H=32, E=32, A=32, V=53, seed=11)
         gen_butd_decoder("butd_dec_odd", B=3, R=36, D=96, H=48, E=16, A=64, V=70, seed=12)
@@ -857,5 +901,7 @@ if __name__ == "__main__":
         gen_aoa("aoa_tiny", B=4, Hd=32, E=16, V=53, seed=41)
     if "cider" in which:
         gen_cider("ciderd_cases", seed=5)
+    if "corpus" in which:
+        gen_corpus_cider("corpus_cider_cases", seed=7)
     if "engine" in which:
         gen_engine("butd_engine_tiny", seed=21)

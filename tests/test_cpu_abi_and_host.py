@@ -117,3 +117,19 @@ def test_synthetic_generators_are_deterministic():
     p1 = random_butd_params(36, 32, 16, 16, 16, 50, "cpu", seed=1)
     p2 = random_butd_params(36, 32, 16, 16, 16, 50, "cpu", seed=1)
     assert all(torch.equal(p1[k], p2[k]) for k in p1)
+
+
+def test_ptb_lite_tokenizer_and_annotation_loader(tmp_path):
+    import json
+    from simpleimagecaptionzoo_amd.coco_eval import load_annotations, ptb_lite_tokenize, tokenize
+    assert ptb_lite_tokenize("A man riding a wave on top of a surfboard.") == "a man riding a wave on top of a surfboard"
+    assert ptb_lite_tokenize("Two dogs, one black; one white -- can't sit!") == "two dogs one black one white ca n't sit"
+    assert ptb_lite_tokenize("The dog's toy isn't here... it's the cats' toy") == "the dog 's toy is n't here it 's the cats toy"
+    assert ptb_lite_tokenize('He said "hello" (twice) at 3 o\'clock.') == "he said hello -lrb- twice -rrb- at 3 o'clock"
+    assert ptb_lite_tokenize("") == "" and ptb_lite_tokenize(" . ") == ""
+    ann = {"annotations": [{"image_id": 7, "caption": "A cat."}, {"image_id": 9, "caption": "Dogs!"}, {"image_id": 7, "caption": "Cat sits"}]}
+    p = tmp_path / "ann.json"
+    p.write_text(json.dumps(ann))
+    got = load_annotations(str(p))
+    assert list(got.keys()) == [7, 9] and [c["caption"] for c in got[7]] == ["A cat.", "Cat sits"]
+    assert tokenize(got) == {7: ["a cat", "cat sits"], 9: ["dogs"]}

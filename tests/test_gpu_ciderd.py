@@ -69,3 +69,37 @@ def test_self_critical_reward_matches_reference(golden_dir):
         ids = [int(i) for i in g[pre + "img_ids"]]
         r = scorer.reward(torch.tensor(g[pre + "seq"]), torch.tensor(g[pre + "greedy_ids"]), gts, ids)
         assert np.array_equal(r.cpu().numpy(), g[pre + "reward"])
+
+
+def test_corpus_cider_device_scorer_bit_exact(golden_dir):
+    """coco_eval's CIDEr (cider.py:34-56 / cider_scorer.py:96-195) on the device vs the reference scorer's output."""
+    import json
+    from simpleimagecaptionzoo_amd.coco_eval import Cider
+    fx = json.load(open(os.path.join(golden_dir, "corpus_cider_cases.json")))
+    for name, c in fx.items():
+        gts = {k: c["gts"][k] for k in c["ids"]}
+        res = {k: c["res"][k] for k in c["ids"]}
+        score, scores = Cider().compute_score(gts, res)
+        assert [float(x) for x in scores] == [float.fromhex(x) for x in c["scores"]], name
+        assert score == float.fromhex(c["score"]), name
+
+
+def test_coco_eval_end_to_end(tmp_path):
+    """results json + annotation file -> tokenise -> device CIDEr; equals the oracle on the same tokenised strings."""
+    import json
+    from oracle.ciderd import corpus_cider
+    from simpleimagecaptionzoo_amd.coco_eval import coco_eval, load_annotations, tokenize
+    anns = {"annotations": []}
+    caps = {11: ["A man rides a horse.", "A person on a horse, outside.", "Man riding a brown horse"],
+            12: ["Two dogs play in the snow!", "Dogs playing; it's snowing.", "a couple of dogs in snow"],
+            13: ["A plate of food.", "Food on a white plate", "some food"]}
+    for i, cs in caps.items():
+        anns["annotations"] += [{"image_id": i, "caption": c} for c in cs]
+    p = tmp_path / "captions_val.json"
+    p.write_text(json.dumps(anns))
+    results = [{"image_id": 11, "caption": "a man riding a horse"}, {"image_id": 12, "caption": "two dogs in the snow"},
+               {"image_id": 13, "caption": "a plate"}]
+    got = coco_eval(results, str(p))
+    gts = tokenize(load_annotations(str(p)))
+    want, _ = corpus_cider({i: gts[i] for i in (11, 12, 13)}, {r["image_id"]: [r["caption"]] for r in results})
+    assert got == want and got > 0

@@ -354,3 +354,16 @@ def test_aoa_xe_and_rl_decoder_grads(aoa):
     for k, v in p.items():
         if k.startswith("decoder."):
             np.testing.assert_allclose(v.grad.numpy(), g["rl_grad." + k[8:]], atol=2e-6, rtol=1e-4, err_msg=k)
+
+
+def test_corpus_cider_oracle_matches_reference_scorer(golden_dir):
+    """Evaluation-path CIDEr (cider_scorer.py:96-195, df from the evaluated references): bit-exact in float64."""
+    import json
+    from oracle.ciderd import corpus_cider
+    fx = json.load(open(os.path.join(golden_dir, "corpus_cider_cases.json")))
+    for name, c in fx.items():
+        gts = {k: c["gts"][k] for k in c["ids"]}
+        res = {k: c["res"][k] for k in c["ids"]}
+        score, scores = corpus_cider(gts, res)
+        assert score == float.fromhex(c["score"]), name
+        assert [float(x) for x in scores] == [float.fromhex(x) for x in c["scores"]], name
