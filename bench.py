@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE config: 64)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive extra measurement")
     ap.add_argument("--cpu-rows", type=int, default=64)
     args = ap.parse_args()
 
@@ -145,6 +146,28 @@ def main():
         run(3)
         torch.cuda.synchronize()
         lib().icz_prof_end(C.byref(avg_us), C.byref(bpl), C.byref(fpl), C.byref(nl))
+    # PCIe-inclusive variant (never `value`): the same steps with the features starting in host memory, as the reference
+    # boundary hands them over (BUTD_Engine.py:45), streamed through the pinned double-buffered prefetcher
+    pcie = None
+    if rank == 0 and world == 1 and not args.no_h2d:
+        from simpleimagecaptionzoo_amd.features import DevicePrefetcher
+        eng.use_graphs = True
+        eng._hot_handle().set_concurrent(True)
+        host = []
+        for ids, _, gts, supp in batches:
+            f = supp["bu_feats"].cpu().numpy()
+            host.append((ids, None, gts, tuple({"bu_feat": f[j], "bu_bbox": None} for j in range(f.shape[0]))))
+
+        def run_h2d(n):
+            eng.SCST_training_epoch(DevicePrefetcher([host[i % n_distinct] for i in range(n)], device), opt, None, tqdm_visible=False)
+        run_h2d(4)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        run_h2d(args.steps)
+        torch.cuda.synchronize()
+        dth = time.perf_counter() - t1
+        pcie = {"value": B * args.steps / dth, "unit": "captions/s", "ms_per_step": dth / args.steps * 1e3,
+                "note": "features start in host memory: gather into pinned buffers + async H2D (18.9 MB per batch) overlapped with the previous step"}
     if world > 1:
         tt = torch.tensor([dt], dtype=torch.float64, device=device)
         torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
@@ -178,6 +201,8 @@ def main():
                      "measured": "HIP event pair around every launch; eager single-stream re-run of the same steps right after the timed region",
                      "mfma_f32_tflops": ach_tf, "mfma_f32_frac": ach_tf / MFMA_F32_PEAK_TFLOPS},
     }
+    if pcie:
+        out["pcie_inclusive"] = pcie
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(words, args.cpu_rows)
     print(json.dumps(out))

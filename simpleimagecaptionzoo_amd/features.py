@@ -1,0 +1,139 @@
+"""Feature input pipeline for the bottom-up models.
+
+The reference reads one zlib-compressed `.npz` per image and sample (`Datasets.py:54-62,101,139`:
+`np.load('<supp_dir>/fixed_bu_feat/<img_id>.npz')['feat']`, (36, 2048) fp32) and copies the stacked batch from pageable
+memory (`BUTD_Engine.py:45`).  At several thousand captions/s per GPU that costs more than the decode itself, so the
+features are packed once into one flat, memory-mapped fp32 file and streamed to the GPU from pinned double buffers:
+
+  pack_npz_dir()        per-image .npz (+ .npy boxes)  ->  <name>.feats.npy ([N, R, D] fp32, uncompressed) + <name>.index.json
+  PackedFeatureStore    memory-mapped rows by image id (no decompression, no per-file open)
+  DevicePrefetcher      wraps any iterable of the reference's batch tuples: batch i+1 is gathered into a pinned buffer and
+                        copied on a side stream while batch i is being decoded; it yields the same tuples with
+                        `supp_info_datas` replaced by {'bu_feats': device tensor, 'bu_bboxes': [...]}, which the Engines'
+                        `modify_visual_inputs` passes through unchanged.
+The bytes are the reference's (fp32, no re-quantisation), so results do not change.  Fixed 36-region features only.
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+
+def pack_npz_dir(supp_dir, img_ids, out_prefix, kind="fixed"):
+    """Pack `<supp_dir>/<kind>_bu_feat/<id>.npz['feat']` (and `<kind>_bu_bbox/<id>.npy`) of `img_ids` into
+    `<out_prefix>.feats.npy`, `<out_prefix>.boxes.npy`, `<out_prefix>.index.json`.  All images must have the same (R, D)."""
+    img_ids = list(img_ids)
+    first = np.load(os.path.join(supp_dir, "%s_bu_feat/%s.npz" % (kind, img_ids[0])))["feat"]
+    R, D = first.shape
+    feats = np.lib.format.open_memmap(out_prefix + ".feats.npy", mode="w+", dtype=np.float32, shape=(len(img_ids), R, D))
+    boxes = np.zeros((len(img_ids), R, 4), dtype=np.float32)
+    for n, i in enumerate(img_ids):
+        f = np.load(os.path.join(supp_dir, "%s_bu_feat/%s.npz" % (kind, i)))["feat"]
+        if f.shape != (R, D):
+            raise ValueError("image %s has %s features, expected %s: only fixed-size feature sets can be packed" % (i, f.shape, (R, D)))
+        feats[n] = f
+        bpath = os.path.join(supp_dir, "%s_bu_bbox/%s.npy" % (kind, i))
+        if os.path.exists(bpath):
+            boxes[n] = np.load(bpath)
+    feats.flush()
+    del feats
+    np.save(out_prefix + ".boxes.npy", boxes)
+    with open(out_prefix + ".index.json", "w") as fh:
+        json.dump({"ids": [str(i) for i in img_ids], "R": int(R), "D": int(D)}, fh)
+    return out_prefix
+
+
+class PackedFeatureStore:
+    """Read side of pack_npz_dir(): `store[img_id]` -> {'bu_feat': (R, D) fp32 view, 'bu_bbox': (R, 4)} -- the dict the
+    reference's datasets put into `supp_info_data` (Datasets.py:54-58)."""
+
+    def __init__(self, prefix):
+        meta = json.load(open(prefix + ".index.json"))
+        self.R, self.D = meta["R"], meta["D"]
+        self.row = {k: n for n, k in enumerate(meta["ids"])}
+        self.feats = np.load(prefix + ".feats.npy", mmap_mode="r")
+        self.boxes = np.load(prefix + ".boxes.npy", mmap_mode="r")
+
+    def __len__(self):
+        return len(self.row)
+
+    def __contains__(self, img_id):
+        return str(img_id) in self.row
+
+    def __getitem__(self, img_id):
+        n = self.row[str(img_id)]
+        return {"bu_feat": self.feats[n], "bu_bbox": self.boxes[n]}
+
+    def gather_into(self, img_ids, out):
+        """out[j] = features of img_ids[j] (out: (B, R, D) fp32 numpy view of a pinned buffer)."""
+        for j, i in enumerate(img_ids):
+            out[j] = self.feats[self.row[str(i)]]
+
+
+class DevicePrefetcher:
+    """Iterate `loader` (batch tuples of Datasets.py:153-175: img_ids first, supp_info_datas last) one batch ahead of the
+    consumer.  Features come from `store` (by image id) or, without a store, from the tuples' own supp_info_datas."""
+
+    def __init__(self, loader, device="cuda:0", store=None, depth=2):
+        self.loader, self.store = loader, store
+        self.device = torch.device(device)
+        self.depth = max(2, int(depth))
+        self.copy_stream = torch.cuda.Stream(device=self.device)
+        self._pinned, self._dev, self._ready, self._free = [None] * self.depth, [None] * self.depth, [None] * self.depth, [None] * self.depth
+
+    def _stage(self, slot, batch):
+        img_ids, supp = batch[0], batch[-1]
+        if self.store is not None:
+            B, R, D = len(img_ids), self.store.R, self.store.D
+        else:
+            B, (R, D) = len(supp), supp[0]["bu_feat"].shape
+        if self._pinned[slot] is None or self._pinned[slot].shape[0] < B or tuple(self._pinned[slot].shape[1:]) != (R, D):
+            self._pinned[slot] = torch.empty(B, R, D, dtype=torch.float32).pin_memory()
+            self._dev[slot] = torch.empty(B, R, D, dtype=torch.float32, device=self.device)
+            self._free[slot] = None
+        if self._free[slot] is not None:
+            self._free[slot].synchronize()          # the consumer is done with this slot's device buffer
+        host = self._pinned[slot][:B].numpy()
+        if self.store is not None:
+            self.store.gather_into(img_ids, host)
+            boxes = [self.store[i]["bu_bbox"] for i in img_ids]
+        else:
+            for j, s in enumerate(supp):
+                if s["bu_feat"].shape != (R, D):
+                    raise NotImplementedError("adaptive (variable-size) feature sets are outside the packed pipeline")
+                host[j] = s["bu_feat"]
+            boxes = [s["bu_bbox"] for s in supp]
+        with torch.cuda.stream(self.copy_stream):
+            self._dev[slot][:B].copy_(self._pinned[slot][:B], non_blocking=True)
+            ev = torch.cuda.Event()
+            ev.record(self.copy_stream)
+        self._ready[slot] = ev
+        return batch[:-1] + ({"bu_feats": self._dev[slot][:B], "bu_bboxes": boxes},)
+
+    def __iter__(self):
+        it = iter(self.loader)
+        queue = []
+        slot = 0
+        try:
+            for _ in range(self.depth - 1):
+                queue.append((slot, self._stage(slot, next(it))))
+                slot = (slot + 1) % self.depth
+        except StopIteration:
+            pass
+        while queue:
+            cur_slot, out = queue.pop(0)
+            try:
+                queue.append((slot, self._stage(slot, next(it))))
+                slot = (slot + 1) % self.depth
+            except StopIteration:
+                pass
+            torch.cuda.current_stream(self.device).wait_event(self._ready[cur_slot])
+            yield out
+            # everything the consumer queued on its stream so far must finish before the slot is overwritten
+            done = torch.cuda.Event()
+            done.record(torch.cuda.current_stream(self.device))
+            self._free[cur_slot] = done
+
+    def __len__(self):
+        return len(self.loader)

@@ -133,3 +133,34 @@ def test_ptb_lite_tokenizer_and_annotation_loader(tmp_path):
     got = load_annotations(str(p))
     assert list(got.keys()) == [7, 9] and [c["caption"] for c in got[7]] == ["A cat.", "Cat sits"]
     assert tokenize(got) == {7: ["a cat", "cat sits"], 9: ["dogs"]}
+
+
+def _write_ref_feature_files(root, ids, R=36, D=64, seed=0):
+    """The on-disk layout of PreProcess/Generate_coco14_bottom_up_features_data.py:56-58 that Datasets.py:54-58 reads."""
+    import numpy as np
+    rng = np.random.RandomState(seed)
+    os.makedirs(os.path.join(root, "fixed_bu_feat"))
+    os.makedirs(os.path.join(root, "fixed_bu_bbox"))
+    data = {}
+    for i in ids:
+        f = rng.rand(R, D).astype(np.float32)
+        b = rng.rand(R, 4).astype(np.float32)
+        np.savez_compressed(os.path.join(root, "fixed_bu_feat", "%s.npz" % i), feat=f)
+        np.save(os.path.join(root, "fixed_bu_bbox", "%s.npy" % i), b)
+        data[i] = (f, b)
+    return data
+
+
+def test_packed_feature_store_roundtrip(tmp_path):
+    import numpy as np
+    from simpleimagecaptionzoo_amd.features import PackedFeatureStore, pack_npz_dir
+    ids = [391895, 522418, 184613, 318219]
+    data = _write_ref_feature_files(str(tmp_path / "supp"), ids)
+    prefix = pack_npz_dir(str(tmp_path / "supp"), ids, str(tmp_path / "packed"))
+    store = PackedFeatureStore(prefix)
+    assert len(store) == 4 and 522418 in store and 1 not in store and (store.R, store.D) == (36, 64)
+    for i in ids:
+        assert np.array_equal(store[i]["bu_feat"], data[i][0]) and np.array_equal(store[i]["bu_bbox"], data[i][1])
+    out = np.zeros((2, 36, 64), np.float32)
+    store.gather_into([184613, 391895], out)
+    assert np.array_equal(out[0], data[184613][0]) and np.array_equal(out[1], data[391895][0])

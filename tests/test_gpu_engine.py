@@ -173,3 +173,28 @@ def test_xe_then_scst_steps_match_reference_engine(golden_dir, path):
         torch.cuda.synchronize()
         assert abs(loss - float(g[pre + "loss"])) < 1e-4
         _check_pinned(g, pre + "sd.", eng.model, slack=8e-4 + 2e-5 * (s + 1))
+
+
+def test_device_prefetcher_feeds_engine_identically(golden_dir, tmp_path):
+    """Packed store + pinned double-buffered H2D (features.py) in front of eval_captions_json_generation: same JSON as the
+    reference-style path that stacks per-image numpy arrays."""
+    from simpleimagecaptionzoo_amd.features import DevicePrefetcher, PackedFeatureStore, pack_npz_dir
+    g, fx = _load(golden_dir)
+    eng, _ = _engine(g, fx)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    feats = feats_from_seed(int(g["eval_feats_seed"]), B, R, D)
+    ids = tuple(int(i) for i in g["eval_img_ids"])
+    root = str(tmp_path / "supp")
+    os.makedirs(os.path.join(root, "fixed_bu_feat"))
+    for j, i in enumerate(ids):
+        np.savez_compressed(os.path.join(root, "fixed_bu_feat", "%d.npz" % i), feat=feats[j])
+    store = PackedFeatureStore(pack_npz_dir(root, ids, str(tmp_path / "packed")))
+    # three batches (2 + 2 + rest) through two staging slots; the supp entries of the tuples are ignored when a store is given
+    cuts = [ids[0:2], ids[2:4], ids[4:]]
+    loader = [(c, None, None) for c in cuts if len(c)]
+    res = eng.eval_captions_json_generation(DevicePrefetcher(loader, "cuda:0", store), eval_beam_size=-1, tqdm_visible=False)
+    assert res == fx["eval_greedy_json"]
+    # without a store the prefetcher stages the tuples' own numpy features
+    loader = [(ids, None, _supp(feats))]
+    res = eng.eval_captions_json_generation(DevicePrefetcher(loader, "cuda:0"), eval_beam_size=3, tqdm_visible=False)
+    assert res == fx["eval_beam3_json"]
