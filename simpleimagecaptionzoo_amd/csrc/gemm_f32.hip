@@ -18,7 +18,8 @@ static int total_chunks(const GemmArgs& a, int bk = GEMM_BK) {
 
 // Walks the chunk sequence of one split: (segment, k offset) advance with scalar arithmetic only; the segment's
 // operand descriptors are re-read from the kernel arguments only when the segment changes.
-struct ChunkCursor {
+template <int BK>
+struct ChunkCursorT {
     int seg, k0;
     const float* A; const float* B;
     int lda, ldb, K;
@@ -32,26 +33,28 @@ struct ChunkCursor {
 #pragma unroll
         for (int s = 0; s < GEMM_MAX_SEG - 1; ++s) {
             if (seg == s && s < a.nseg - 1) {
-                int n = (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+                int n = (a.seg[s].K + BK - 1) / BK;
                 if (c >= n) { c -= n; seg = s + 1; }
             }
         }
-        k0 = c * GEMM_BK;
+        k0 = c * BK;
         load_seg(a);
     }
     __device__ __forceinline__ void next(const GemmArgs& a) {
-        k0 += GEMM_BK;
+        k0 += BK;
         if (k0 >= K && seg < a.nseg - 1) { ++seg; k0 = 0; load_seg(a); }
     }
 };
+using ChunkCursor = ChunkCursorT<GEMM_BK>;
 
+template <int BK = GEMM_BK>
 __device__ __forceinline__ int split_range(const GemmArgs& a, int z, int* c_end_out) {
     const int c_begin = z * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
     int tot = 0;
 #pragma unroll
     for (int s = 0; s < GEMM_MAX_SEG; ++s)
-        if (s < a.nseg) tot += (a.seg[s].K + GEMM_BK - 1) / GEMM_BK;
+        if (s < a.nseg) tot += (a.seg[s].K + BK - 1) / BK;
     *c_end_out = c_end > tot ? tot : c_end;
     return c_begin;
 }
@@ -282,36 +285,37 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
 // Mirror image of NT: the B chunk (64 k x 64 n, shared by the 4 waves) goes through LDS, each wave owns 16
 // rows and all 64 columns; A fragments straight to registers.  Column tiles are interleaved: a lane's
 // float4 along n at [k][4i..4i+3] supplies column 4i+j to column tile j, so one ds_read_b128 feeds 4 MFMAs.
-template <bool TAIL>
+template <bool TAIL, int BKC = GEMM_BK>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
-    __shared__ __attribute__((aligned(16))) float lds[2][GEMM_BK * GEMM_BN];
+    constexpr int NS = BKC / 16;                 // k-groups of 16 per stage = A float4 per lane = B staging loads per thread
+    __shared__ __attribute__((aligned(16))) float lds[2][BKC * GEMM_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
     const int n0 = blockIdx.x * GEMM_BN, m0 = blockIdx.y * GEMM_BM, z = blockIdx.z;
     int c_end;
-    const int c_begin = split_range(a, z, &c_end);
+    const int c_begin = split_range<BKC>(a, z, &c_end);
     const int mrow = m0 + wave * 16 + li;
     const size_t mrow_c = mrow < a.M ? mrow : a.M - 1;
 
     f32x4 acc[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) acc[t] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    f32x4 br[4];
-    f32x4 acur[4], anxt[4];
+    f32x4 br[NS];
+    f32x4 acur[NS], anxt[NS];
     // B staging: thread -> (row = idx>>4, n = n0 + 4*(idx&15)); columns beyond N are clamped (never stored)
     int bn = n0 + 4 * (tid & 15);
     if (bn > a.N - 4) bn = a.N - 4;
 
-    ChunkCursor cc;
-    auto load_chunk = [&](f32x4 (&av)[4]) {
+    ChunkCursorT<BKC> cc;
+    auto load_chunk = [&](f32x4 (&av)[NS]) {
 #pragma unroll
-        for (int s = 0; s < 4; ++s) {
+        for (int s = 0; s < NS; ++s) {
             const int k = cc.k0 + 16 * s + 4 * lq;
             const int kc = k < cc.K ? k : cc.K - 4;
             av[s] = ld4z<TAIL>(cc.A + mrow_c * cc.lda + kc, k < cc.K);
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < NS; ++j) {
             const int k = cc.k0 + (tid >> 4) + 16 * j;
             const int kc = k < cc.K ? k : cc.K - 1;
             br[j] = ld4z<TAIL>(cc.B + (size_t)kc * cc.ldb + bn, k < cc.K);
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
     };
     auto store_stage = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < NS; ++j)
             *reinterpret_cast<f32x4*>(&lds[buf][((tid >> 4) + 16 * j) * GEMM_BN + 4 * (tid & 15)]) = br[j];
     };
 
@@ -332,8 +336,10 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
             const int buf = (c - c_begin) & 1;
             const bool more = (c + 1 < c_end);
             if (more) { cc.next(a); load_chunk(anxt); }
+            // keep the next stage's loads HERE (the compiler otherwise sinks them below the MFMAs, next to their first use)
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
+            for (int s = 0; s < NS; ++s) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     // MFMA k index q <-> k = 16s + 4q + e (A side: component e of the lane's float4)
@@ -346,7 +352,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
             if (more) store_stage(buf ^ 1);
             __syncthreads();
 #pragma unroll
-            for (int s = 0; s < 4; ++s) acur[s] = anxt[s];
+            for (int s = 0; s < NS; ++s) acur[s] = anxt[s];
         }
     }
     // epilogue: acc[t][r] <-> row m0 + 16*wave + 4q + r, column n0 + 4*i + t
@@ -490,7 +496,19 @@ static int nt_stage_k(const GemmArgs& a) {
         if (a.seg[s].K % 128) return 64;
     return force == 64 ? 64 : 128;
 }
-static int stage_k(GemmLayout layout, const GemmArgs& a) { return layout == GEMM_NT ? nt_stage_k(a) : GEMM_BK; }
+// NN pipeline-stage depth: 128 when every segment's K is a multiple of 128 (halves the barriers and gives the next
+// stage's loads 128 MFMAs per wave to land behind)
+static int nn_stage_k(const GemmArgs& a) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ICZ_GEMM_NN_BK"); force = e ? atoi(e) : 0; }
+    if (force == 64) return 64;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % 128) return 64;
+    return 128;
+}
+static int stage_k(GemmLayout layout, const GemmArgs& a) {
+    return layout == GEMM_NT ? nt_stage_k(a) : (layout == GEMM_NN ? nn_stage_k(a) : GEMM_BK);
+}
 
 // NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
 static int nt_waves(const GemmArgs& a) {
@@ -585,7 +603,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
-        if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
+        if (nn_stage_k(a) == 128) hipLaunchKernelGGL((gemm_nn_kernel<false, 128>), grid, block, 0, stream, a);
+        else if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
     } else {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
