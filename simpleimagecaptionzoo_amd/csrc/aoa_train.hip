@@ -321,7 +321,7 @@ int Aoa::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int
     g.nseg = 1;
     g.seg[0] = {A, Bm, lda, ldb, K, nullptr};
     g.M = M; g.N = N; g.out = slab_out; g.ldo = N;
-    g.nsplit = gemm_pick_split(g, target, GEMM_NN);
+    g.nsplit = M <= 64 ? gemm_pick_split(g, target, GEMM_NN) : gemm_pick_split_balanced(g, GEMM_NN, cap);
     ICZ_REQUIRE(gemm_slab_floats(M, N, g.nsplit) <= cap, "aoa: slab buffer too small");
     ICZ_TRY(gemm_f32(GEMM_NN, g, st));
     *ns_out = g.nsplit;

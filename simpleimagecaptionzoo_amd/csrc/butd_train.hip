@@ -379,7 +379,7 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
 // helpers for the backward GEMMs
 int Butd::gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st) {
     // direct output (nsplit 1) if there are already enough tiles, else slabs
-    g.nsplit = gemm_pick_split(g, g.M <= 64 ? STEP_WGS : TARGET_WGS, layout);
+    g.nsplit = g.M <= 64 ? gemm_pick_split(g, STEP_WGS, layout) : gemm_pick_split_balanced(g, layout, slab ? slab_floats : 0);
     if (g.nsplit > 1) {
         ICZ_REQUIRE(slab && gemm_slab_floats(g.M, g.N, g.nsplit) <= slab_floats, "butd: slab buffer too small (%d x %d x %d)", g.nsplit, g.M, g.N);
         g.out = slab; g.ldo = g.N; g.bias = nullptr; g.accumulate = 0;

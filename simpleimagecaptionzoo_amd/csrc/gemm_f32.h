@@ -56,6 +56,8 @@ struct GemmArgs {
 int gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t stream);
 // picks a split-K factor so that the launch has about `target_wgs` workgroups
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout = GEMM_NT);
+// the same for launches with many tiles: balances whole rounds of workgroups over the 256 CUs (see gemm_f32.hip)
+int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_capacity_floats);
 size_t gemm_slab_floats(int M, int N, int nsplit);
 // clamp a caller-chosen split so that no split is empty (stage depth depends on layout and shape)
 int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit);

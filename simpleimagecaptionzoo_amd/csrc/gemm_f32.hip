@@ -533,6 +533,28 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     return cdiv(tot, cps);
 }
 
+// Split-K factor for GEMMs with many output tiles (the batched dgrad GEMMs over all time steps): the launch runs in
+// ceil(tiles * s / 256) rounds of one workgroup per CU, each round costing its K chunks plus a fixed prologue/epilogue
+// (about 6 us = 2.4 stages of 128); s is chosen to minimise rounds * (chunks per split + fixed) under the slab capacity.
+// E.g. 320 tiles x 79 chunks: s = 1 needs 2 rounds of 79 (the second a quarter full), s = 4 needs 5 full rounds of 20.
+int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_capacity_floats) {
+    const int bk = stage_k(layout, a);
+    const int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
+    const int tot = total_chunks(a, bk);
+    const double fixed = 2.4 * 128.0 / bk;
+    int best = 1;
+    double best_cost = 1e30;
+    for (int s = 1; s <= 32 && s <= tot; ++s) {
+        const int cps = cdiv(tot, s);
+        if (cdiv(tot, cps) != s) continue;
+        if (s > 1 && (size_t)s * a.M * a.N > slab_capacity_floats) break;
+        const int rounds = cdiv(tiles * s, 256);
+        const double cost = rounds * (cps + fixed) + (s > 1 ? 0.25 * s : 0.0);
+        if (cost < best_cost - 1e-9) { best_cost = cost; best = s; }
+    }
+    return best;
+}
+
 int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit) {
     const int tot = total_chunks(a, stage_k(layout, a));
     if (nsplit < 1) nsplit = 1;

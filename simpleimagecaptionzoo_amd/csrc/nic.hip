@@ -333,7 +333,7 @@ int Nic::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int
     g.nseg = 1;
     g.seg[0] = {A, Bm, lda, ldb, K, nullptr};
     g.M = M; g.N = N; g.out = out; g.ldo = N;
-    g.nsplit = gemm_pick_split(g, target, GEMM_NN);
+    g.nsplit = M <= 64 ? gemm_pick_split(g, target, GEMM_NN) : gemm_pick_split_balanced(g, GEMM_NN, ns_out ? xfloats : ws_floats);
     float* slab = ns_out ? out : ws;
     if (g.nsplit > 1) {
         ICZ_REQUIRE(gemm_slab_floats(M, N, g.nsplit) <= (ns_out ? xfloats : ws_floats), "nic: slab buffer too small");
