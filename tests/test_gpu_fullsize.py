@@ -1,0 +1,135 @@
+"""Parity at BASELINE.json's full model size (R=36, D=2048, H=E=A=1024, V=10102): a few rows against the CPU oracle (sizes it
+finishes in seconds) and, at the full batch of 64, size-independent properties of the path."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+R, D, H, E, A, V = 36, 2048, 1024, 1024, 1024, 10102
+
+
+@pytest.fixture(scope="module")
+def full():
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    params = random_butd_params(R, D, H, E, A, V, "cuda", seed=77)
+    # trained decoders are far from uniform: sharpen the output layer so that argmax / draws are well separated
+    params["predict.weight_g"].mul_(6.0)
+    h = ButdHandle(R, D, H, E, A, V, 64 * 3, 20)
+    h.bind(params)
+    torch.manual_seed(5)
+    feats = torch.relu(torch.randn(64, R, D, device="cuda"))
+    return h, params, feats
+
+
+def _cpu(params):
+    return {k: v.detach().cpu().clone() for k, v in params.items()}
+
+
+def test_fullsize_greedy_matches_oracle(full):
+    from oracle import butd as ob
+    h, params, feats = full
+    n, T = 6, 5
+    ids, alphas = h.greedy(feats[:n], T, want_alphas=True)
+    want_ids, want_al, _ = ob.greedy(feats[:n].cpu(), _cpu(params), T)
+    assert np.array_equal(ids.cpu().numpy(), want_ids.numpy())
+    np.testing.assert_allclose(alphas.cpu().numpy(), want_al.numpy(), atol=2e-5)
+
+
+def test_fullsize_sample_and_reinforce_gradients_match_oracle(full):
+    """4 rows x 4 steps with injected masks / uniforms: ids exact, log-probs 1e-4 (north_star), every gradient tensor within
+    2e-4 of its maximum against torch autograd through the oracle."""
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    h, params, feats = full
+    n, T = 4, 4
+    rs = np.random.RandomState(9)
+    em = (rs.rand(T, n, E) < 0.5).astype(np.uint8)
+    am = (rs.rand(T, n, R, A) < 0.5).astype(np.uint8)
+    om = (rs.rand(T, n, H) < 0.5).astype(np.uint8)
+    u = rs.rand(T, n)
+    reward = rs.randn(n, T).astype(np.float32)
+    rng = make_rng(0, torch.tensor(u, dtype=torch.float32, device="cuda"), torch.tensor(em, device="cuda"),
+                   torch.tensor(am, device="cuda"), torch.tensor(om, device="cuda"))
+    seq, lp = h.sample(feats[:n], T, rng)
+    p = {k: v.requires_grad_(True) for k, v in _cpu(params).items()}
+    u32 = torch.tensor(u, dtype=torch.float32).double().numpy()          # the uniforms the device saw
+    wseq, wlp, _ = ob.sample_rl(feats[:n].cpu(), p, u32, em.astype(bool), am.astype(bool), om.astype(bool), T, early_exit=False)
+    assert np.array_equal(seq.cpu().numpy(), wseq.numpy())
+    np.testing.assert_allclose(lp.cpu().numpy(), wlp.detach().numpy(), atol=1e-4)
+    loss = ob.reward_criterion(wlp, wseq, torch.from_numpy(reward))
+    loss.backward()
+    grads = h.new_grads()
+    got_loss, _ = h.sample_backward(torch.tensor(reward, device="cuda"), grads)
+    assert abs(got_loss.item() - loss.item()) < 1e-4
+    for k, g in grads.items():
+        want = p[k].grad.numpy()
+        if k == "atten.affine.bias":
+            continue                                   # identically zero (softmax shift invariance); autograd leaves rounding noise
+        scale = max(1e-6, float(np.abs(want).max()))
+        assert np.abs(g.cpu().numpy() - want).max() <= 2e-4 * scale + 1e-7, (k, np.abs(g.cpu().numpy() - want).max(), scale)
+
+
+def test_fullsize_beam1_equals_greedy_and_beams_are_sorted(full):
+    """Beam size 1 is greedy decoding cut at <end> (BUTD_Model.py:236-318 with k = 1); wider beams never score below it."""
+    h, _, feats = full
+    T = 20
+    ids = h.greedy(feats, T).cpu().numpy()
+    seqs, lens = h.beam_search(feats, 1, T)
+    seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+    for i in range(feats.shape[0]):
+        g = ids[i].tolist()
+        want = [1] + (g[:g.index(2) + 1] if 2 in g else g)
+        assert seqs[i, :lens[i]].astype(np.int64).tolist() == want, i
+    s3, l3 = h.beam_search(feats, 3, T)
+    assert (l3.cpu().numpy() >= 2).all() and (s3[:, 0] == 1).all()
+
+
+def test_fullsize_reinforce_is_linear_in_reward_and_reproducible(full):
+    """Batch 64, Philox randomness: same seed -> bit-identical rollout and gradients; zero reward -> zero gradients;
+    doubling the reward doubles every gradient exactly (powers of two commute with fp32 rounding)."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    h, _, feats = full
+    reward = torch.randn(64, 20, device="cuda")
+    out = []
+    for scale in (1.0, 1.0, 2.0, 0.0):
+        greedy, seq, lp = h.rollouts(feats, 20, make_rng(4242))
+        grads = h.new_grads()
+        loss, msum = h.sample_backward(reward * scale, grads)
+        out.append((greedy.clone(), seq.clone(), lp.clone(), loss.item(), {k: v.clone() for k, v in grads.items()}))
+    a, b, c, z = out
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and a[3] == b[3]
+    assert torch.equal(a[0], h.greedy(feats, 20))
+    for k in a[4]:
+        assert torch.equal(a[4][k], b[4][k]), k
+        assert torch.equal(c[4][k], a[4][k] * 2), k
+        assert not z[4][k].any(), k
+        assert torch.isfinite(a[4][k]).all()
+    # log-probs are log-softmax values of the drawn tokens: <= 0, and exactly 0 after a row has finished
+    seq, lp = a[1], a[2]
+    assert (lp <= 0).all()
+    done = torch.cumsum((seq == 0).int(), 1) > 1
+    assert (lp[done] == 0).all() and (seq[done] == 0).all()
+
+
+def test_fullsize_xe_loss_is_mean_negative_log_likelihood(full):
+    """smoothing = 0: LabelSmoothingLoss (Utils.py:268-286) reduces to the token-averaged NLL of the packed logits."""
+    h, _, feats = full
+    rs = np.random.RandomState(3)
+    lengths = sorted(rs.randint(5, 17, size=64).tolist(), reverse=True)
+    L = max(lengths) + 1
+    caps = torch.zeros(64, L, dtype=torch.int64)
+    for b, n in enumerate(lengths):
+        caps[b, 0] = 1
+        caps[b, 1:n] = torch.from_numpy(rs.randint(4, V, size=n - 1))
+        caps[b, n] = 2
+    logits = h.xe_forward(feats, caps.cuda(), lengths, None, train=False, want_logits=True)
+    grads = h.new_grads()
+    loss = h.xe_backward(grads, smoothing=0.0)
+    tgt = torch.cat([caps[:sum(l > t for l in lengths), t + 1] for t in range(max(lengths))]).cuda()
+    want = torch.nn.functional.cross_entropy(logits.double(), tgt, reduction="mean")
+    assert abs(loss.item() - want.item()) < 1e-4
+    assert all(torch.isfinite(v).all() for v in grads.values())
+    # the bias gradient of the output layer is mean(softmax - onehot) over tokens: columns sum to ~0
+    assert abs(float(grads["predict.bias"].sum())) < 1e-4
