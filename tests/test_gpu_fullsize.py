@@ -133,3 +133,50 @@ def test_fullsize_xe_loss_is_mean_negative_log_likelihood(full):
     assert all(torch.isfinite(v).all() for v in grads.values())
     # the bias gradient of the output layer is mean(softmax - onehot) over tokens: columns sum to ~0
     assert abs(float(grads["predict.bias"].sum())) < 1e-4
+
+
+def test_fullsize_aoa_matches_oracle():
+    """AoADetection at its real size (Hd = E = 1024, 8 heads of 128, V = 10102): refined features, greedy ids and the XE
+    gradients of the decoder for 3 images against the CPU oracle / torch autograd."""
+    from oracle import aoa as oa
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, make_aoa_rng
+    torch.manual_seed(11)
+    cap = AoADetection_Captioner(V, max_batch=4, max_beam=2).cuda()
+    with torch.no_grad():
+        cap.decoder.predict.weight_g.mul_(6.0)
+        for l in cap.aoa_refine.aoa_layers:          # clones() starts the six layers identical; make them differ
+            for p_ in l.parameters():
+                p_.add_(torch.randn_like(p_) * 0.01)
+    h = cap._handle()
+    p = {k: v.detach().cpu().clone() for k, v in cap.state_dict().items()}
+    n, T = 3, 4
+    feats = torch.relu(torch.randn(n, R, D, device="cuda"))
+    np.testing.assert_allclose(h.refine(feats).cpu().numpy(), oa.refine(feats.cpu(), p).numpy(), atol=2e-4, rtol=1e-4)
+    ids = h.greedy(feats, T)
+    want_ids, _ = oa.greedy(feats.cpu(), p, T)
+    assert np.array_equal(ids.cpu().numpy(), want_ids.numpy())
+    # XE, evaluation mode (no dropout): packed logits, loss and decoder gradients
+    lengths = [4, 3, 2]
+    caps = torch.tensor([[1, 17, 230, 4001, 2], [1, 9, 77, 2, 0], [1, 5000, 2, 0, 0]])
+    logits = h.xe_forward(feats, caps.cuda(), lengths, None, train=False, want_logits=True)
+    for k in p:
+        p[k].requires_grad_(k.startswith("decoder."))
+    want_logits = oa.forward_xe(feats.cpu(), caps, lengths, p)
+    np.testing.assert_allclose(logits.cpu().numpy(), want_logits.detach().numpy(), atol=5e-4, rtol=1e-4)
+    tgt = torch.tensor([caps[b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(want_logits, tgt, 0.1)
+    loss.backward()
+    grads = h.new_grads()
+    got = h.xe_backward(grads, 0.1)
+    assert abs(got.item() - loss.item()) < 1e-4
+    for k, g in grads.items():
+        if k == "decoder.aoa_block.linear_K.bias":
+            continue                                   # identically zero (softmax shift invariance)
+        want = p[k].grad.numpy()
+        scale = max(1e-6, float(np.abs(want).max()))
+        assert np.abs(g.cpu().numpy() - want).max() <= 3e-4 * scale + 1e-7, (k, np.abs(g.cpu().numpy() - want).max(), scale)
+    # Philox path at full size: reproducible, finite
+    seq1, lp1 = h.sample(feats, 20, make_aoa_rng(5))
+    seq2, lp2 = h.sample(feats, 20, make_aoa_rng(5))
+    assert torch.equal(seq1, seq2) and torch.equal(lp1, lp2) and torch.isfinite(lp1).all()
