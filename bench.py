@@ -137,14 +137,20 @@ def main():
     # bracketed one by one) and with the side streams switched off, so that a pair measures the kernel alone, which is
     # also how rocprofv3 sees it (it serialises concurrent branches).
     avg_us, bpl, fpl, nl = C.c_double(), C.c_double(), C.c_double(), C.c_longlong()
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device=device)
+        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
+        dt = float(tt.item())
+    # every rank runs the same extra steps (they contain the gradient all-reduce); only rank 0 records events
+    eng.use_graphs = False
+    eng._hot_handle().set_concurrent(False)
+    run(1)
+    torch.cuda.synchronize()
     if rank == 0:
-        eng.use_graphs = False
-        eng._hot_handle().set_concurrent(False)
-        run(1)
-        torch.cuda.synchronize()
         lib().icz_prof_begin()
-        run(3)
-        torch.cuda.synchronize()
+    run(3)
+    torch.cuda.synchronize()
+    if rank == 0:
         lib().icz_prof_end(C.byref(avg_us), C.byref(bpl), C.byref(fpl), C.byref(nl))
     # PCIe-inclusive variant (never `value`): the same steps with the features starting in host memory, as the reference
     # boundary hands them over (BUTD_Engine.py:45), streamed through the pinned double-buffered prefetcher
@@ -169,9 +175,7 @@ def main():
         pcie = {"value": B * args.steps / dth, "unit": "captions/s", "ms_per_step": dth / args.steps * 1e3,
                 "note": "features start in host memory: gather into pinned buffers + async H2D (18.9 MB per batch) overlapped with the previous step"}
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device=device)
-        torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
-        dt = float(tt.item())
+        torch.distributed.barrier()
     if rank != 0:
         return
     value = world * B * args.steps / dt

@@ -70,6 +70,14 @@ int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
  * "concurrent" = 0: independent chains (greedy vs sampled rollout, predict gradients vs BPTT) run on ONE stream instead
  * of side streams (default 1); used by bench.py to time single kernels with events. */
 int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
+/* Data-parallel overlap hook (no reference counterpart: the reference is single-process).  While a backward call is
+ * being enqueued, `cb(user, stage)` is invoked each time a group of gradient tensors is complete in stream order:
+ *   stage 0: predict.{weight_v, weight_g, bias};  stage 1: embed.0.weight, TD_atten.weight_{ih,hh};
+ *   stage 2: language_model.weight_{ih,hh};  everything else is complete when the call returns.
+ * The host side starts the all-reduce of that group on the same stream (it then runs beside the remaining weight-gradient
+ * GEMMs).  NULL removes the hook. */
+typedef void (*icz_grad_ready_cb)(void* user, int32_t stage);
+int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user);
 /* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream);
 

@@ -15,6 +15,9 @@ class IczError(RuntimeError):
     pass
 
 
+GRAD_READY_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int32)       # icz_grad_ready_cb
+
+
 class ButdDims(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("R", "D", "H", "E", "A", "V", "max_rows", "max_len")]
 
@@ -112,6 +115,7 @@ def lib():
         "icz_butd_destroy": (C.c_int, [vp]),
         "icz_butd_bind_params": (C.c_int, [vp, C.POINTER(ButdParams)]),
         "icz_butd_set_option": (C.c_int, [vp, C.c_char_p, i32]),
+        "icz_butd_set_grad_callback": (C.c_int, [vp, GRAD_READY_CB, vp]),
         "icz_butd_refresh_weights": (C.c_int, [vp, vp]),
         "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),
         "icz_butd_step": (C.c_int, [vp, vp, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp]),

@@ -39,6 +39,12 @@ class ButdHandle:
         self._persistent = bool(on)
         check(lib().icz_butd_set_option(self._h, b"graphs", 1 if on else 0))
 
+    def set_grad_callback(self, fn):
+        """fn(stage) is called while a backward call is being enqueued, each time a group of gradients is complete in
+        stream order (include/icz.h: icz_butd_set_grad_callback); None removes it."""
+        self._grad_cb = _lib.GRAD_READY_CB(lambda user, stage: fn(int(stage))) if fn is not None else _lib.GRAD_READY_CB()
+        check(lib().icz_butd_set_grad_callback(self._h, self._grad_cb, None))
+
     def set_concurrent(self, on=True):
         check(lib().icz_butd_set_option(self._h, b"concurrent", 1 if on else 0))
 

@@ -298,6 +298,13 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
     return ICZ_ERR_INVALID;
 }
 
+int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user) {
+    ICZ_REQUIRE(h, "null handle");
+    Butd* b = reinterpret_cast<Butd*>(h);
+    b->grad_cb = cb; b->grad_cb_user = user;
+    return ICZ_OK;
+}
+
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Butd*>(h)->refresh((hipStream_t)stream);

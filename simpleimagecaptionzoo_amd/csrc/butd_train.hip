@@ -221,7 +221,8 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
     mode = 0;   // the saved logits are consumed
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
-    if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
+    // the DP hook must fire on every call (a replayed graph would not call it): backward is enqueued eagerly then
+    if (explicit_rng || !use_graphs || grad_cb) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
     std::vector<uintptr_t> key = {3, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)mask_sum_out, (uintptr_t)cur_B, (uintptr_t)cur_T,
                                   (uintptr_t)cur_feats, (uintptr_t)cur_seq, (uintptr_t)cur_logp};
     const float* const* gp = reinterpret_cast<const float* const*>(G);
@@ -539,6 +540,12 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         cur ^= 1;
     }
 
+    bool joined = false;
+    if (grad_cb) {      // the predict branch has long finished beside the loop: join it now so that its gradients can be reduced
+        ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        joined = true;
+        grad_cb(grad_cb_user, 0);
+    }
     // ---- embedding gradient: dEmb = dG_td . W_ih_td[:, H+D:] for all steps, then ordered scatter
     {
         GemmArgs g = {};
@@ -562,9 +569,11 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     ICZ_TRY(wgrad(tb.dGsum, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));               // mean features
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st));         // embedding
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st));                     // h1_{t-1}
+    if (grad_cb) grad_cb(grad_cb_user, 1);
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st));                 // ctx_t
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st));         // h1_t
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
+    if (grad_cb) grad_cb(grad_cb_user, 2);
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
     {   // d enc_ctx (sum over time) and the affine-weight partials, from the ds_t recorded by the loop
         AttBwdDencArgs ea = {enc_ctx, tb.dec, tb.dS, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
@@ -587,7 +596,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
                        G.dec_att_v, G.dec_att_g, A, H);
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(1), dim3(256), 0, st, tb.dWaff, A, P.affine_v, P.affine_g, n_aff,
                        G.affine_v, G.affine_g, 1, A);
-    ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
+    if (!joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }

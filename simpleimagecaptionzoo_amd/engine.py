@@ -150,17 +150,70 @@ class BUTDDetection_Eng(Engine):
         return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": bu_masks}
 
     # ---- helpers ------------------------------------------------------------------------------------------
+    # Gradient groups in the order the backward pass completes them (include/icz.h: icz_butd_set_grad_callback); the flat
+    # buffer is laid out group by group so that each group is one contiguous slice = one all-reduce.
+    _GRAD_STAGES = (("predict.weight_v", "predict.weight_g", "predict.bias"),
+                    ("embed.0.weight", "TD_atten.weight_ih", "TD_atten.weight_hh"),
+                    ("language_model.weight_ih", "language_model.weight_hh"))
+
     def _grads(self):
-        """Gradient buffers as views into ONE flat fp32 buffer (a single all-reduce over xGMI moves them all)."""
+        """Gradient buffers as views into ONE flat fp32 buffer (few large all-reduces over xGMI move them all)."""
         if getattr(self, "_flat", None) is None:
             named = self._trainable()
-            offs, total = {}, 0
-            for k, p in named.items():
+            staged = [k for st in self._GRAD_STAGES for k in st if k in named]
+            order = staged + [k for k in named if k not in staged]
+            offs, total, bounds = {}, 0, []
+            for k in order:
                 offs[k] = total
-                total += (p.numel() + 63) // 64 * 64
+                total += (named[k].numel() + 63) // 64 * 64
+                bounds.append(total)
             self._flat = torch.zeros(total, dtype=torch.float32, device=self.device)
-            self._gviews = {k: self._flat[o:o + named[k].numel()].view_as(named[k]) for k, o in offs.items()}
+            self._gviews = {k: self._flat[offs[k]:offs[k] + named[k].numel()].view_as(named[k]) for k in named}
+            # slice of the flat buffer per stage (+ the remainder), only meaningful when every staged key is present
+            self._stage_slices = []
+            if len(staged) == sum(len(st) for st in self._GRAD_STAGES):
+                lo, i = 0, 0
+                for st in self._GRAD_STAGES:
+                    i += len(st)
+                    self._stage_slices.append((lo, bounds[i - 1]))
+                    lo = bounds[i - 1]
+                self._stage_slices.append((lo, total))
         return self._gviews
+
+    def _reduce_grads_begin(self, h):
+        """Data-parallel: start the all-reduce of each gradient group as soon as the backward pass has enqueued it, so that
+        RCCL moves it over xGMI beside the remaining weight-gradient GEMMs (the hook is a no-op for one process)."""
+        self._pending = []
+        if not icz_dist.is_distributed() or not self._stage_slices or not hasattr(h, "set_grad_callback"):
+            return False
+        if getattr(self, "_hooked", None) is not h:
+            import torch.distributed as td
+
+            def on_ready(stage):
+                try:      # called from inside the C library: an exception cannot propagate through it
+                    lo, hi = self._stage_slices[stage]
+                    self._pending.append(td.all_reduce(self._flat[lo:hi], op=td.ReduceOp.SUM, async_op=True))
+                except Exception as e:      # re-raised by _reduce_grads_end
+                    self._hook_error = e
+            h.set_grad_callback(on_ready)
+            self._hooked = h
+        return True
+
+    def _reduce_grads_end(self, overlapped):
+        if not icz_dist.is_distributed():
+            return
+        if not overlapped:
+            icz_dist.all_reduce_sum_(self._flat)
+            return
+        err, self._hook_error = getattr(self, "_hook_error", None), None
+        if err is not None or len(self._pending) != len(self._stage_slices) - 1:
+            raise RuntimeError("gradient hook: %d of %d groups were reduced%s" % (
+                len(self._pending), len(self._stage_slices) - 1, "" if err is None else " (%r)" % (err,)))
+        lo, hi = self._stage_slices[-1]
+        icz_dist.all_reduce_sum_(self._flat[lo:hi])
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
     def _trainable(self):
         """name -> parameter for everything the optimizer updates (AoA: the decoder only, AoA_Model.py:669-674)."""
@@ -216,9 +269,9 @@ class BUTDDetection_Eng(Engine):
             grads = self._grads()
             n_tok = float(sum(lengths))
             n_glob = icz_dist.all_reduce_scalar(n_tok) if icz_dist.is_distributed() else 0.0
+            ov = self._reduce_grads_begin(h)
             loss = h.xe_backward(grads, smoothing, n_glob)
-            if icz_dist.is_distributed():
-                icz_dist.all_reduce_sum_(self._flat)
+            self._reduce_grads_end(ov)
             self._apply(optimizer, 0.1)
             losses.append(loss)
             if tqdm_visible:
@@ -248,9 +301,9 @@ class BUTDDetection_Eng(Engine):
             msum_glob = 0.0
             if icz_dist.is_distributed():
                 msum_glob = icz_dist.all_reduce_scalar(h.sample_mask_sum())
+            ov = self._reduce_grads_begin(h)
             loss, _ = h.sample_backward(rewards, grads, msum_glob)
-            if icz_dist.is_distributed():
-                icz_dist.all_reduce_sum_(self._flat)
+            self._reduce_grads_end(ov)
             self._apply(optimizer, 0.25)
             losses.append(loss)
             if tqdm_visible:

@@ -198,3 +198,52 @@ def test_device_prefetcher_feeds_engine_identically(golden_dir, tmp_path):
     loader = [(ids, None, _supp(feats))]
     res = eng.eval_captions_json_generation(DevicePrefetcher(loader, "cuda:0"), eval_beam_size=3, tqdm_visible=False)
     assert res == fx["eval_beam3_json"]
+
+
+def test_dp_overlap_hook_single_rank_group(golden_dir):
+    """The data-parallel path of the Engine (normaliser all-reduce, gradient groups all-reduced from the backward hook while
+    the remaining weight-gradient GEMMs run, clamp + Adam afterwards) on a one-rank RCCL group: sums over one rank are
+    identities, so the reference Engine's parameters after 2 XE + 2 SCST steps must come out unchanged."""
+    import torch.distributed as td
+    from simpleimagecaptionzoo_amd import dist as icz_dist
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import init_optimizer
+    g, fx = _load(golden_dir)
+    eng, vocab = _engine(g, fx)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    dev = "cuda"
+    if not td.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    real = icz_dist.is_distributed
+    icz_dist.is_distributed = lambda: True
+    calls = []
+    try:
+        def rng_of(seed, T, with_u):
+            em, am, om, u = masks_from_seed(seed, T, B, R, E, A, H)
+            return make_rng(0, torch.tensor(u, dtype=torch.float32, device=dev) if with_u else None,
+                            torch.tensor(em, device=dev), torch.tensor(am, device=dev), torch.tensor(om, device=dev))
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 4e-4}), 4e-4)
+        for s in range(2):
+            pre = "xe%d_" % s
+            feats = feats_from_seed(int(g[pre + "feats_seed"]), B, R, D)
+            lens = [int(x) for x in g[pre + "lengths"]]
+            batch = (tuple(range(B)), None, torch.tensor(g[pre + "captions"]), lens, _supp(feats))
+            losses = eng.training_epoch([batch], opt, _Crit(), tqdm_visible=False, rngs=[rng_of(int(g[pre + "mask_seed"]), max(lens) - 1, False)])
+            calls.append(len(eng._stage_slices))
+            assert abs(losses[0].item() - float(g[pre + "loss"])) < 1e-4
+            _check_pinned(g, pre + "sd.", eng.model, slack=4e-4 * (s + 1))
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+        for s in range(2):
+            pre = "rl%d_" % s
+            feats = feats_from_seed(int(g[pre + "feats_seed"]), B, R, D)
+            img_ids = tuple(int(i) for i in g[pre + "img_ids"])
+            gts = {int(k): v for k, v in fx[pre + "gts"].items()}
+            losses = eng.SCST_training_epoch([(img_ids, None, gts, _supp(feats))], opt, None, tqdm_visible=False,
+                                             rngs=[rng_of(int(g[pre + "mask_seed"]), 20, True)])
+            assert abs(losses[0].item() - float(g[pre + "loss"])) < 1e-4
+            _check_pinned(g, pre + "sd.", eng.model, slack=4e-4 * 2 + 2e-5 * (s + 1))
+        assert calls == [4, 4] and eng._hooked is not None and eng._pending == []
+    finally:
+        icz_dist.is_distributed = real
