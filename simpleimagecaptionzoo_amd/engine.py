@@ -39,6 +39,34 @@ class FusedAdam:
     def zero_grad(self):
         pass
 
+    def state_dict(self):
+        """Same layout as torch.optim.Adam.state_dict(): parameters are numbered in param_groups order.  (The reference
+        neither saves the optimizer, Engine.py:81-88, nor keeps it across epochs, Engine.py:133-136; with this a caller
+        can -- SURVEY.md 8f row 4.)"""
+        index, groups = {}, []
+        for g in self.param_groups:
+            ids = []
+            for p in g["params"]:
+                index.setdefault(p, len(index))
+                ids.append(index[p])
+            groups.append({**{k: v for k, v in g.items() if k != "params"}, "betas": (0.9, 0.999), "eps": 1e-8,
+                           "weight_decay": 0, "params": ids})
+        state = {index[p]: {"step": torch.tensor(float(st["step"])), "exp_avg": st["exp_avg"].clone(),
+                            "exp_avg_sq": st["exp_avg_sq"].clone()} for p, st in self.state.items()}
+        return {"state": state, "param_groups": groups}
+
+    def load_state_dict(self, sd):
+        params = [p for g in self.param_groups for p in g["params"]]
+        if [len(g["params"]) for g in sd["param_groups"]] != [len(g["params"]) for g in self.param_groups]:
+            raise ValueError("optimizer state has a different parameter grouping")
+        for g, saved in zip(self.param_groups, sd["param_groups"]):
+            g["lr"] = saved["lr"]
+        self.state = {}
+        for i, st in sd["state"].items():
+            p = params[int(i)]
+            self.state[p] = {"step": int(float(st["step"])), "exp_avg": st["exp_avg"].to(p.device, torch.float32).clone(),
+                             "exp_avg_sq": st["exp_avg_sq"].to(p.device, torch.float32).clone()}
+
     def step_with(self, grads_by_param, clip):
         """grads_by_param: {parameter: gradient tensor}.  One multi-tensor launch per param group."""
         import ctypes as C

@@ -247,3 +247,33 @@ def test_dp_overlap_hook_single_rank_group(golden_dir):
         assert calls == [4, 4] and eng._hooked is not None and eng._pending == []
     finally:
         icz_dist.is_distributed = real
+
+
+def test_fused_adam_state_dict_roundtrip():
+    """Stop / save / load / continue gives the same parameters as continuing; the state loads into torch.optim.Adam too."""
+    from simpleimagecaptionzoo_amd.engine import FusedAdam
+    torch.manual_seed(0)
+    w0 = [torch.randn(300, 40, device="cuda"), torch.randn(77, device="cuda")]
+    grads = [[torch.randn_like(w) for w in w0] for _ in range(4)]
+
+    def run(opt, ps, steps):
+        for gs in steps:
+            opt.step_with({p: g for p, g in zip(ps, gs)}, 0.25)
+
+    a = [torch.nn.Parameter(w.clone()) for w in w0]
+    oa = FusedAdam([{"params": a, "lr": 1e-3}], 1e-3)
+    run(oa, a, grads)
+    b = [torch.nn.Parameter(w.clone()) for w in w0]
+    ob_ = FusedAdam([{"params": b, "lr": 1e-3}], 1e-3)
+    run(ob_, b, grads[:2])
+    sd = ob_.state_dict()
+    c = [torch.nn.Parameter(p.data.clone()) for p in b]
+    oc = FusedAdam([{"params": c, "lr": 5e-4}], 5e-4)
+    oc.load_state_dict(sd)
+    assert oc.param_groups[0]["lr"] == 1e-3
+    run(oc, c, grads[2:])
+    for x, y in zip(a, c):
+        assert torch.equal(x.data, y.data)
+    ref = torch.optim.Adam([{"params": [torch.nn.Parameter(p.data.clone()) for p in b], "lr": 1e-3}], lr=1e-3)
+    ref.load_state_dict(sd)                      # same key layout as torch's own
+    assert ref.state_dict()["param_groups"][0]["params"] == [0, 1]
