@@ -196,7 +196,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
             if ((MT * 16 * C4) % NTHR == 0 || tid + NTHR * j < MT * 16 * C4)
                 *reinterpret_cast<f32x4*>(&lds[buf][xlds[j]]) = xr[j];
     };
-    // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer)
+    // A-fragment reads for k-group s+1 are issued before the MFMAs of group s (register double buffer).  The scheduling
+    // fences pin that order: left alone, hipcc issues the reads of two groups back to back AFTER the previous group's MFMAs
+    // and the first MFMA of every pair of groups waits out the whole LDS latency with the matrix pipe idle.
     auto compute = [&](int buf, const f32x4 (&w)[NTW][NS]) {
         f32x4 af[2][MT];
         const float* base = &lds[buf][li * LDSS + 4 * lq];
@@ -209,6 +211,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
                 for (int t = 0; t < MT; ++t)
                     af[(s + 1) & 1][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * LDSS + 16 * (s + 1));
             }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
 #pragma unroll
@@ -216,6 +219,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
 #pragma unroll
                     for (int t = 0; t < MT; ++t)
                         acc[t][nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][t][e], w[nt][s][e], acc[t][nt], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
     };
 
