@@ -10,7 +10,15 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_REQUIRE(d.E % 4 == 0 && d.Hd % 4 == 0 && d.D % 4 == 0 && d.V > 3 && d.max_rows > 0 && d.max_len > 0, "aoa: bad dimensions");
     ICZ_REQUIRE(d.R >= 1 && d.R <= 64, "aoa: %d regions per image (supported: 1..64)", d.R);
     const size_t dh = d.Hd / d.NH;
-    ICZ_REQUIRE((3 * d.R * (dh + 1) + d.R * (d.R + 1)) * sizeof(float) <= 64 * 1024, "aoa: head tile does not fit the LDS budget");
+    // per-(image, head) tiles live in LDS: Q, K, V [R][dh+1] + P [R][R+1] in the refiner, K, V in the decoder.  gfx950 has
+    // 160 KB per CU; above the 64 KB default the kernels need the explicit opt-in below (49 regions x 128 columns: 86 KB)
+    const size_t lds_self = (3 * d.R * (dh + 1) + d.R * (d.R + 1)) * sizeof(float);
+    const size_t lds_dec = (2 * d.R * (dh + 1) + dh + 64) * sizeof(float);
+    ICZ_REQUIRE(lds_self <= 156 * 1024, "aoa: head tile (%zu bytes) does not fit the LDS budget", lds_self);
+    if (lds_self > 48 * 1024)
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_self_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_self));
+    if (lds_dec > 48 * 1024)
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aoa_dec_attn_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dec));
     Vp = pad_vocab(d.V);
     const size_t rows = d.max_rows, Hd = d.Hd, E = d.E, RR = rows * d.R;
     ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * Vp * Hd));

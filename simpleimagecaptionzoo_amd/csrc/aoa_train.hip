@@ -147,6 +147,12 @@ __global__ void aoa_gather_packed_kernel(const float* __restrict__ logit, int V,
 int Aoa::ensure_train() {
     if (tready) return ICZ_OK;
     const size_t B = dims.max_rows, T = dims.max_len, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
+    {
+        const size_t dh = Hd / NH, lds_bwd = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
+        if (lds_bwd > 48 * 1024)
+            ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aoa_dec_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                              (int)lds_bwd));
+    }
     const size_t TB = T * B;
     ICZ_TRY(alloc((void**)&tok, sizeof(int64_t) * (TB + B)));
     float** st1[] = {&th, &tm, &tctx};

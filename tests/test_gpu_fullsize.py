@@ -180,3 +180,36 @@ def test_fullsize_aoa_matches_oracle():
     seq1, lp1 = h.sample(feats, 20, make_aoa_rng(5))
     seq2, lp2 = h.sample(feats, 20, make_aoa_rng(5))
     assert torch.equal(seq1, seq2) and torch.equal(lp1, lp2) and torch.isfinite(lp1).all()
+
+
+def test_spatial_49_regions_butd_and_aoa_match_oracle():
+    """BUTDSpatial / AoASpatial feed a 7x7 grid = 49 regions (BUTD_Model.py:8-38, AoA_Model.py:638-655) through the same
+    decoders: greedy ids against the oracle at full width (AoA's per-head LDS tiles then exceed the 64 KB default)."""
+    from oracle import aoa as oa
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    R49, n, T = 49, 3, 4
+    torch.manual_seed(21)
+    feats = torch.relu(torch.randn(n, R49, D, device="cuda"))
+    params = random_butd_params(R49, D, H, E, A, V, "cuda", seed=78)
+    params["predict.weight_g"].mul_(6.0)
+    h = ButdHandle(R49, D, H, E, A, V, 8, 20)
+    h.bind(params)
+    ids, alphas = h.greedy(feats, T, want_alphas=True)
+    want_ids, want_al, _ = ob.greedy(feats.cpu(), _cpu(params), T)
+    assert np.array_equal(ids.cpu().numpy(), want_ids.numpy())
+    np.testing.assert_allclose(alphas.cpu().numpy(), want_al.numpy(), atol=2e-5)
+    cap = AoADetection_Captioner(V, num_regions=R49, max_batch=4, max_beam=2).cuda()
+    with torch.no_grad():
+        cap.decoder.predict.weight_g.mul_(6.0)
+    p = {k: v.detach().cpu().clone() for k, v in cap.state_dict().items()}
+    ha = cap._handle()
+    np.testing.assert_allclose(ha.refine(feats).cpu().numpy(), oa.refine(feats.cpu(), p).numpy(), atol=2e-4, rtol=1e-4)
+    want_ids, _ = oa.greedy(feats.cpu(), p, T)
+    assert np.array_equal(ha.greedy(feats, T).cpu().numpy(), want_ids.numpy())
+    seq, lp = ha.sample(feats, 6)
+    grads = ha.new_grads()
+    ha.sample_backward(torch.ones(n, 6, device="cuda"), grads)
+    assert all(torch.isfinite(g).all() for g in grads.values())
