@@ -342,16 +342,26 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
             if (more) { cc.next(a); load_chunk(anxt); }
             // keep the next stage's loads HERE (the compiler otherwise sinks them below the MFMAs, next to their first use)
             __builtin_amdgcn_sched_barrier(0);
+            // B fragments: one ds_read_b128 per k (MFMA k index q <-> k = 16s + 4q + e, A side: component e of the lane's
+            // float4) feeds 4 MFMAs.  The reads run two steps ahead of their MFMAs through a ring of three registers; the
+            // fences pin that order (left alone, hipcc issues each read right before its use and every second group of
+            // MFMAs waits out the LDS latency).
+            constexpr int NJ = 4 * NS;
+            const float* bbase = &lds[buf][(4 * lq) * GEMM_BN + 4 * li];
+            f32x4 bf[3];
+            bf[0] = *reinterpret_cast<const f32x4*>(bbase);
+            bf[1] = *reinterpret_cast<const f32x4*>(bbase + GEMM_BN);
 #pragma unroll
-            for (int s = 0; s < NS; ++s) {
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    // MFMA k index q <-> k = 16s + 4q + e (A side: component e of the lane's float4)
-                    f32x4 bf = *reinterpret_cast<const f32x4*>(&lds[buf][(16 * s + 4 * lq + e) * GEMM_BN + 4 * li]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t)
-                        acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[s][e], bf[t], acc[t], 0, 0, 0);
+            for (int j = 0; j < NJ; ++j) {
+                if (j + 2 < NJ) {
+                    const int s2 = (j + 2) >> 2, e2 = (j + 2) & 3;
+                    bf[(j + 2) % 3] = *reinterpret_cast<const f32x4*>(bbase + (16 * s2 + e2) * GEMM_BN);
                 }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int t = 0; t < 4; ++t)
+                    acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(acur[j >> 2][j & 3], bf[j % 3][t], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
             }
             if (more) store_stage(buf ^ 1);
             __syncthreads();
