@@ -82,7 +82,7 @@ __device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
 // overhead (barrier, waits, address arithmetic) per MFMA.
 // Rows beyond M / columns beyond N are read from a clamped (valid) row: they only feed accumulator rows /
 // columns that are never stored, so no zero-fill is needed; only the K tail must be zero (TAIL variant).
-template <int MT, int NTW, bool TAIL, int BKC, int NW = 4>
+template <int MT, int NTW, bool TAIL, int BKC, int NW = 4, bool SPREAD = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
     constexpr int BN = 16 * NW * NTW;
     constexpr int NTHR = 64 * NW;
@@ -234,10 +234,41 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
         __syncthreads();
         auto body = [&](int buf, const f32x4 (&wuse)[NTW][NS], f32x4 (&wload)[NTW][NS]) {
             advance();
-            load_stage(wload);
-            // keep the loads HERE: without the fence hipcc sinks them below the MFMAs, next to their first use
-            __builtin_amdgcn_sched_barrier(0);
-            compute(buf, wuse);
+            if (SPREAD && !TAIL && NTW == 1) {
+                // Decoder-step shape (M = 64: one workgroup per CU, all in lockstep).  Issued in one burst at the top of the
+                // stage, the loads put 256 x 64 KB on the fabric at once and then leave it idle while the matrix pipe runs:
+                // memory time and MFMA time add up (2.65 us per stage against 1.86 us of MFMA issue, while a pure streaming
+                // kernel moves the same weight bytes in 1.3 us).  So only the X loads go out at the top (their LDS store is
+                // due at the end of the stage); the next stage's W loads follow one per k-group, between the MFMA groups.
+#pragma unroll
+                for (int j = 0; j < XL; ++j) xr[j] = *reinterpret_cast<const f32x4*>(xp[j]);
+                __builtin_amdgcn_sched_barrier(0);
+                f32x4 af[2][MT];
+                const float* base = &lds[buf][li * LDSS + 4 * lq];
+#pragma unroll
+                for (int t = 0; t < MT; ++t) af[0][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * LDSS);
+#pragma unroll
+                for (int s = 0; s < NS; ++s) {
+                    if (s < NS - 1) {
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            af[(s + 1) & 1][t] = *reinterpret_cast<const f32x4*>(base + t * 16 * LDSS + 16 * (s + 1));
+                    }
+                    wload[0][s] = *reinterpret_cast<const f32x4*>(wp[0] + 16 * s);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+#pragma unroll
+                        for (int t = 0; t < MT; ++t)
+                            acc[t][0] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[s & 1][t][e], wuse[0][s][e], acc[t][0], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            } else {
+                load_stage(wload);
+                // keep the loads HERE: without the fence hipcc sinks them below the MFMAs, next to their first use
+                __builtin_amdgcn_sched_barrier(0);
+                compute(buf, wuse);
+            }
             store_stage(buf ^ 1);
             __syncthreads();
         };
@@ -525,6 +556,12 @@ static int stage_k(GemmLayout layout, const GemmArgs& a) {
 }
 
 // NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
+// spread-load variant for the skinny decoder-step GEMMs (see the kernel body); ICZ_GEMM_SPREAD=0 keeps the burst for A/B runs
+static bool nt_spread(const GemmArgs& a) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ICZ_GEMM_SPREAD"); force = e ? atoi(e) : 1; }
+    return force != 0 && a.M <= 64;
+}
 static int nt_waves(const GemmArgs& a) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_GEMM_NW"); force = e ? atoi(e) : 0; }
@@ -633,6 +670,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         else if (nt_stage_k(a) == 128 && nt_waves(a) == 8) {
             hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 8>), grid, dim3(512), 0, stream, a);
         }
+        else if (nt_stage_k(a) == 128 && nt_spread(a)) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 4, true>), grid, block, 0, stream, a);
         else if (nt_stage_k(a) == 128) ICZ_NT(4, 1, 128);
         else ICZ_NT(4, 1, 64);
 #undef ICZ_NT

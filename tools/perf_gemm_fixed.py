@@ -7,5 +7,5 @@ from simpleimagecaptionzoo_amd.butd import gemm
 for K in (512, 1024, 2048, 4096, 8192):
     X = torch.randn(64, K, device="cuda"); W = torch.randn(4096, K, device="cuda")
     for _ in range(30):
-        gemm("nt", X, W, None, 4)
+        gemm("nt", X, W, None, int(sys.argv[1]) if len(sys.argv) > 1 else 4)
     torch.cuda.synchronize()
