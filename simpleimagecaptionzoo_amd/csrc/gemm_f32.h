@@ -51,6 +51,7 @@ struct GemmArgs {
     int nsplit;
     int chunks_per_split;
     int accumulate;      // nsplit == 1 only: C += result (used by wgrad accumulation)
+    int spread;          // set by gemm_f32 (NN, skinny shapes): spread the next stage's loads over the stage
 };
 
 int gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t stream);

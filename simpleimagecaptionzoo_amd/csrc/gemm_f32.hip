@@ -370,7 +370,14 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
         for (int c = c_begin; c < c_end; ++c) {
             const int buf = (c - c_begin) & 1;
             const bool more = (c + 1 < c_end);
-            if (more) { cc.next(a); load_chunk(anxt); }
+            // Skinny shapes (one workgroup per CU, all in lockstep): the next stage's loads are spread over the stage instead
+            // of issued in one burst (see gemm_nt_kernel): the weight tile's staging loads one per two MFMA groups over the
+            // first half (their LDS store is due at the end of the stage), the A fragments one per four groups.
+            const bool spread = !TAIL && BKC == 128 && a.M <= 64 && a.spread;
+            if (more) {
+                cc.next(a);
+                if (!spread) load_chunk(anxt);
+            }
             // keep the next stage's loads HERE (the compiler otherwise sinks them below the MFMAs, next to their first use)
             __builtin_amdgcn_sched_barrier(0);
             // B fragments: one ds_read_b128 per k (MFMA k index q <-> k = 16s + 4q + e, A side: component e of the lane's
@@ -387,6 +394,16 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
                 if (j + 2 < NJ) {
                     const int s2 = (j + 2) >> 2, e2 = (j + 2) & 3;
                     bf[(j + 2) % 3] = *reinterpret_cast<const f32x4*>(bbase + (16 * s2 + e2) * GEMM_BN);
+                }
+                if (spread && more) {
+                    if ((j & 1) == 0 && (j >> 1) < NS) {
+                        const int jj = j >> 1;
+                        br[jj] = *reinterpret_cast<const f32x4*>(cc.B + (size_t)(cc.k0 + (tid >> 4) + 16 * jj) * cc.ldb + bn);
+                    }
+                    if ((j & 3) == 1) {
+                        const int ss = j >> 2;
+                        anxt[ss] = *reinterpret_cast<const f32x4*>(cc.A + mrow_c * cc.lda + cc.k0 + 16 * ss + 4 * lq);
+                    }
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
@@ -677,6 +694,11 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
+        {
+            static int sp = -1;
+            if (sp < 0) { const char* e = getenv("ICZ_GEMM_NN_SPREAD"); sp = e ? atoi(e) : 1; }
+            a.spread = sp;
+        }
         if (nn_stage_k(a) == 128) hipLaunchKernelGGL((gemm_nn_kernel<false, 128>), grid, block, 0, stream, a);
         else if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
