@@ -526,6 +526,108 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TN, large outputs (M, N >= 128; K a multiple of 32; no split): 128 x 128 tile per workgroup, both operand tiles
+// ([32 k][128] floats each) staged through LDS and shared by the four waves, wave (wr, wc) owning the 64 x 64 quadrant.
+// The 64 x 64-tile kernel above streams (64 + 64) x 4 bytes per k for 64 x 64 MACs -- 16 flop/B, i.e. ~38 GB/s per CU at
+// full MFMA rate, more than a CU gets from beyond L2; this one needs half of that.  Fragments use the same interleave as
+// above: the lane's float4 along m (n) at row k supplies row 4i+j (column 4i+j) of quadrant tile j, so one ds_read_b128
+// per operand and k-step feeds 16 MFMAs.  Loads of the next stage are spread over the stage (one per k-step).
+__global__ __launch_bounds__(256) void gemm_tn128_kernel(GemmArgs a) {
+    constexpr int KC = 32, LD = 128 + 4;                       // row stride 132 dwords: the four k rows of a read hit disjoint banks
+    __shared__ __attribute__((aligned(16))) float sA[2][KC * LD];
+    __shared__ __attribute__((aligned(16))) float sB[2][KC * LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    const int mbase = 64 * (wave >> 1), nbase = 64 * (wave & 1);
+    const GemmSeg& g = a.seg[0];
+    const int nst = g.K / KC;
+
+    f32x4 acc[4][4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int u = 0; u < 4; ++u) acc[t][u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> 4 float4 of the A tile and 4 of the B tile per stage (row = idx >> 5, column = 4 * (idx & 31))
+    const float* ap[4];
+    const float* bp[4];
+    int so[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5, c4 = 4 * (idx & 31);
+        int mc = m0 + c4, nc = n0 + c4;
+        if (mc > a.M - 4) mc = a.M - 4;                           // clamped columns feed only never-stored outputs
+        if (nc > a.N - 4) nc = a.N - 4;
+        ap[j] = g.A + (size_t)row * g.lda + mc;
+        bp[j] = g.B + (size_t)row * g.ldb + nc;
+        so[j] = row * LD + c4;
+    }
+    const size_t astep = (size_t)KC * g.lda, bstep = (size_t)KC * g.ldb;
+    f32x4 ar[4], br[4];
+    auto load_stage = [&]() {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { ar[j] = *reinterpret_cast<const f32x4*>(ap[j]); br[j] = *reinterpret_cast<const f32x4*>(bp[j]); }
+    };
+    auto store_stage = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            *reinterpret_cast<f32x4*>(&sA[buf][so[j]]) = ar[j];
+            *reinterpret_cast<f32x4*>(&sB[buf][so[j]]) = br[j];
+        }
+    };
+    load_stage();
+    store_stage(0);
+    __syncthreads();
+    for (int st = 0; st < nst; ++st) {
+        const int buf = st & 1;
+        const bool more = st + 1 < nst;
+        if (more) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { ap[j] += astep; bp[j] += bstep; }
+        }
+        const float* pa = &sA[buf][lq * LD + mbase + 4 * li];
+        const float* pb = &sB[buf][lq * LD + nbase + 4 * li];
+        f32x4 fa[2], fb[2];
+        fa[0] = *reinterpret_cast<const f32x4*>(pa);
+        fb[0] = *reinterpret_cast<const f32x4*>(pb);
+#pragma unroll
+        for (int ks = 0; ks < KC / 4; ++ks) {
+            if (ks + 1 < KC / 4) {
+                fa[(ks + 1) & 1] = *reinterpret_cast<const f32x4*>(pa + 4 * (ks + 1) * LD);
+                fb[(ks + 1) & 1] = *reinterpret_cast<const f32x4*>(pb + 4 * (ks + 1) * LD);
+            }
+            if (more) {      // the next stage's 8 loads, one per k-step
+                if (ks < 4) ar[ks] = *reinterpret_cast<const f32x4*>(ap[ks]);
+                else br[ks - 4] = *reinterpret_cast<const f32x4*>(bp[ks - 4]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_16x16x4f32(fa[ks & 1][t], fb[ks & 1][u], acc[t][u], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (more) store_stage(buf ^ 1);
+        __syncthreads();
+    }
+    // acc[t][u][r] <-> row m0 + mbase + 4*(4q + r) + t, column n0 + nbase + 4*i + u
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int m = m0 + mbase + 4 * (4 * lq + r) + t, n = n0 + nbase + 4 * li;
+            if (m < a.M && n < a.N) {
+                f32x4 v = {acc[t][0][r], acc[t][1][r], acc[t][2][r], acc[t][3][r]};
+                float* o = a.out + (size_t)m * a.ldo + n;
+                if (a.accumulate) v += *reinterpret_cast<f32x4*>(o);
+                *reinterpret_cast<f32x4*>(o) = v;
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Optional timing of every gemm_nt_kernel<4> launch with HIP events on the launch stream (bench.py's live
 // roofline measurement).  Off by default; nothing is recorded or allocated unless enabled.
 struct GemmProf {
@@ -703,6 +805,14 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         else if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
     } else {
+        static int big = -1;
+        if (big < 0) { const char* e = getenv("ICZ_GEMM_TN128"); big = e ? atoi(e) : 1; }
+        // at least one 128 x 128 tile per CU, else the 64 x 64 kernel (4x the workgroups) fills the chip better
+        if (big && a.nsplit == 1 && a.nseg == 1 && cdiv(a.M, 128) * cdiv(a.N, 128) >= 256 && a.seg[0].K % 32 == 0 && a.seg[0].K >= 64) {
+            hipLaunchKernelGGL(gemm_tn128_kernel, dim3(cdiv(a.N, 128), cdiv(a.M, 128), 1), block, 0, stream, a);
+            ICZ_CHECK_HIP(hipGetLastError());
+            return ICZ_OK;
+        }
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
         if (tail) hipLaunchKernelGGL(gemm_tn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_tn_kernel<false>, grid, block, 0, stream, a);
