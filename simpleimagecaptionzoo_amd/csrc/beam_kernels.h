@@ -18,69 +18,112 @@ struct BeamArgs {
     int* n_live;            // [1] number of images that still have active beams after this step
 };
 
-__global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
+// Beam expand / prune of one step (:271-300) in two launches:
+//   beam_rowtopk_kernel  grid (n_img * k): one workgroup per decoder row -> its log-softmax normaliser and its own best
+//                        n_act candidates (value = run + log_softmax, index v); every row of every image in parallel
+//   beam_merge_kernel    grid (n_img), one wave: top-n_act of the <= k*k row candidates (ties -> lower flat index r*V+v,
+//                        the order of a top-k over the flattened [k, V] scores), retire finished beams, compact the rest
+// The global top-n_act are contained in the union of the per-row top-n_act, so the result equals a search over all k*V.
+__global__ __launch_bounds__(256) void beam_rowtopk_kernel(const float* __restrict__ logits, int V, int ldl, int k, int step,
+                                                           const int* __restrict__ n_act, const float* __restrict__ run,
+                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx) {
     __shared__ float smf[4];
-    __shared__ int smi[4];
-    __shared__ float s_mx[BEAM_MAX_K], s_lse[BEAM_MAX_K];
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4], s_who[4];
+    const int row = blockIdx.x, img = row / k, r = row % k, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = n_act[img];
+    const int nr = (step == 1) ? 1 : na;          // step 1 scores row 0 only (:273-274)
+    if (r >= nr) return;
+    const float* l = logits + (size_t)row * ldl;
+    float mx = -INFINITY;
+    for (int v = tid; v < V; v += 256) mx = fmaxf(mx, l[v]);
+    mx = block_max_256(mx, smf);
+    float se = 0.f;
+    for (int v = tid; v < V; v += 256) se += expf(l[v] - mx);
+    se = block_sum_256(se, smf);
+    const float ls = logf(se);
+    const float rs = (step == 1) ? 0.f : run[row];
+    // thread-local best `na` of its strided slice (sorted: value descending, index ascending on ties)
+    float tv[BEAM_MAX_K];
+    int ti[BEAM_MAX_K];
+#pragma unroll
+    for (int j = 0; j < BEAM_MAX_K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    for (int v = tid; v < V; v += 256) {
+        float val = rs + ((l[v] - mx) - ls);
+        int idx = v;
+#pragma unroll
+        for (int j = 0; j < BEAM_MAX_K; ++j) {
+            if (j < na && (val > tv[j] || (val == tv[j] && idx < ti[j]))) {
+                const float ov = tv[j]; const int oi = ti[j];
+                tv[j] = val; ti[j] = idx;
+                val = ov; idx = oi;
+            }
+        }
+    }
+    // na rounds: every thread offers the head of its list, the block takes the best and that thread pops it
+    int head = 0;
+    for (int j = 0; j < na; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < BEAM_MAX_K; ++q)
+            if (q == head) { best = tv[q]; bi = ti[q]; }
+        int who = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64), ow = __shfl_xor(who, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; who = ow; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; s_who[wave] = who; }
+        __syncthreads();
+        best = s_val[0]; bi = s_idx[0]; who = s_who[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; who = s_who[w]; }
+        if (tid == who) ++head;
+        if (tid == 0) { cand_val[row * BEAM_MAX_K + j] = best; cand_idx[row * BEAM_MAX_K + j] = bi; }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(64) void beam_merge_kernel(BeamArgs a, const float* __restrict__ cand_val, const int* __restrict__ cand_idx) {
     __shared__ float pick_val[BEAM_MAX_K];
     __shared__ int pick_idx[BEAM_MAX_K];
     __shared__ int new_src[BEAM_MAX_K], new_tok[BEAM_MAX_K], s_newn;
     __shared__ float new_run[BEAM_MAX_K];
-    const int img = blockIdx.x, tid = threadIdx.x;
+    const int img = blockIdx.x, lane = threadIdx.x;
     const int k = a.k, V = a.V;
     const int na = a.n_act[img];
     const int row0 = img * k;
     if (na == 0) {
-        for (int j = tid; j < k; j += 256) { a.src_row[row0 + j] = row0 + j; a.it_next[row0 + j] = 0; }
+        for (int j = lane; j < k; j += 64) { a.src_row[row0 + j] = row0 + j; a.it_next[row0 + j] = 0; }
         return;
     }
-    const int nr = (a.step == 1) ? 1 : na;    // step 1 scores row 0 only (:273-274)
-    for (int r = 0; r < nr; ++r) {
-        const float* l = a.logits + (size_t)(row0 + r) * a.ldl;
-        float mx = -INFINITY;
-        for (int v = tid; v < V; v += 256) mx = fmaxf(mx, l[v]);
-        mx = block_max_256(mx, smf);
-        float se = 0.f;
-        for (int v = tid; v < V; v += 256) se += expf(l[v] - mx);
-        se = block_sum_256(se, smf);
-        if (tid == 0) { s_mx[r] = mx; s_lse[r] = logf(se); }
+    const int nr = (a.step == 1) ? 1 : na;
+    // lane c <-> candidate (row r = c / BEAM_MAX_K, rank j = c % BEAM_MAX_K)
+    const int cr = lane / BEAM_MAX_K, cj = lane % BEAM_MAX_K;
+    float val = -INFINITY;
+    int idx = 0x7fffffff;
+    if (cr < nr && cj < na) {
+        val = cand_val[(row0 + cr) * BEAM_MAX_K + cj];
+        idx = cr * V + cand_idx[(row0 + cr) * BEAM_MAX_K + cj];
     }
-    __syncthreads();
-    // top-na of run[r] + log_softmax(logits[r])[v] over (r, v); ties -> lower flat index
     for (int j = 0; j < na; ++j) {
-        float best = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int r = 0; r < nr; ++r) {
-            const float* l = a.logits + (size_t)(row0 + r) * a.ldl;
-            const float rs = (a.step == 1) ? 0.f : a.run[row0 + r];
-            const float mx = s_mx[r], ls = s_lse[r];
-            for (int v = tid; v < V; v += 256) {
-                const int idx = r * V + v;
-                bool taken = false;
-                for (int q = 0; q < j; ++q) taken |= (pick_idx[q] == idx);
-                if (taken) continue;
-                const float val = rs + ((l[v] - mx) - ls);
-                if (val > best || (val == best && idx < bi)) { best = val; bi = idx; }
-            }
-        }
+        float best = val;
+        int bi = idx;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
-            float ob = __shfl_xor(best, o, 64);
-            int oi = __shfl_xor(bi, o, 64);
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64);
             if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
         }
-        if ((tid & 63) == 0) { smf[tid >> 6] = best; smi[tid >> 6] = bi; }
-        __syncthreads();
-        if (tid == 0) {
-            for (int w = 1; w < 4; ++w)
-                if (smf[w] > best || (smf[w] == best && smi[w] < bi)) { best = smf[w]; bi = smi[w]; }
-            pick_val[j] = best;
-            pick_idx[j] = bi;
-        }
-        __syncthreads();
+        if (idx == bi) { val = -INFINITY; idx = 0x7fffffff; }      // taken (flat indices are unique)
+        if (lane == 0) { pick_val[j] = best; pick_idx[j] = bi; }
     }
+    __syncthreads();
     // retire finished beams, compact the rest (:279-300)
-    if (tid == 0) {
+    if (lane == 0) {
         int nn = 0;
         for (int j = 0; j < na; ++j) {
             const int src = pick_idx[j] / V, tok = pick_idx[j] % V;
@@ -109,14 +152,14 @@ __global__ __launch_bounds__(256) void beam_step_kernel(BeamArgs a) {
         if (j < nn) {
             const int32_t* ss = a.seqs_in + (size_t)(row0 + new_src[j]) * a.L;
             int32_t* so = a.seqs_out + (size_t)(row0 + j) * a.L;
-            for (int i = tid; i < a.step; i += 256) so[i] = ss[i];
-            if (tid == 0) {
+            for (int i = lane; i < a.step; i += 64) so[i] = ss[i];
+            if (lane == 0) {
                 so[a.step] = new_tok[j];
                 a.run[row0 + j] = new_run[j];
                 a.src_row[row0 + j] = row0 + new_src[j];
                 a.it_next[row0 + j] = new_tok[j];
             }
-        } else if (tid == 0) {
+        } else if (lane == 0) {
             a.src_row[row0 + j] = row0 + j;
             a.it_next[row0 + j] = 0;
         }

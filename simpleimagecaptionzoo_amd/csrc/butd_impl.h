@@ -56,6 +56,7 @@ struct BeamBuf {
     int32_t *src_row = nullptr, *img_of_row = nullptr, *best_seq = nullptr;
     float* best_score = nullptr; int *best_len = nullptr, *has_complete = nullptr, *n_live = nullptr, *n_live_host = nullptr;
     float* feat_rows = nullptr;       // NIC: image embedding replicated per beam row
+    float* cand_val = nullptr; int* cand_idx = nullptr;     // [rows, BEAM_MAX_K] per-row candidates of one step
 };
 
 struct Butd {

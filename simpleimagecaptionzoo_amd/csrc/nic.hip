@@ -421,6 +421,8 @@ int Nic::beam_search(const float* feats, int n_img, int k, int max_steps, float*
         ICZ_TRY(alloc((void**)&bm.has_complete, sizeof(int) * R_));
         ICZ_TRY(alloc((void**)&bm.best_seq, sizeof(int32_t) * R_ * L_));
         ICZ_TRY(alloc((void**)&bm.n_live, sizeof(int) * 260));
+        ICZ_TRY(alloc((void**)&bm.cand_val, sizeof(float) * R_ * BEAM_MAX_K));
+        ICZ_TRY(alloc((void**)&bm.cand_idx, sizeof(int) * R_ * BEAM_MAX_K));
         ICZ_TRY(alloc((void**)&bm.feat_rows, sizeof(float) * R_ * dims.E));
         ICZ_CHECK_HIP(hipHostMalloc((void**)&bm.n_live_host, sizeof(int) * 4, 0));
         bm.cap_rows = (int)R_;
@@ -439,7 +441,9 @@ int Nic::beam_search(const float* feats, int n_img, int k, int max_steps, float*
         ICZ_TRY(token_step(rows, it, false, h[0], c[0], h[1], c[1], emb, nullptr, hdrop, logits, off, st));
         BeamArgs a = {logits, dims.V, Vp, k, step, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + step};
-        hipLaunchKernelGGL(beam_step_kernel, dim3(n_img), dim3(256), 0, st, a);
+        hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run,
+                           bm.cand_val, bm.cand_idx);
+        hipLaunchKernelGGL(beam_merge_kernel, dim3(n_img), dim3(64), 0, st, a, (const float*)bm.cand_val, (const int*)bm.cand_idx);
         hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h[1], c[1], h[1], c[1], h[0], c[0], h[0], c[0]);
         sb ^= 1;
         steps_done = step;

@@ -4,7 +4,8 @@ import time
 
 import torch
 
-sys.path.insert(0, ".")
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, make_aoa_rng  # noqa: E402
 
 
