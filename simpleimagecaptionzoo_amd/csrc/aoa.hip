@@ -6,7 +6,7 @@ namespace icz {
 
 int Aoa::init(const icz_aoa_dims& d) {
     dims = d;
-    ICZ_REQUIRE(d.NH > 0 && d.Hd % d.NH == 0, "aoa: hidden size %d not divisible by %d heads", d.Hd, d.NH);
+    ICZ_REQUIRE(d.NH > 0 && d.Hd % d.NH == 0 && (d.Hd / d.NH) % 4 == 0, "aoa: hidden size %d must split into %d heads of a multiple of 4 columns", d.Hd, d.NH);
     ICZ_REQUIRE(d.E % 4 == 0 && d.Hd % 4 == 0 && d.D % 4 == 0 && d.V > 3 && d.max_rows > 0 && d.max_len > 0, "aoa: bad dimensions");
     ICZ_REQUIRE(d.R >= 1 && d.R <= 64, "aoa: %d regions per image (supported: 1..64)", d.R);
     const size_t dh = d.Hd / d.NH;
@@ -153,7 +153,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd};
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(Hd, 256), rows), dim3(256), 0, st, a, off);
-    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
     ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 64);
     hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(64), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,

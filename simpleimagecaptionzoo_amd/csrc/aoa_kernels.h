@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
                                                          const float* __restrict__ bias, float* __restrict__ y, int rows, int n,
                                                          float* __restrict__ stats) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row
     if (row >= rows) return;
     const float* xr = x + (size_t)row * n;
     float s = 0.f;
@@ -138,6 +138,30 @@ __global__ __launch_bounds__(256) void aoa_u_kernel(const float* __restrict__ me
     u[i] = meanf[(size_t)img * Hd + c] + dp.apply(ctx_prev[i], i);
 }
 
+// K and V head tiles [R][d] -> LDS [R][d+1] by one wave: 16-byte loads, eight in flight per lane (d % 4 == 0)
+__device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const float* __restrict__ V, float* sk, float* sv, int R, int d,
+                                             int Hd, int lane) {
+    const int d4 = d >> 2, n = R * d4, ld = d + 1;
+    for (int i0 = lane; i0 < n; i0 += 256) {
+        f32x4 kk[4], vv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = min(i0 + 64 * u, n - 1), r = i / d4, j = (i % d4) * 4;
+            kk[u] = *reinterpret_cast<const f32x4*>(K + (size_t)r * Hd + j);
+            vv[u] = *reinterpret_cast<const f32x4*>(V + (size_t)r * Hd + j);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + 64 * u;
+            if (i < n) {
+                const int r = i / d4, j = (i % d4) * 4;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) { sk[r * ld + j + c] = kk[u][c]; sv[r * ld + j + c] = vv[u][c]; }
+            }
+        }
+    }
+}
+
 // Decoder attention, one query per row (AoA_Model.py:329-334 -> :90-120), one wave per (row, head):
 //   s_r = Qp_h . Kd_h[r] / sqrt(d);  P = softmax_R(s);  Pd = drop(P, 0.1);  x_h = sum_r Pd_r Vd_h[r]
 // Kd / Vd: [n_img, R, Hd] (linear_K / linear_V of the refined features, hoisted: time-invariant).
@@ -155,11 +179,7 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restric
     float* sp = sq + d;
     const int img = img_of_row ? img_of_row[row] : row;
     const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
-    for (int i = lane; i < R * d; i += 64) {
-        const int r = i / d, j = i % d;
-        sk[r * ld + j] = Kd[base + (size_t)r * Hd + j];
-        sv[r * ld + j] = Vd[base + (size_t)r * Hd + j];
-    }
+    aoa_stage_kv(Kd + base, Vd + base, sk, sv, R, d, Hd, lane);
     for (int j = lane; j < d; j += 64) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
     __syncthreads();
     float s = -INFINITY;

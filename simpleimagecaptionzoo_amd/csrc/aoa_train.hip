@@ -50,11 +50,7 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
     float* sds = sdx + d;
     float* spd = sds + 64;
     const size_t base = (size_t)row * R * Hd + (size_t)hd * d;
-    for (int i = lane; i < R * d; i += 64) {
-        const int r = i / d, j = i % d;
-        sk[r * ld + j] = Kd[base + (size_t)r * Hd + j];
-        sv[r * ld + j] = Vd[base + (size_t)r * Hd + j];
-    }
+    aoa_stage_kv(Kd + base, Vd + base, sk, sv, R, d, Hd, lane);
     const size_t MN = (size_t)rows * 2 * Hd;
     for (int j = lane; j < d; j += 64) {
         sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
@@ -95,7 +91,7 @@ __global__ __launch_bounds__(256) void aoa_ln_bwd_kernel(const float* __restrict
                                                          const float* __restrict__ x, const float* __restrict__ stats,
                                                          const float* __restrict__ gain, float* __restrict__ dq_tot, float* __restrict__ dx, int n) {
     const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row
     if (row >= rows) return;
     const float mean = stats[2 * row], inv = stats[2 * row + 1];
     const float stdv = 1.0f / inv - 1e-6f;
@@ -381,7 +377,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
                            tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, dKd, dVd, R, Hd, NH, io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
-        hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(cdiv(bt, 4)), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
+        hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(64), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
                            P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
         LstmBwdArgs a = {};
         a.dh_a = bnext ? X + Hd : nullptr; a.ns_a = nsx; a.lda_a = 2 * Hd; a.rows_a = bnext;
