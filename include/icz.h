@@ -281,6 +281,9 @@ size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
  * pair; end synchronises on them and reports the average duration [us] and the ALGORITHMIC bytes / flops per launch
  * (A read once + W read once + C written once; 2MNK). */
 int icz_prof_begin(void);
+/* Average time [us] of an event pair around an EMPTY kernel on `stream` (n pairs): what the pair itself and the dispatch
+ * of the bracketed kernel add to every duration icz_prof_end reports. */
+int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us);
 int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches);
 
 #ifdef __cplusplus

@@ -154,6 +154,7 @@ def lib():
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
+        "icz_prof_pair_overhead": (C.c_int, [vp, i32, C.POINTER(C.c_double)]),
         "icz_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
         "icz_adam_clamp_multi": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, i32, vp]),
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),

@@ -845,9 +845,37 @@ int gemm_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_la
     return ICZ_OK;
 }
 
+__global__ void prof_null_kernel(int* p) { if (p) *p = 0; }
+
+// What an event pair costs by itself: the average pair time around an empty one-thread kernel on `stream`, launched after
+// another kernel like the timed GEMMs are (the gap between the two records holds the dispatch of the bracketed kernel).
+int gemm_prof_pair_overhead(hipStream_t stream, int n, double* avg_us) {
+    if (n < 1) n = 1;
+    if (n > 256) n = 256;
+    std::vector<hipEvent_t> ev(2 * n);
+    for (auto& e : ev) ICZ_CHECK_HIP(hipEventCreate(&e));
+    for (int i = 0; i < n; ++i) {
+        hipLaunchKernelGGL(prof_null_kernel, dim3(256), dim3(256), 0, stream, (int*)nullptr);     // predecessor on the stream
+        ICZ_CHECK_HIP(hipEventRecord(ev[2 * i], stream));
+        hipLaunchKernelGGL(prof_null_kernel, dim3(1), dim3(1), 0, stream, (int*)nullptr);
+        ICZ_CHECK_HIP(hipEventRecord(ev[2 * i + 1], stream));
+    }
+    double tot = 0.0;
+    for (int i = 0; i < n; ++i) {
+        ICZ_CHECK_HIP(hipEventSynchronize(ev[2 * i + 1]));
+        float ms = 0.f;
+        ICZ_CHECK_HIP(hipEventElapsedTime(&ms, ev[2 * i], ev[2 * i + 1]));
+        tot += ms;
+    }
+    for (auto& e : ev) (void)hipEventDestroy(e);
+    if (avg_us) *avg_us = tot * 1e3 / n;
+    return ICZ_OK;
+}
+
 }  // namespace icz
 
 extern "C" {
+int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us) { return icz::gemm_prof_pair_overhead((hipStream_t)stream, n, avg_us); }
 int icz_prof_begin(void) { icz::gemm_prof_begin(); return ICZ_OK; }
 int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
     return icz::gemm_prof_end(avg_us, bytes_per_launch, flops_per_launch, launches);
