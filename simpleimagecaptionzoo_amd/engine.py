@@ -243,6 +243,10 @@ class BUTDDetection_Eng(Engine):
             w.wait()
         self._pending = []
 
+    def _features(self, visual_inputs):
+        """The device tensor the decoder handle consumes (bottom-up features here; NIC: the image embedding)."""
+        return visual_inputs["bu_feats"]
+
     def _trainable(self):
         """name -> parameter for everything the optimizer updates (AoA: the decoder only, AoA_Model.py:669-674)."""
         return getattr(self.model, "_trainable", self.model._named)()
@@ -293,7 +297,7 @@ class BUTDDetection_Eng(Engine):
             lengths = [cap_len - 1 for cap_len in lengths]
             h = self.model._handle()
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
-            h.xe_forward(visual_inputs["bu_feats"], captions, lengths, rng, train=True)
+            h.xe_forward(self._features(visual_inputs), captions, lengths, rng, train=True)
             grads = self._grads()
             n_tok = float(sum(lengths))
             n_glob = icz_dist.all_reduce_scalar(n_tok) if icz_dist.is_distributed() else 0.0
@@ -320,7 +324,7 @@ class BUTDDetection_Eng(Engine):
         losses = []
         for batch_i, (img_ids, img_tensors, img_gts, supp_info_datas) in enumerate(monitor):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
-            feats = visual_inputs["bu_feats"]
+            feats = self._features(visual_inputs)
             h = self._hot_handle()
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
             greedy_res, seq_gen, seq_logprobs = h.rollouts(feats, 20, rng)
@@ -354,11 +358,11 @@ class BUTDDetection_Eng(Engine):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
             h = self._hot_handle()
             if eval_beam_size != -1:
-                seqs, lens = h.beam_search(visual_inputs["bu_feats"], eval_beam_size, 50)
+                seqs, lens = h.beam_search(self._features(visual_inputs), eval_beam_size, 50)
                 seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
                 rows = [seqs[i, :lens[i]] for i in range(len(lens))]
             else:
-                rows = list(h.greedy(visual_inputs["bu_feats"], 20).cpu().numpy())
+                rows = list(h.greedy(self._features(visual_inputs), 20).cpu().numpy())
             for image_idx, sampled_ids in enumerate(rows):
                 sampled_caption = []
                 for word_id in sampled_ids:
@@ -381,6 +385,27 @@ class AoADetection_Eng(BUTDDetection_Eng):
         return AoADetection_Captioner(vocab_size=len(self.caption_vocab), num_heads=s.get("num_heads", 8), hidden_dim=s["hidden_dim"],
                                       embed_dim=s["embed_dim"], device=str(self.device), num_regions=s.get("num_regions", 36),
                                       enc_dim=s.get("enc_dim", 2048), max_batch=max_batch)
+
+
+class NIC_Eng(BUTDDetection_Eng):
+    """ModelEngines/NIC_Engine.py (= the base Engine) with the three hot methods on the NIC decoder handle.  The CNN encoder +
+    img_embedding of NIC_Model.py:8-37 is outside the path: batches carry the image embedding -- `supp_info_datas =
+    {'img_feats': (B, embed_dim) tensor}` -- or the Captioner was given an `encoder` module for `img_tensors`."""
+
+    def model_construction(self, max_batch):
+        from .nic import NICDecoder_Captioner
+        s = self.settings
+        assert s["model_type"] == "NIC"
+        return NICDecoder_Captioner(embed_dim=s["embed_dim"], hidden_dim=s["hidden_dim"], vocab_size=len(self.caption_vocab),
+                                    device=str(self.device), max_batch=max_batch)
+
+    def modify_visual_inputs(self, img_tensors, supp_info_datas=None):
+        if isinstance(supp_info_datas, dict) and torch.is_tensor(supp_info_datas.get("img_feats")):
+            return {"img_feats": supp_info_datas["img_feats"].to(self.device, torch.float32)}
+        return {"img_tensors": img_tensors.to(self.device)}            # Engine.py:32-41
+
+    def _features(self, visual_inputs):
+        return self.model._features(visual_inputs).detach().contiguous()
 
 
 class BUTDSpatial_Eng(BUTDDetection_Eng):

@@ -15,6 +15,7 @@ class NicHandle:
         self.device = torch.device(device)
         self._h = C.c_void_p()
         self._params = None
+        self._persistent = False
         with torch.cuda.device(self.device):
             check(lib().icz_nic_create(C.byref(NicDims(E, H, V, max_rows, max_len)), C.byref(self._h)))
 
@@ -28,6 +29,19 @@ class NicHandle:
             self.close()
         except Exception:
             pass
+
+    def enable_graphs(self, on):      # the NIC paths are launched eagerly
+        self._persistent = bool(on)
+
+    def rollouts(self, feats, max_len=20, rng=None):
+        """Greedy baseline (eval mode) then the sampled rollout (train mode): Engine.py:256-261."""
+        greedy = self.greedy(feats, max_len)
+        seq, lp = self.sample(feats, max_len, rng)
+        return greedy, seq, lp
+
+    def sample_mask_sum(self):
+        seq = self._live[2]
+        return float((seq[:, :-1] > 0).sum().item() + seq.shape[0])
 
     def bind(self, tensors):
         st = NicParams()
@@ -169,6 +183,10 @@ class NICDecoder_Captioner(nn.Module):
         else:
             self._h.refresh()
         return self._h
+
+    def _next_rng(self):
+        self._seed += 1
+        return make_rng(self._seed)
 
     def _features(self, visual_inputs):
         if "img_feats" in visual_inputs:

@@ -101,3 +101,38 @@ def test_nic_captioner_state_dict_keys(golden_dir):
     cap.eval()
     ids = cap.sampler({"img_feats": torch.tensor(g["feats"], device="cuda")}, 20)
     assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])
+
+
+def test_nic_engine_xe_step_and_scst(golden_dir):
+    """NIC_Eng: one training_epoch step = golden XE gradients -> clamp 0.1 -> Adam (oracle restatement); an SCST step and the
+    evaluation JSON run on the device."""
+    from oracle.butd import Adam
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import NIC_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    g = load(golden_dir, "nic_dec_tiny")
+    B, H, E, V = [int(x) for x in g["dims"]]
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    gts = synthetic_references(B, words, seed=5)
+    eng = NIC_Eng({"model_type": "NIC", "embed_dim": E, "hidden_dim": H}, "SYN", vocab, data_dir="/tmp/", device="cuda:0",
+                  cider_df=document_frequency(gts), max_batch=8)
+    sd0 = {"decoder." + k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")}
+    eng.model.load_state_dict(sd0, strict=True)
+    feats = torch.tensor(g["feats"], device="cuda")
+    lr = 4e-4
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": lr}), lr)
+    rng = make_rng(0, None, None, None, torch.tensor(g["xe_out_mask"], device="cuda"))
+    batch = (tuple(range(B)), None, torch.tensor(g["xe_captions"]), [int(x) + 1 for x in g["xe_lengths"]], {"img_feats": feats})
+    losses = eng.training_epoch([batch], opt, type("C", (), {"smoothing": 0.1})(), tqdm_visible=False, rngs=[rng])
+    assert abs(losses[0].item() - float(g["xe_loss"])) < 1e-4
+    want = {k: v.clone() for k, v in sd0.items()}
+    Adam(want, lr).step({k: torch.tensor(g["xe_grad." + k[len("decoder."):]]) for k in want}, 0.1)
+    for k, v in eng.model.state_dict().items():
+        np.testing.assert_allclose(v.cpu().numpy(), want[k].numpy(), atol=2e-5, rtol=0, err_msg=k)
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    losses = eng.SCST_training_epoch([(tuple(range(B)), None, gts, {"img_feats": feats})], opt, None, tqdm_visible=False)
+    assert np.isfinite(losses[0].item())
+    res = eng.eval_captions_json_generation([(tuple(range(B)), None, {"img_feats": feats})], eval_beam_size=3, tqdm_visible=False)
+    assert len(res) == B and all(isinstance(r["caption"], str) for r in res)
