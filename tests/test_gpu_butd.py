@@ -218,3 +218,50 @@ def test_graph_replay_equals_eager_and_reseeds(golden_dir):
     assert torch.equal(r[0][1], r[1][1]) and torch.equal(r[0][2], r[1][2])      # same seed -> same rollout
     assert not torch.equal(r[0][2], r[2][2])                                    # new seed -> new rollout
     assert np.array_equal(r[0][0].numpy(), g["greedy_ids"])
+
+
+def test_edge_cases_single_row_single_step_and_argument_errors(golden_dir):
+    """Smallest shapes (one image, one step, beam of one) against the oracle, and the C ABI's argument checks."""
+    from simpleimagecaptionzoo_amd._lib import IczError
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    g = load(golden_dir, "butd_dec_tiny")
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    h, params = make_handle(g, max_rows=8)
+    p_cpu = {k: v.detach().cpu() for k, v in params.items()}
+    feats = torch.tensor(g["feats"], device="cuda")
+    one = feats[:1]
+    # one image, one step
+    ids = h.greedy(one, 1)
+    want, _, _ = ob.greedy(one.cpu(), p_cpu, 1)
+    assert ids.shape == (1, 1) and np.array_equal(ids.cpu().numpy(), want.numpy())
+    # one image, full length == row 0 of the batched decode (rows are independent)
+    assert np.array_equal(h.greedy(one, 20).cpu().numpy(), g["greedy_ids"][:1])
+    # beam of one, one step: <sta> + the greedy token
+    seqs, lens = h.beam_search(one, 1, 1)
+    assert int(lens[0]) == 2 and seqs[0, :2].cpu().tolist() == [1.0, float(g["greedy_ids"][0, 0])]
+    # teacher forcing with every caption of length 1 (a single time step, all rows active)
+    caps = torch.tensor([[1, 7, 2]] * B, device="cuda")
+    logits = h.xe_forward(feats, caps, [1] * B, None, train=False, want_logits=True)
+    want = ob.forward_xe(feats.cpu(), caps.cpu(), [1] * B, p_cpu)
+    np.testing.assert_allclose(logits.cpu().numpy(), want.numpy(), atol=1e-4)
+    grads = h.new_grads()
+    loss = h.xe_backward(grads, 0.1)
+    assert np.isfinite(loss.item()) and all(torch.isfinite(v).all() for v in grads.values())
+    # sampled rollout of a single step
+    seq, lp = h.sample(one, 1, make_rng(3))
+    assert seq.shape == (1, 1) and float(lp[0, 0]) <= 0.0
+    # argument checks: nothing is clamped or silently truncated
+    with pytest.raises(IczError):
+        h.greedy(torch.zeros(9, R, D, device="cuda"), 20)                   # more rows than the handle's capacity
+    with pytest.raises(IczError):
+        h.greedy(torch.zeros(2, R + 1, D, device="cuda"), 20)               # wrong region count
+    with pytest.raises(IczError):
+        h.greedy(feats.double(), 20)                                        # wrong dtype
+    with pytest.raises(IczError):
+        h.beam_search(feats, 9, 20)                                         # beam wider than BEAM_MAX_K
+    with pytest.raises(IczError):
+        h.xe_forward(feats, torch.tensor([[1, 5, 6, 2]] * B, device="cuda"), [1, 2, 2, 1, 1][:B], None, train=False)   # lengths not sorted
+    h.sample(one, 1, make_rng(3))
+    h.sample_backward(torch.zeros(1, 1, device="cuda"), h.new_grads())
+    with pytest.raises(IczError):
+        h.sample_backward(torch.zeros(1, 1, device="cuda"), h.new_grads())     # the stored rollout was consumed
