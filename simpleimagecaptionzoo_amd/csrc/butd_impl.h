@@ -41,7 +41,7 @@ struct TrainBuf {
     int32_t* draw = nullptr; float* lse = nullptr;
     uint8_t* unf = nullptr; int* nunf = nullptr; float *coef = nullptr, *loss_rows = nullptr;
     float *dGtd = nullptr, *dGlm = nullptr, *dDec = nullptr, *dEmb = nullptr, *dH2d = nullptr, *dEnc = nullptr;
-    float *dwaff = nullptr, *ddec_part = nullptr, *dalpha = nullptr, *dS = nullptr, *dGsum = nullptr;
+    float *dwaff = nullptr, *dalpha = nullptr, *dS = nullptr, *dGsum = nullptr;
     float *dc1[2] = {nullptr, nullptr}, *dc2[2] = {nullptr, nullptr};
     float* X[4] = {nullptr, nullptr, nullptr, nullptr}; size_t xfloats = 0;
     float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;

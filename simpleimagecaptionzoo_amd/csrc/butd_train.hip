@@ -56,7 +56,6 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dH2d, sizeof(float) * TB * H));
     ICZ_TRY(zalloc((void**)&tb.dEnc, sizeof(float) * (size_t)B * R * A));
     ICZ_TRY(zalloc((void**)&tb.dwaff, sizeof(float) * (size_t)B * ATT_PARTS * A));
-    ICZ_TRY(zalloc((void**)&tb.ddec_part, sizeof(float) * (size_t)B * ATT_PARTS * A));
     ICZ_TRY(zalloc((void**)&tb.dalpha, sizeof(float) * (size_t)B * R));
     ICZ_TRY(zalloc((void**)&tb.dS, sizeof(float) * TB * R));
     ICZ_TRY(zalloc((void**)&tb.dGsum, sizeof(float) * (size_t)B * 4 * H));
