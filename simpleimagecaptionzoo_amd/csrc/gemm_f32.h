@@ -7,18 +7,22 @@
 //   NN  (dgrad):    A_s(m,k) = dY[m*lda + k],  B_s(k,n) = W[k*ldw + n]     dx = dy W
 //   TN  (wgrad):    A_s(m,k) = dY[k*lda + m],  B_s(k,n) = X[k*ldw + n]     dW = dy^T x
 //
-// Tiling: one 256-thread workgroup = 4 waves computes a 64 x 64 tile of C over a contiguous range of
-// 64-deep K chunks (split-K over blockIdx.z).  Wave w owns columns [16w, 16w+16) and all 64 rows
-// (MT = 4 row tiles of 16) -> 4 independent 16x16 accumulators per wave, which is what the 16x16x4 f32
+// Tiling: one 256-thread workgroup = 4 waves computes a 64 x 64 tile of C over a contiguous range of K stages
+// (split-K over blockIdx.z; stage depth 128, or 64 for short / ragged K).  NT: wave w owns columns [16w, 16w+16) and
+// all 64 rows (MT = 4 row tiles of 16) -> 4 independent 16x16 accumulators per wave, which is what the 16x16x4 f32
 // MFMA needs to issue back to back (40-cycle dependent latency vs 32-cycle issue).
-//   * the A chunk (64 rows x 64 k, shared by the 4 waves) is staged through LDS, row stride 72 dwords:
-//     with that stride the A-fragment ds_read_b128 (lane (i,q) reads row i, dwords 16s+4q..+3) is
-//     conflict-free in every one of the instruction's four 16-lane groups;
-//   * the B operand is streamed straight into registers (each wave reads only its own 16 columns; for NT
-//     that is the weight matrix, read exactly once from HBM per workgroup row) -- LDS would be a pure
-//     round trip for it;
-//   * next chunk's global loads are issued before the current chunk's MFMAs (register double buffer for
-//     B, LDS double buffer for A, one barrier per chunk).
+//   * the A stage (64 rows x BK, shared by the 4 waves) is staged through LDS, row stride BK + 8 dwords (the A-fragment
+//     ds_read_b128 of lane (i,q) reads row i, dwords 16s+4q..+3);
+//   * the B operand is streamed straight into registers (each wave reads only its own 16 columns; for NT that is the
+//     weight matrix, read exactly once per workgroup row) -- LDS would be a pure round trip for it;
+//   * the next stage's global loads are in flight behind the current stage's MFMAs (register double buffer for B, LDS
+//     double buffer for A, one barrier per stage); fragment reads from LDS run one or two k-steps ahead of their MFMAs,
+//     pinned with scheduling fences.  At the decoder-step shape (M <= 64: one workgroup per CU, all in lockstep) the
+//     weight loads are issued one per k-group instead of in one burst at the top of the stage, which otherwise leaves
+//     the fabric idle while the matrix pipe runs (NT and NN).
+//   * NN mirrors NT (the weight tile goes through LDS, interleaved column tiles); TN streams both operands as float4
+//     along their output index (2 loads -> 16 MFMAs), and for large outputs uses a 128 x 128 tile with both operand
+//     tiles in LDS (half the operand bytes per MFMA).
 // Split-K partials go to slabs [z][M][N]; the consumer kernels (LSTM pointwise, attention, argmax ...) sum
 // the slabs in fixed z order, so results are bitwise reproducible run to run (no float atomics).
 #pragma once
@@ -28,7 +32,6 @@ namespace icz {
 
 constexpr int GEMM_MAX_SEG = 4;
 constexpr int GEMM_BM = 64, GEMM_BN = 64, GEMM_BK = 64;
-constexpr int GEMM_LDS_STRIDE = 72;   // dwords per staged A row (64 + 8 pad)
 
 enum GemmLayout { GEMM_NT = 0, GEMM_NN = 1, GEMM_TN = 2 };
 
