@@ -193,7 +193,8 @@ def main():
     traffic = None
     try:
         pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")))
-        traffic = [v["hbm_bytes_per_launch"] for k, v in pmc["kernels"].items() if "gemm_nt_kernel" in k][0]
+        nt = [v for k, v in pmc["kernels"].items() if "gemm_nt_kernel" in k]
+        traffic = max(nt, key=lambda v: v["launches"])["hbm_bytes_per_launch"]      # the decoder-step instantiation
     except Exception:
         pass
     out = {
