@@ -7,8 +7,8 @@ features are packed once into one flat, memory-mapped fp32 file and streamed to 
 
   pack_npz_dir()        per-image .npz (+ .npy boxes)  ->  <name>.feats.npy ([N, R, D] fp32, uncompressed) + <name>.index.json
   PackedFeatureStore    memory-mapped rows by image id (no decompression, no per-file open)
-  DevicePrefetcher      wraps any iterable of the reference's batch tuples: batch i+1 is gathered into a pinned buffer and
-                        copied on a side stream while batch i is being decoded; it yields the same tuples with
+  DevicePrefetcher      wraps any iterable of the reference's batch tuples: a worker thread gathers batch i+1 into a pinned
+                        buffer and copies it on a side stream while batch i is being decoded; it yields the same tuples with
                         `supp_info_datas` replaced by {'bu_feats': device tensor, 'bu_bboxes': [...]}, which the Engines'
                         `modify_visual_inputs` passes through unchanged.
 The bytes are the reference's (fp32, no re-quantisation), so results do not change.  Fixed 36-region features only.
@@ -112,28 +112,57 @@ class DevicePrefetcher:
         return batch[:-1] + ({"bu_feats": self._dev[slot][:B], "bu_bboxes": boxes},)
 
     def __iter__(self):
-        it = iter(self.loader)
-        queue = []
-        slot = 0
-        try:
-            for _ in range(self.depth - 1):
-                queue.append((slot, self._stage(slot, next(it))))
-                slot = (slot + 1) % self.depth
-        except StopIteration:
-            pass
-        while queue:
-            cur_slot, out = queue.pop(0)
+        """Batches are staged by a worker thread (the gather is a numpy copy that releases the GIL) up to depth - 1 ahead of
+        the consumer, so neither the copy into pinned memory nor the H2D transfer delays the consumer's kernel launches."""
+        import queue
+        import threading
+        todo = queue.Queue(maxsize=self.depth - 1)
+        stop = threading.Event()
+        released = [threading.Event() for _ in range(self.depth)]      # slot handed back by the consumer (host side)
+        for e in released:
+            e.set()
+
+        def worker():
             try:
-                queue.append((slot, self._stage(slot, next(it))))
-                slot = (slot + 1) % self.depth
-            except StopIteration:
-                pass
-            torch.cuda.current_stream(self.device).wait_event(self._ready[cur_slot])
-            yield out
-            # everything the consumer queued on its stream so far must finish before the slot is overwritten
-            done = torch.cuda.Event()
-            done.record(torch.cuda.current_stream(self.device))
-            self._free[cur_slot] = done
+                torch.cuda.set_device(self.device)
+                slot = 0
+                for batch in self.loader:
+                    while not released[slot].wait(timeout=0.05):
+                        if stop.is_set():
+                            return
+                    if stop.is_set():
+                        return
+                    released[slot].clear()
+                    todo.put((slot, self._stage(slot, batch), None))
+                    slot = (slot + 1) % self.depth
+                todo.put((None, None, None))
+            except BaseException as e:      # surfaced in the consumer thread
+                todo.put((None, None, e))
+
+        th = threading.Thread(target=worker, daemon=True)
+        th.start()
+        try:
+            while True:
+                slot, out, err = todo.get()
+                if err is not None:
+                    raise err
+                if out is None:
+                    break
+                torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
+                yield out
+                # everything the consumer queued on its stream so far must finish before the slot is overwritten
+                done = torch.cuda.Event()
+                done.record(torch.cuda.current_stream(self.device))
+                self._free[slot] = done
+                released[slot].set()
+        finally:
+            stop.set()
+            while th.is_alive():            # unblock a worker waiting on the bounded queue
+                try:
+                    todo.get_nowait()
+                except queue.Empty:
+                    pass
+                th.join(timeout=0.05)
 
     def __len__(self):
         return len(self.loader)
