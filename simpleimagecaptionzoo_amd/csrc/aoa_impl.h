@@ -67,7 +67,10 @@ struct Aoa {
     const int64_t* cur_captions = nullptr;
     std::vector<int> rows_t;
 
-    ~Aoa() { for (void* p : allocs) (void)hipFree(p); }
+    ~Aoa() {
+        if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
+        for (void* p : allocs) (void)hipFree(p);
+    }
     int alloc(void** p, size_t bytes) {
         ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
         ICZ_CHECK_HIP(hipMemset(*p, 0, bytes ? bytes : 16));

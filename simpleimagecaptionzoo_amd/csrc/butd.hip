@@ -77,6 +77,7 @@ Butd::~Butd() {
     if (ev_join) (void)hipEventDestroy(ev_join);
     for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
     if (cap_st) (void)hipStreamDestroy(cap_st);
+    if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
     for (void* p : allocs) (void)hipFree(p);
 }
 
