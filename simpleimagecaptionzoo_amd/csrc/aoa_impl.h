@@ -31,7 +31,7 @@ struct AoaStepIO {
 };
 
 struct Aoa {
-    static constexpr int STEP_WGS = 256, TARGET_WGS = 512, ARGMAX_PARTS = 8, COLSUM_PARTS = 64, NL = 6;
+    static constexpr int STEP_WGS = 256, TARGET_WGS = 512, ARGMAX_PARTS = 8, NL = 6;
     icz_aoa_dims dims;
     icz_aoa_params P;
     bool bound = false, fresh = false;
@@ -57,7 +57,7 @@ struct Aoa {
           *tQp = nullptr, *tP = nullptr, *tPd = nullptr, *txatt = nullptr, *tz = nullptr, *tcd = nullptr, *tlogit = nullptr;
     float *dCd = nullptr, *dZ = nullptr, *dQp = nullptr, *dQn = nullptr, *dHln = nullptr, *dG = nullptr, *dEmb = nullptr, *dKd = nullptr,
           *dVd = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *X2 = nullptr, *dWp = nullptr, *prod = nullptr;
-    float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr, *colsum_part = nullptr;
+    float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr;
     int32_t* draw = nullptr; uint8_t* unf = nullptr; int* nunf = nullptr; int* pack_idx = nullptr;
     size_t xfloats = 0;
     icz_aoa_rng rng = {};

@@ -170,7 +170,6 @@ int Aoa::ensure_train() {
     ICZ_TRY(alloc((void**)&dHln, sizeof(float) * B * Hd));
     ICZ_TRY(alloc((void**)&dcb[0], sizeof(float) * B * Hd));
     ICZ_TRY(alloc((void**)&dcb[1], sizeof(float) * B * Hd));
-    const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
     xfloats = (size_t)TARGET_WGS * 4096 * 2 + TB * (Hd > E ? Hd : E) + B * 4 * Hd;
     ICZ_TRY(alloc((void**)&X, sizeof(float) * xfloats));
     ICZ_TRY(alloc((void**)&X2, sizeof(float) * xfloats));
@@ -182,7 +181,6 @@ int Aoa::ensure_train() {
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
-    ICZ_TRY(alloc((void**)&colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
     tready = true;
     return ICZ_OK;
 }
@@ -307,12 +305,7 @@ int Aoa::xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, 
 }
 
 int Aoa::colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st) {
-    int KS = cdiv(K, 16);
-    if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
-    const int rows_per = cdiv(K, KS);
-    KS = cdiv(K, rows_per);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), KS), dim3(256), 0, st, Xm, K, N, ldx, rows_per, colsum_part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, colsum_part, KS, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, st, Xm, K, N, ldx, out);
     return ICZ_OK;
 }
 

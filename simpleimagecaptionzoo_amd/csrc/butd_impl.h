@@ -46,8 +46,6 @@ struct TrainBuf {
     float* X[4] = {nullptr, nullptr, nullptr, nullptr}; size_t xfloats = 0;
     float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;
     int* scalars_i = nullptr; int scalars_i_cap = 0;
-    float* colsum_part = nullptr;
-    float* colsum_part2 = nullptr;     // for the predict-bias colsum on the side stream
 };
 
 struct BeamBuf {
@@ -64,7 +62,6 @@ struct Butd {
     static constexpr int ATT_PARTS = 4;
     static constexpr int STEP_WGS = 256;     // skinny decoder-step GEMMs: split-K for ~1 workgroup per CU
     static constexpr int ARGMAX_PARTS = 8;
-    static constexpr int COLSUM_PARTS = 64;
     icz_butd_dims dims;
     icz_butd_params P;
     bool bound = false, fresh = false;

@@ -823,24 +823,34 @@ __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// out[n] = sum_k X[k, n] (column sums over K rows; bias gradients), two stages, fixed order -> reproducible:
-// stage 1: grid (N/256, KS) -- block (x, y) sums rows [y*rows_per, (y+1)*rows_per) of its 256 columns into part[y, n];
-// stage 2: out[n] = sum_y part[y, n].
-__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int K, int N, int ldx, int rows_per,
-                                                          float* __restrict__ part) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    const int k0 = blockIdx.y * rows_per, k1 = min(K, k0 + rows_per);
+// out[n] = sum_k X[k, n] (column sums over K rows; bias gradients) in one launch, fixed order -> reproducible.
+// Grid (N/32), 256 threads = 32 columns x 8 row groups: thread (c, g) adds rows g, g+8, ... of its column (eight independent
+// loads in flight), the eight groups meet in LDS and are added in group order.
+__global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X, int K, int N, int ldx, float* __restrict__ out) {
+    __shared__ float part[8][33];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     float s = 0.f;
-    for (int k = k0; k < k1; ++k) s += X[(size_t)k * ldx + n];
-    part[(size_t)blockIdx.y * N + n] = s;
-}
-__global__ __launch_bounds__(256) void colsum_final_kernel(const float* __restrict__ part, int KS, int N, float* __restrict__ out) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float s = 0.f;
-    for (int y = 0; y < KS; ++y) s += part[(size_t)y * N + n];
-    out[n] = s;
+    if (n < N) {
+        const float* x = X + n;
+        int k = g;
+        for (; k + 56 < K; k += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(k + 8 * u) * ldx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; k < K; k += 8) s += x[(size_t)k * ldx];
+    }
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < N) {
+        float t = part[0][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][c];
+        out[n] = t;
+    }
 }
 
 // out[b, n] = sum_t X[t, b, n]   (time sum of the TD gate gradients for the hoisted mean-feature weights)

@@ -70,12 +70,6 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dWdec, sizeof(float) * A * H));
     ICZ_TRY(zalloc((void**)&tb.dWaff, sizeof(float) * A));
     ICZ_TRY(zalloc((void**)&tb.scalars, sizeof(float) * 16));
-    {
-        size_t nmax = Vp > 4 * H ? Vp : 4 * H;
-        if (A > nmax) nmax = A;
-        ICZ_TRY(zalloc((void**)&tb.colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
-        ICZ_TRY(zalloc((void**)&tb.colsum_part2, sizeof(float) * COLSUM_PARTS * nmax));
-    }
     (void)V;
     tb.B = B;
     tb.T = T;
@@ -398,12 +392,7 @@ int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N,
 }
 
 int Butd::colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st) {
-    int KS = cdiv(K, 16);
-    if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
-    const int rows_per = cdiv(K, KS);
-    KS = cdiv(K, rows_per);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), KS), dim3(256), 0, st, X, K, N, ldx, rows_per, tb.colsum_part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, tb.colsum_part, KS, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, st, X, K, N, ldx, out);
     return ICZ_OK;
 }
 
@@ -431,13 +420,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
     {
         hipStream_t sb = concurrent ? low_st : st;   // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
         int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb);
-        // colsum scratch is shared with the main chain's later colsums: use the tail of dWp's neighbour? no -- a private one
-        int KS = cdiv(TB, 16);
-        if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
-        const int rows_per = cdiv(TB, KS);
-        KS = cdiv(TB, rows_per);
-        hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(V, 256), KS), dim3(256), 0, sb, tb.logit, TB, V, Vp, rows_per, tb.colsum_part2);
-        hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(V, 256)), dim3(256), 0, sb, tb.colsum_part2, KS, V, G.predict_b);
+        hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 32)), dim3(256), 0, sb, tb.logit, TB, V, (int)Vp, G.predict_b);
         hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, sb, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
                            G.predict_v, G.predict_g, V, H);
         ICZ_CHECK_HIP(hipEventRecord(ev_join, sb));

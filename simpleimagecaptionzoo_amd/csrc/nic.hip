@@ -11,7 +11,7 @@
 namespace icz {
 
 struct Nic {
-    static constexpr int STEP_WGS = 256, TARGET_WGS = 512, ARGMAX_PARTS = 8, COLSUM_PARTS = 64;
+    static constexpr int STEP_WGS = 256, TARGET_WGS = 512, ARGMAX_PARTS = 8;
     icz_nic_dims dims;
     icz_nic_params P;
     bool bound = false, fresh = false;
@@ -30,7 +30,7 @@ struct Nic {
     int64_t* tok = nullptr;
     float *th = nullptr, *tc = nullptr, *temb = nullptr, *tg = nullptr, *thd = nullptr, *tlogit = nullptr;
     float *dG = nullptr, *dHd = nullptr, *dEmb = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *dWp = nullptr;
-    float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr, *colsum_part = nullptr;
+    float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr;
     int32_t* draw = nullptr; uint8_t* unf = nullptr; int* nunf = nullptr; int* pack_idx = nullptr;
     size_t xfloats = 0;
     BeamBuf bm;
@@ -186,8 +186,6 @@ int Nic::ensure_train() {
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
-    const size_t nmax = 4 * H > (size_t)Vp ? 4 * H : (size_t)Vp;
-    ICZ_TRY(alloc((void**)&colsum_part, sizeof(float) * COLSUM_PARTS * nmax));
     tready = true;
     return ICZ_OK;
 }
@@ -321,12 +319,7 @@ int Nic::xe_backward(float smoothing, const icz_nic_params* G, float* dfeats, fl
 }
 
 int Nic::colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st) {
-    int KS = cdiv(K, 16);
-    if (KS > COLSUM_PARTS) KS = COLSUM_PARTS;
-    const int rows_per = cdiv(K, KS);
-    KS = cdiv(K, rows_per);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3(cdiv(N, 256), KS), dim3(256), 0, st, Xm, K, N, ldx, rows_per, colsum_part);
-    hipLaunchKernelGGL(colsum_final_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, colsum_part, KS, N, out);
+    hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(N, 32)), dim3(256), 0, st, Xm, K, N, ldx, out);
     return ICZ_OK;
 }
 
