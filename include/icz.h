@@ -76,6 +76,9 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
  *   stage 2: language_model.weight_{ih,hh};  everything else is complete when the call returns.
  * The host side starts the all-reduce of that group on the same stream (it then runs beside the remaining weight-gradient
  * GEMMs).  NULL removes the hook. */
+/* Data-parallel: the global (all-reduced) mask sum as a DEVICE scalar, so that no host round trip separates the rollout
+ * from the backward pass; then call icz_butd_sample_backward with mask_sum_global < 0 ("use the device value"). */
+int icz_butd_set_mask_sum_global(icz_butd_t* h, const float* mask_sum_global_dev, void* stream);
 typedef void (*icz_grad_ready_cb)(void* user, int32_t stage);
 int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user);
 /* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */

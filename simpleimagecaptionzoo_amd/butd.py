@@ -137,6 +137,10 @@ class ButdHandle:
         check(lib().icz_butd_sample_mask_sum(self._h, ptr(out), stream_ptr()))
         return out
 
+    def set_mask_sum_global(self, t):
+        """DP: hand the all-reduced mask sum over as a 1-element device tensor; then sample_backward(..., mask_sum_global=-1)."""
+        check(lib().icz_butd_set_mask_sum_global(self._h, ptr(t), stream_ptr()))
+
     def sample_backward(self, reward, grads, mask_sum_global=0.0):
         """RewardCriterion + backward (Utils.py:295-317) for the last sample(); fills `grads`; returns
         (loss, local mask sum) as 1-element device tensors."""

@@ -299,6 +299,13 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
     return ICZ_ERR_INVALID;
 }
 
+int icz_butd_set_mask_sum_global(icz_butd_t* h, const float* mask_sum_global_dev, void* stream) {
+    ICZ_REQUIRE(h && mask_sum_global_dev, "icz_butd_set_mask_sum_global: null argument");
+    Butd* b = reinterpret_cast<Butd*>(h);
+    ICZ_CHECK_HIP(hipMemcpyAsync(b->d_msum_global, mask_sum_global_dev, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ICZ_OK;
+}
+
 int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user) {
     ICZ_REQUIRE(h, "null handle");
     Butd* b = reinterpret_cast<Butd*>(h);

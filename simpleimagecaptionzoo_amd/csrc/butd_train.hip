@@ -211,7 +211,8 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
                           float mask_sum_global, hipStream_t st) {
     ICZ_REQUIRE(mode == 1, "butd: no rollout stored (call icz_butd_sample first)");
     ICZ_REQUIRE(reward && G, "butd sample_backward: null argument");
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
+    if (mask_sum_global >= 0.f)      // < 0: keep the device value set by icz_butd_set_mask_sum_global
+        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
     mode = 0;   // the saved logits are consumed
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
     // the DP hook must fire on every call (a replayed graph would not call it): backward is enqueued eagerly then

@@ -332,7 +332,14 @@ class BUTDDetection_Eng(Engine):
             grads = self._grads()
             msum_glob = 0.0
             if icz_dist.is_distributed():
-                msum_glob = icz_dist.all_reduce_scalar(h.sample_mask_sum())
+                ms = h.sample_mask_sum()
+                if torch.is_tensor(ms) and hasattr(h, "set_mask_sum_global"):
+                    # all-reduced on the device and handed over as a device scalar: no host round trip before backward
+                    icz_dist.all_reduce_sum_(ms)
+                    h.set_mask_sum_global(ms)
+                    msum_glob = -1.0
+                else:
+                    msum_glob = icz_dist.all_reduce_scalar(ms)
             ov = self._reduce_grads_begin(h)
             loss, _ = h.sample_backward(rewards, grads, msum_glob)
             self._reduce_grads_end(ov)
