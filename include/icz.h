@@ -225,6 +225,9 @@ int icz_aoa_beam_search(icz_aoa_t* h, const float* feats, int32_t n_img, int32_t
                         int32_t* lens_out, void* stream);
 int icz_aoa_sample(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, const icz_aoa_rng* rng, int64_t* seq_out,
                    float* logprobs_out, void* stream);
+/* The two decodes of one SCST step (Engine.py:256-261: greedy in eval mode, sampler_rl in train mode) as concurrent chains. */
+int icz_aoa_scst_rollouts(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, const icz_aoa_rng* rng, int64_t* ids_out,
+                          int64_t* seq_out, float* logprobs_out, void* stream);
 int icz_aoa_sample_backward(icz_aoa_t* h, const float* reward, const icz_aoa_params* grads, float* loss_out, float* mask_sum_out,
                             float mask_sum_global, void* stream);
 int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,

@@ -148,6 +148,7 @@ def lib():
         "icz_aoa_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "icz_aoa_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "icz_aoa_sample": (C.c_int, [vp, vp, i32, i32, C.POINTER(AoaRng), vp, vp, vp]),
+        "icz_aoa_scst_rollouts": (C.c_int, [vp, vp, i32, i32, C.POINTER(AoaRng), vp, vp, vp, vp]),
         "icz_aoa_sample_backward": (C.c_int, [vp, vp, C.POINTER(AoaParams), vp, vp, f32, vp]),
         "icz_aoa_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(AoaRng), i32, vp, vp]),
         "icz_aoa_xe_backward": (C.c_int, [vp, f32, C.POINTER(AoaParams), vp, f32, vp]),

@@ -125,10 +125,17 @@ class AoaHandle:
         return seq, lp
 
     def rollouts(self, feats, max_len=20, rng=None):
-        """Greedy baseline (eval mode) then the sampled rollout (train mode): Engine.py:256-261."""
-        greedy = self.greedy(feats, max_len)
-        seq, lp = self.sample(feats, max_len, rng)
-        return greedy, seq, lp
+        """Greedy baseline (eval mode) and sampled rollout (train mode) of one SCST step, Engine.py:256-261, as two concurrent
+        chains on the device; identical to greedy() followed by sample()."""
+        feats = self._feats(feats)
+        B = feats.shape[0]
+        rng = rng or make_aoa_rng(0)
+        ids = torch.empty(B, max_len, dtype=torch.int64, device=feats.device)
+        seq = torch.zeros(B, max_len, dtype=torch.int64, device=feats.device)
+        lp = torch.zeros(B, max_len, dtype=torch.float32, device=feats.device)
+        check(lib().icz_aoa_scst_rollouts(self._h, ptr(feats), B, max_len, C.byref(rng), ptr(ids), ptr(seq), ptr(lp), stream_ptr()))
+        self._live = (feats, rng, seq, lp)
+        return ids, seq, lp
 
     def sample_mask_sum(self):
         seq = self._live[2]

@@ -25,10 +25,17 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_TRY(alloc((void**)&n_pred, sizeof(float) * d.V));
     ICZ_TRY(alloc((void**)&w_rec, sizeof(float) * 4 * Hd * 2 * Hd));
     ICZ_TRY(alloc((void**)&zeros, sizeof(float) * rows * Hd));
-    float** ref[] = {&xa, &xb, &ln, &q, &k, &v, &o, &od, &nd, &refined, &Kd, &Vd};
-    for (float** p : ref) ICZ_TRY(alloc((void**)p, sizeof(float) * RR * Hd));
-    ICZ_TRY(alloc((void**)&z, sizeof(float) * RR * 2 * Hd));
-    ICZ_TRY(alloc((void**)&meanf, sizeof(float) * rows * Hd));
+    const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
+    ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    for (int b = 0; b < 2; ++b) {
+        Bank& s = bank[b];
+        float** ref[] = {&s.xa, &s.xb, &s.ln, &s.q, &s.k, &s.v, &s.o, &s.od, &s.nd, &s.refined, &s.Kd, &s.Vd};
+        for (float** p : ref) ICZ_TRY(alloc((void**)p, sizeof(float) * RR * Hd));
+        ICZ_TRY(alloc((void**)&s.z, sizeof(float) * RR * 2 * Hd));
+        ICZ_TRY(alloc((void**)&s.meanf, sizeof(float) * rows * Hd));
+        ICZ_TRY(alloc((void**)&s.ws, sizeof(float) * ws_floats));
+    }
+    use_bank(0);
     for (int i = 0; i < 2; ++i) {
         ICZ_TRY(alloc((void**)&h[i], sizeof(float) * rows * Hd));
         ICZ_TRY(alloc((void**)&m[i], sizeof(float) * rows * Hd));
@@ -43,9 +50,6 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_TRY(alloc((void**)&amax_idx, sizeof(int) * rows * ARGMAX_PARTS));
     ICZ_TRY(alloc((void**)&d_seed, 16));
     ICZ_TRY(alloc((void**)&d_msum, 16));
-    const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
-    ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
-    ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
     return ICZ_OK;
 }
 
@@ -199,6 +203,7 @@ static int zero_state(Aoa& a, int rows, hipStream_t st) {
 int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st) {
     ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && T > 0, "aoa greedy: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    use_bank(0);
     ICZ_TRY(refine(feats, B, false, st));
     ICZ_TRY(zero_state(*this, B, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);
@@ -243,6 +248,7 @@ int Aoa::beam_search(const float* feats, int n_img, int kb, int max_steps, float
         bm.cap_rows = (int)R_;
         bm.cap_L = (int)L_;
     }
+    use_bank(0);
     ICZ_TRY(refine(feats, n_img, false, st));
     ICZ_CHECK_HIP(hipMemsetAsync(bm.n_live, 0, sizeof(int) * 260, st));
     ICZ_CHECK_HIP(hipMemsetAsync(bm.run, 0, sizeof(float) * rows, st));
@@ -310,6 +316,7 @@ int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_o
     Aoa* n = reinterpret_cast<Aoa*>(h);
     ICZ_REQUIRE(B > 0 && B <= n->dims.max_rows, "icz_aoa_refine: B out of range");
     ICZ_REQUIRE(n->fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
+    n->use_bank(0);
     ICZ_TRY(n->refine(feats, B, false, (hipStream_t)stream));
     ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, sizeof(float) * (size_t)B * n->dims.R * n->dims.Hd, hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));

@@ -39,7 +39,18 @@ struct Aoa {
     int Vp = 0;
     float *w_pred = nullptr, *n_pred = nullptr, *zeros = nullptr;
     float* w_rec = nullptr;          // [4Hd, 2Hd] = [W_ih[:, E:] | W_hh]: one dgrad GEMM per BPTT step for (du, dh_prev)
-    // refiner scratch / per-image tensors (rows = max_rows * R)
+    // refiner scratch / per-image tensors (rows = max_rows * R).  Two banks: bank 0 serves the evaluation-mode paths (greedy,
+    // beam), bank 1 the training-mode ones (sample, XE, backward), so that the greedy baseline and the sampled rollout of
+    // one SCST step can be in flight together; use_bank() points the members below at a bank before a chain is enqueued.
+    struct Bank { float *xa, *xb, *ln, *q, *k, *v, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; };
+    Bank bank[2] = {};
+    void use_bank(int b) {
+        const Bank& s = bank[b];
+        xa = s.xa; xb = s.xb; ln = s.ln; q = s.q; k = s.k; v = s.v; o = s.o; od = s.od; nd = s.nd; z = s.z;
+        refined = s.refined; meanf = s.meanf; Kd = s.Kd; Vd = s.Vd; ws = s.ws;
+    }
+    hipStream_t side_st = nullptr;
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     float *xa = nullptr, *xb = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
           *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;
     // decoder state + scratch
@@ -68,6 +79,9 @@ struct Aoa {
     std::vector<int> rows_t;
 
     ~Aoa() {
+        if (side_st) (void)hipStreamDestroy(side_st);
+        if (ev_fork) (void)hipEventDestroy(ev_fork);
+        if (ev_join) (void)hipEventDestroy(ev_join);
         if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
         for (void* p : allocs) (void)hipFree(p);
     }
@@ -84,6 +98,7 @@ struct Aoa {
     int refine(const float* feats, int n_img, bool train, hipStream_t st);
     int step(const AoaStepIO& s, hipStream_t st);
     int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
+    int rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
     DropP dropp(bool train, const uint8_t* mask, size_t off, uint32_t stream, int step, float p) const {
         DropP d = {0, nullptr, d_seed, stream, (uint32_t)step, (uint32_t)((double)p * 4294967296.0), 1.0f / (1.0f - p)};

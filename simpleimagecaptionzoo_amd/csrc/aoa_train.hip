@@ -207,6 +207,7 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
     ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0 && T <= dims.max_len, "aoa sample: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     ICZ_TRY(ensure_train());
+    use_bank(1);
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_seq = seq_out; cur_logp = logp_out;
@@ -234,6 +235,23 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
     return ICZ_OK;
 }
 
+// Greedy baseline (evaluation mode, bank 0, side stream) and sampled rollout (training mode, bank 1) of one SCST step
+// (Engine.py:256-261) enqueued as two concurrent chains; identical to greedy() followed by sample().
+int Aoa::rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    if (!side_st) {
+        ICZ_CHECK_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
+    }
+    ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
+    ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
+    const int sg = greedy(feats, B, T, ids_out, side_st);
+    const int ss = sg == ICZ_OK ? sample(feats, B, T, r, seq_out, logp_out, st) : sg;
+    ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));
+    ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+    return ss;
+}
+
 int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st) {
     ICZ_REQUIRE(mode == 1, "aoa: no rollout stored (call icz_aoa_sample first)");
     ICZ_REQUIRE(reward && G, "aoa sample_backward: null argument");
@@ -258,6 +276,7 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
     }
     ICZ_REQUIRE(T <= dims.max_len, "aoa xe_forward: %d steps exceed max_len %d", T, dims.max_len);
     ICZ_TRY(ensure_train());
+    use_bank(1);
     if (r) rng = *r; else rng = {};
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 2; cur_B = B; cur_T = T; cur_L = L; cur_train = train != 0; cur_captions = captions;
@@ -332,6 +351,7 @@ int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, in
 }
 
 int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
+    use_bank(1);
     const int B = cur_B, T = cur_T, Hd = dims.Hd, E = dims.E, V = dims.V, NH = dims.NH, R = dims.R, dh = Hd / NH;
     const int TB = T * B;
     const size_t sH = (size_t)B * Hd;
@@ -430,6 +450,11 @@ int icz_aoa_sample(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len,
                    float* logprobs_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Aoa*>(h)->sample(feats, B, max_len, rng, seq_out, logprobs_out, (hipStream_t)stream);
+}
+int icz_aoa_scst_rollouts(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, const icz_aoa_rng* rng, int64_t* ids_out,
+                          int64_t* seq_out, float* logprobs_out, void* stream) {
+    ICZ_REQUIRE(h, "null handle");
+    return reinterpret_cast<Aoa*>(h)->rollouts(feats, B, max_len, rng, ids_out, seq_out, logprobs_out, (hipStream_t)stream);
 }
 int icz_aoa_sample_backward(icz_aoa_t* h, const float* reward, const icz_aoa_params* grads, float* loss_out, float* mask_sum_out,
                             float mask_sum_global, void* stream) {

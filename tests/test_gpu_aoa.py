@@ -247,3 +247,23 @@ def test_aoa_random_shapes_match_oracle(cfg):
             assert np.abs(g_.cpu().numpy() - want).max() <= 3e-4 * scale + 1e-7, (k, cfg)
     finally:
         oa.NH = oa_nh
+
+
+def test_aoa_concurrent_rollouts_equal_sequential(g):
+    """icz_aoa_scst_rollouts (greedy on bank 0 / side stream beside the sampled rollout on bank 1) = greedy() then sample()."""
+    from simpleimagecaptionzoo_amd.aoa import make_aoa_rng
+    h = make(g)
+    feats = feats_of(g)
+    want_ids = h.greedy(feats, 20).clone()
+    want_seq, want_lp = h.sample(feats, 20, make_aoa_rng(77))
+    want_seq, want_lp = want_seq.clone(), want_lp.clone()
+    for _ in range(3):
+        ids, seq, lp = h.rollouts(feats, 20, make_aoa_rng(77))
+        assert torch.equal(ids, want_ids) and torch.equal(seq, want_seq) and torch.equal(lp, want_lp)
+    grads = h.new_grads()
+    loss, _ = h.sample_backward(torch.ones(seq.shape, device="cuda"), grads)
+    h.sample(feats, 20, make_aoa_rng(77))
+    grads2 = h.new_grads()
+    loss2, _ = h.sample_backward(torch.ones(seq.shape, device="cuda"), grads2)
+    assert loss.item() == loss2.item() and all(torch.equal(grads[k], grads2[k]) for k in grads)
+    assert np.array_equal(ids.cpu().numpy(), g["greedy_ids"])

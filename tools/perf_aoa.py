@@ -43,8 +43,8 @@ def main():
     print("sample+bwd    %.3f ms" % t)
 
     def scst():
-        h.greedy(feats, 20)
-        rl()
+        h.rollouts(feats, 20, make_aoa_rng(1))
+        h.sample_backward(reward, grads)
     t = timed(scst, n)
     print("scst (no reward/adam) %.3f ms  -> %.0f captions/s" % (t, B / t * 1e3))
 
