@@ -31,7 +31,7 @@ def make_handle(g, sd=None, max_rows=None, max_len=20):
 
 @pytest.mark.parametrize("layout,M,N,K", [
     ("nt", 64, 4096, 1024), ("nt", 5, 53, 96), ("nt", 64, 10102, 1024), ("nt", 130, 256, 2048),
-    ("nt", 16, 128, 48), ("nt", 33, 70, 16),
+    ("nt", 16, 128, 48), ("nt", 33, 70, 16), ("nt", 320, 4096, 1024), ("nt", 2304, 1024, 2048), ("nt", 130, 3000, 96),
     ("nn", 64, 1024, 4096), ("nn", 5, 96, 53 * 4), ("nn", 100, 64, 10104), ("nn", 20, 2048, 4096),
     ("tn", 4096, 1024, 1280), ("tn", 64, 52, 100), ("tn", 128, 2048, 37), ("tn", 1024, 10104, 64),
 ])

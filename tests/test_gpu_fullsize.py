@@ -71,6 +71,17 @@ def test_fullsize_sample_and_reinforce_gradients_match_oracle(full):
         assert np.abs(g.cpu().numpy() - want).max() <= 2e-4 * scale + 1e-7, (k, np.abs(g.cpu().numpy() - want).max(), scale)
 
 
+def test_fullsize_tall_batch_uses_the_same_numbers(full):
+    """128 decoder rows take the 128 x 128-tile GEMM (three K segments, split-K slabs) instead of the 64-row one: rows are
+    independent, so the first 64 must decode exactly as the 64-row batch does, and the rest like their copies."""
+    h, _, feats = full
+    T = 6
+    ids64 = h.greedy(feats, T).clone()
+    both = torch.cat([feats, feats.flip(0)], 0).contiguous()
+    ids128 = h.greedy(both, T)
+    assert torch.equal(ids128[:64], ids64) and torch.equal(ids128[64:], ids64.flip(0))
+
+
 def test_fullsize_beam1_equals_greedy_and_beams_are_sorted(full):
     """Beam size 1 is greedy decoding cut at <end> (BUTD_Model.py:236-318 with k = 1); wider beams never score below it."""
     h, _, feats = full
