@@ -679,7 +679,8 @@ static int stage_k(GemmLayout layout, const GemmArgs& a) {
 static bool nt_spread(const GemmArgs& a) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_GEMM_SPREAD"); force = e ? atoi(e) : 1; }
-    return force != 0 && a.M <= 64;
+    // measured: -9.5 % at M = 64, -3 % at M = 2304 (refiner / prologue GEMMs), +4 % at M = 320 (beam rows)
+    return force != 0 && (a.M <= 64 || a.M >= 1024);
 }
 static int nt_waves(const GemmArgs& a) {
     static int force = -1;
