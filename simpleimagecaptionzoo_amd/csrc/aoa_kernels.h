@@ -37,7 +37,8 @@ __global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, s
     x[i] = dp.apply(fmaxf(x[i], 0.f), i);
 }
 
-// Custom LayerNorm (AoA_Model.py:14-25): y = gain * (x - mean) / (std_unbiased + eps) + bias.  One wave per row.
+// Custom LayerNorm (AoA_Model.py:14-25): y = gain * (x - mean) / (std_unbiased + eps) + bias.  One wave per row; the row is
+// read once with 16-byte loads and kept in registers (n <= 2048, n % 4 == 0; longer rows are re-read).
 // Optionally stores (mean, 1/(std+eps)) per row for the backward pass.
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                          const float* __restrict__ bias, float* __restrict__ y, int rows, int n,
@@ -46,6 +47,43 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row
     if (row >= rows) return;
     const float* xr = x + (size_t)row * n;
+    float* yr = y + (size_t)row * n;
+    constexpr int NV = 8;                        // 8 float4 per lane = 2048 floats per row in registers
+    if (n <= 256 * NV && (n & 3) == 0) {
+        f32x4 v[NV];
+        float s = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            v[u] = c < n ? *reinterpret_cast<const f32x4*>(xr + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+            s += (v[u][0] + v[u][1]) + (v[u][2] + v[u][3]);
+        }
+        const float mean = wave_sum(s) / (float)n;
+        float q = 0.f;
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            if (4 * lane + 256 * u < n) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const float d = v[u][j] - mean; q += d * d; }
+            }
+        }
+        const float stdv = sqrtf(wave_sum(q) / (float)(n - 1));
+        const float inv = 1.0f / (stdv + 1e-6f);
+#pragma unroll
+        for (int u = 0; u < NV; ++u) {
+            const int c = 4 * lane + 256 * u;
+            if (c < n) {
+                const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+                const f32x4 b = *reinterpret_cast<const f32x4*>(bias + c);
+                f32x4 o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) o[j] = g[j] * (v[u][j] - mean) * inv + b[j];
+                *reinterpret_cast<f32x4*>(yr + c) = o;
+            }
+        }
+        if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = inv; }
+        return;
+    }
     float s = 0.f;
     for (int c = lane; c < n; c += 64) s += xr[c];
     const float mean = wave_sum(s) / (float)n;
@@ -53,7 +91,6 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     for (int c = lane; c < n; c += 64) { const float d = xr[c] - mean; v += d * d; }
     const float stdv = sqrtf(wave_sum(v) / (float)(n - 1));
     const float inv = 1.0f / (stdv + 1e-6f);
-    float* yr = y + (size_t)row * n;
     for (int c = lane; c < n; c += 64) yr[c] = gain[c] * (xr[c] - mean) * inv + bias[c];
     if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = inv; }
 }
