@@ -33,14 +33,16 @@ __global__ __launch_bounds__(256) void aoa_glu_bwd_kernel(const float* __restric
 
 // Decoder attention backward, one wave per (row, head); row b attends image b (training paths have no beams).
 //   dPd_r = dx_h . V_h[r];  dP = keep/(1-p) * dPd;  dS = P (dP - sum P dP);  dQ_h = sum_r dS_r K_h[r] / sqrt(d)
-//   dK_h[r] += dS_r Q_h / sqrt(d);  dV_h[r] += Pd_r dx_h      (accumulated over time steps in launch order)
+// dK_h[r] = sum_t dS_t[r] Q_t,h / sqrt(d) and dV_h[r] = sum_t Pd_t[r] dx_t,h are sums over time: the steps only record dS_t
+// (already scaled by 1/sqrt(d)) and dx_t, and aoa_dkv_kernel forms both sums once after the loop -- accumulating them
+// step by step would read-modify-write the two [B, R, Hd] tensors (38 MB) in every step.
 // dx = columns [0, Hd) of the GLU-input gradient slabs [ns][rows][2Hd].
 __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __restrict__ dxq, int ns, int rows, const float* __restrict__ Pm,
                                                               const float* __restrict__ Pdm, const float* __restrict__ Qp,
                                                               const float* __restrict__ Kd, const float* __restrict__ Vd,
-                                                              float* __restrict__ dQp, float* __restrict__ dKd, float* __restrict__ dVd, int R, int Hd,
+                                                              float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
                                                               int NH, float keep_scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [64], Pd [64]
+    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [64]
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_db;
@@ -48,7 +50,6 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
     float* sq = sv + R * ld;
     float* sdx = sq + d;
     float* sds = sdx + d;
-    float* spd = sds + 64;
     const size_t base = (size_t)row * R * Hd + (size_t)hd * d;
     aoa_stage_kv(Kd + base, Vd + base, sk, sv, R, d, Hd, lane);
     const size_t MN = (size_t)rows * 2 * Hd;
@@ -68,18 +69,50 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
     const float dot = wave_sum(p * dP);
     const float dS = p * (dP - dot) / sqrtf((float)d);
     sds[lane] = lane < R ? dS : 0.f;
-    spd[lane] = pd;
+    if (lane < R) dS_out[pidx] = dS;
     __syncthreads();
     for (int j = lane; j < d; j += 64) {
         float acc = 0.f;
-        const float qj = sq[j], dxj = sdx[j];
-        for (int r = 0; r < R; ++r) {
-            acc += sds[r] * sk[r * ld + j];
-            const size_t g = base + (size_t)r * Hd + j;
-            dKd[g] += sds[r] * qj;
-            dVd[g] += spd[r] * dxj;
-        }
+        for (int r = 0; r < R; ++r) acc += sds[r] * sk[r * ld + j];
         dQp[(size_t)row * Hd + (size_t)hd * d + j] = acc;
+        dx_out[(size_t)row * Hd + (size_t)hd * d + j] = sdx[j];
+    }
+}
+
+// dKd[img, r, head cols] = sum_t dS_t[img, head, r] Qp_t[img, head cols];  dVd = sum_t Pd_t[r] dx_t   (grid (B, NH), 256 threads)
+__global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ dS_all, const float* __restrict__ Pd_all,
+                                                      const float* __restrict__ Qp_all, const float* __restrict__ dx_all,
+                                                      float* __restrict__ dKd, float* __restrict__ dVd, int B, int T, int R, int Hd, int NH) {
+    extern __shared__ __attribute__((aligned(16))) float sm_kv[];       // dS [T][R], Pd [T][R], Qp [T][d], dx [T][d]
+    const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
+    const int d = Hd / NH;
+    float* sds = sm_kv;
+    float* spd = sds + T * R;
+    float* sq = spd + T * R;
+    float* sdx = sq + T * d;
+    for (int i = tid; i < T * R; i += 256) {
+        const int t = i / R, r = i % R;
+        const size_t g = (((size_t)t * B + img) * NH + hd) * R + r;
+        sds[i] = dS_all[g];
+        spd[i] = Pd_all[g];
+    }
+    for (int i = tid; i < T * d; i += 256) {
+        const int t = i / d, j = i % d;
+        const size_t g = ((size_t)t * B + img) * Hd + (size_t)hd * d + j;
+        sq[i] = Qp_all[g];
+        sdx[i] = dx_all[g];
+    }
+    __syncthreads();
+    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    for (int i = tid; i < R * d; i += 256) {
+        const int r = i / d, j = i % d;
+        float dk = 0.f, dv = 0.f;
+        for (int t = 0; t < T; ++t) {
+            dk += sds[t * R + r] * sq[t * d + j];
+            dv += spd[t * R + r] * sdx[t * d + j];
+        }
+        dKd[base + (size_t)r * Hd + j] = dk;
+        dVd[base + (size_t)r * Hd + j] = dv;
     }
 }
 
@@ -154,7 +187,7 @@ int Aoa::ensure_train() {
     float** st1[] = {&th, &tm, &tctx};
     for (float** p : st1) ICZ_TRY(alloc((void**)p, sizeof(float) * (TB + B) * Hd));
     ICZ_TRY(alloc((void**)&temb, sizeof(float) * TB * E));
-    float** sth[] = {&tu, &tqn, &tQp, &txatt, &tcd, &dCd, &dQp, &dQn, &prod};
+    float** sth[] = {&tu, &tqn, &tQp, &txatt, &tcd, &dCd, &dQp, &dQn, &prod, &tdX};
     for (float** p : sth) ICZ_TRY(alloc((void**)p, sizeof(float) * TB * Hd));
     ICZ_TRY(alloc((void**)&tg, sizeof(float) * TB * 4 * Hd));
     ICZ_TRY(alloc((void**)&dG, sizeof(float) * TB * 4 * Hd));
@@ -163,6 +196,7 @@ int Aoa::ensure_train() {
     ICZ_TRY(alloc((void**)&tstats, sizeof(float) * TB * 2));
     ICZ_TRY(alloc((void**)&tP, sizeof(float) * TB * NH * R));
     ICZ_TRY(alloc((void**)&tPd, sizeof(float) * TB * NH * R));
+    ICZ_TRY(alloc((void**)&tdS, sizeof(float) * TB * NH * R));
     ICZ_TRY(alloc((void**)&tlogit, sizeof(float) * TB * Vp));
     ICZ_TRY(alloc((void**)&dEmb, sizeof(float) * TB * E));
     ICZ_TRY(alloc((void**)&dKd, sizeof(float) * B * R * Hd));
@@ -366,13 +400,13 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     ICZ_TRY(colsum(tlogit, TB, V, Vp, G.predict_b, st));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
                        G.predict_g, V, Hd);
-    ICZ_CHECK_HIP(hipMemsetAsync(dKd, 0, sizeof(float) * sH * R, st));
-    ICZ_CHECK_HIP(hipMemsetAsync(dVd, 0, sizeof(float) * sH * R, st));
     if (rows_t[T - 1] < B) {      // ragged batch: rows that are inactive at step t contribute exact zeros to the batched GEMMs
         ICZ_CHECK_HIP(hipMemsetAsync(dZ, 0, sizeof(float) * (size_t)TB * 2 * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dQp, 0, sizeof(float) * (size_t)TB * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dQn, 0, sizeof(float) * (size_t)TB * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dG, 0, sizeof(float) * (size_t)TB * 4 * Hd, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tdS, 0, sizeof(float) * (size_t)TB * NH * R, st));
+        ICZ_CHECK_HIP(hipMemsetAsync(tdX, 0, sizeof(float) * (size_t)TB * Hd, st));
     }
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
     DropCfg off = {0, nullptr, nullptr, 0, 0};
@@ -388,7 +422,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         int ns2 = 1, nsq = 1;
         ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
-                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, dKd, dVd, R, Hd, NH, io.d_att.mode ? io.d_att.scale : 1.0f);
+                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(64), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
                            P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
@@ -425,6 +459,8 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
     ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st));
     ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));
+    hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)T * 2 * (R + dh), st, tdS, tPd, tQp, tdX, dKd, dVd, B, T, R,
+                       Hd, NH);
     ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.k_w, Hd, 0, st));
     ICZ_TRY(colsum(dKd, B * R, Hd, Hd, G.dec.k_b, st));
     ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.v_w, Hd, 0, st));
