@@ -187,7 +187,9 @@ int icz_nic_beam_search(icz_nic_t* h, const float* features, int32_t n_img, int3
  * AoADetection captioner (Models/AoA_Model.py:657-753): img_feats_porjection (Linear 2048->Hd + ReLU + Dropout) ->
  * AoA_Refine_Core (6 x {LayerNorm -> 8-head self-attention over the R regions -> GLU gate -> residual}, final LayerNorm;
  * :122-162) once per image, then AoA_Decoder (:197-502) per step: embed -> LSTMCell([emb, mean + drop(ctx)]) -> LayerNorm
- * -> 8-head attention over the refined regions + GLU -> predict.  Fixed-region path (bu_masks = None).
+ * -> 8-head attention over the refined regions + GLU -> predict.  Fixed region sets (36 boxes or the 7x7 grid,
+ * bu_masks = None) and the 'adaptive' ones (10..100 boxes per image with prefix bu_masks, AoA_Engine.py:37-44) through
+ * icz_aoa_set_regions.
  * Only decoder.* parameters receive gradients: they are the only ones in the reference's optimizer (:669-674).
  * ---------------------------------------------------------------------------------------------------------- */
 typedef struct icz_aoa icz_aoa_t;
@@ -217,7 +219,15 @@ int icz_aoa_create(const icz_aoa_dims* dims, icz_aoa_t** out);
 int icz_aoa_destroy(icz_aoa_t* h);
 int icz_aoa_bind_params(icz_aoa_t* h, const icz_aoa_params* params);
 int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream);
-/* eval-mode refined features [B,R,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests */
+/* Region layout of the batches that follow (sticky; a new handle has regions = dims.R and no counts): `feats` of every
+ * later call is [B, regions, D] with regions <= dims.R (the handle's capacity).  counts = the number of valid leading
+ * regions of each image, i.e. bu_masks.sum(1) of the reference's prefix masks (AoA_Engine.py:37-40), in device memory
+ * (read by the kernels of the following calls -- keep it alive until they have run) and in host memory (validated here:
+ * 1 <= counts[i] <= regions); both NULL = every region valid (bu_masks = None).  Masked keys get attention weight 0
+ * (masked_fill(-1e9) before the softmax, AoA_Model.py:63-64), the projection of a padded row is 0 (pack_wrapper,
+ * :650-653) and mean_features averages the valid rows (:253). */
+int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev, const int32_t* counts_host, int32_t n_img);
+/* eval-mode refined features [B,regions,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests */
 int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_out, void* stream);
 /* AoADetection_Captioner.sampler / beam_search_sampler / sampler_rl / forward (:698-753, :676-696) */
 int icz_aoa_greedy(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out, void* stream);

@@ -16,15 +16,33 @@ def layer_norm(x, gain, bias, eps=1e-6):
     return gain * (x - mean) / (std + eps) + bias
 
 
-def aoa_block(query, kv, p, pre, att_mask=None, aoa_mask=None, aoa_p=0.3):
-    """AoABlock.forward, AoA_Model.py:90-120 (mask=None path): 8-head dot-product attention + GLU gate."""
+def key_mask(lens, R):
+    """Prefix bu_masks [B, R] (1 = valid) from per-image region counts, AoA_Engine.py:37-40; None = all valid."""
+    if lens is None:
+        return None
+    return (torch.arange(R).unsqueeze(0) < torch.as_tensor(lens).view(-1, 1)).float()
+
+
+def masked_mean(enc, bu_mask):
+    """mean_features, AoA_Model.py:250-253."""
+    if bu_mask is None:
+        return enc.mean(1)
+    return (enc * bu_mask.unsqueeze(-1)).sum(1) / bu_mask.unsqueeze(-1).sum(1)
+
+
+def aoa_block(query, kv, p, pre, att_mask=None, aoa_mask=None, aoa_p=0.3, bu_mask=None):
+    """AoABlock.forward, AoA_Model.py:90-120: 8-head dot-product attention (keys with bu_mask == 0 filled with -1e9
+    before the softmax, :63-64,108-110) + GLU gate."""
     B, nq, Hd = query.shape
     d = Hd // NH
     lin = lambda x, n: x @ p[pre + n + ".weight"].t() + p[pre + n + ".bias"]
     Q = lin(query, "linear_Q").view(B, -1, NH, d).transpose(1, 2)
     K = lin(kv, "linear_K").view(B, -1, NH, d).transpose(1, 2)
     V = lin(kv, "linear_V").view(B, -1, NH, d).transpose(1, 2)
-    P = torch.softmax(Q @ K.transpose(-2, -1) / math.sqrt(d), dim=-1)
+    S = Q @ K.transpose(-2, -1) / math.sqrt(d)
+    if bu_mask is not None:
+        S = S.masked_fill(bu_mask[:, None, None, :] == 0, -1e9)
+    P = torch.softmax(S, dim=-1)
     alpha = P.mean(1)
     P = drop(P, att_mask, 0.1)
     x = (P @ V).transpose(1, 2).contiguous().view(B, nq, Hd)
@@ -33,27 +51,31 @@ def aoa_block(query, kv, p, pre, att_mask=None, aoa_mask=None, aoa_p=0.3):
     return z[..., :Hd] * torch.sigmoid(z[..., Hd:]), alpha
 
 
-def refine(feats, p, masks=None):
+def refine(feats, p, masks=None, lens=None):
     """img_feats_porjection + AoA_Refine_Core, AoA_Model.py:661-665,140-162.  masks: dict proj / ref_att / ref_aoa /
-    ref_sc (None = eval mode)."""
+    ref_sc (None = eval mode).  lens: valid regions per image ('adaptive' features); the projection then runs on the
+    valid rows only and the padding rows are zero (pack_wrapper, :650-653)."""
     g = (lambda k, l=None: None) if masks is None else (lambda k, l=None: torch.as_tensor(masks[k] if l is None else masks[k][l]))
+    bu = key_mask(lens, feats.shape[1])
     x = drop(torch.relu(feats @ p["img_feats_porjection.0.weight"].t() + p["img_feats_porjection.0.bias"]), g("proj"), 0.5)
+    if bu is not None:
+        x = x * bu.unsqueeze(-1)
     for l in range(6):
         pre = "aoa_refine.aoa_layers.%d." % l
         n = layer_norm(x, p[pre + "sublayer.norm.gain"], p[pre + "sublayer.norm.bias"])
-        y, _ = aoa_block(n, n, p, pre + "aoa_block.", g("ref_att", l), g("ref_aoa", l), 0.3)
+        y, _ = aoa_block(n, n, p, pre + "aoa_block.", g("ref_att", l), g("ref_aoa", l), 0.3, bu)
         x = x + drop(y, g("ref_sc", l), 0.1)
     return layer_norm(x, p["aoa_refine.norm.gain"], p["aoa_refine.norm.bias"])
 
 
-def dec_step(it, state, enc, meanf, p, masks=(None, None, None, None)):
+def dec_step(it, state, enc, meanf, p, masks=(None, None, None, None), bu_mask=None):
     """One AoA_Decoder step, AoA_Model.py:319-336.  state = (h, m, ctx); masks = (emb, ctx, att, out)."""
     h, m, ctx = state
     emb = drop(torch.relu(p["decoder.embed.0.weight"][it]), masks[0], 0.5)
     u = meanf + drop(ctx, masks[1], 0.5)
     h, m = lstm_cell(torch.cat([emb, u], 1), h, m, p, "decoder.lstm")
     q = layer_norm(h, p["decoder.h_norm.gain"], p["decoder.h_norm.bias"]).unsqueeze(1)
-    ctx, alpha = aoa_block(q, enc, p, "decoder.aoa_block.", masks[2], None)
+    ctx, alpha = aoa_block(q, enc, p, "decoder.aoa_block.", masks[2], None, bu_mask=bu_mask)
     ctx = ctx.squeeze(1)
     logits = drop(ctx, masks[3], 0.5) @ wn_weight(p, "decoder.predict").t() + p["decoder.predict.bias"]
     return logits, alpha.squeeze(1), (h, m, ctx)
@@ -70,30 +92,32 @@ def _step_masks(masks, t, bt=None):
     return tuple(torch.as_tensor(cut(masks[k][t])) for k in ("emb", "ctx", "att", "out"))
 
 
-def greedy(feats, p, max_len=20):
-    enc = refine(feats, p)
-    B, _, Hd = enc.shape
-    meanf, st = enc.mean(1), _zero(B, Hd)
+def greedy(feats, p, max_len=20, lens=None):
+    enc = refine(feats, p, lens=lens)
+    B, R, Hd = enc.shape
+    bu = key_mask(lens, R)
+    meanf, st = masked_mean(enc, bu), _zero(B, Hd)
     it = torch.full((B,), STA, dtype=torch.long)
     ids, lgs = [], []
     for _ in range(max_len):
-        logits, _, st = dec_step(it, st, enc, meanf, p)
+        logits, _, st = dec_step(it, st, enc, meanf, p, bu_mask=bu)
         it = logits.max(1)[1]
         ids.append(it)
         lgs.append(logits)
     return torch.stack(ids, 1), torch.stack(lgs, 1)
 
 
-def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True):
-    enc = refine(feats, p, masks)
-    B, _, Hd = enc.shape
-    meanf, st = enc.mean(1), _zero(B, Hd)
+def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True, lens=None):
+    enc = refine(feats, p, masks, lens)
+    B, R, Hd = enc.shape
+    bu = key_mask(lens, R)
+    meanf, st = masked_mean(enc, bu), _zero(B, Hd)
     it = torch.full((B,), STA, dtype=torch.long)
     seq = torch.zeros(B, max_len, dtype=torch.long)
     lps = [torch.zeros(B) for _ in range(max_len)]
     unfinished = torch.ones(B, dtype=torch.bool)
     for t in range(max_len):
-        logits, _, st = dec_step(it, st, enc, meanf, p, _step_masks(masks, t))
+        logits, _, st = dec_step(it, st, enc, meanf, p, _step_masks(masks, t), bu)
         logp = torch.log_softmax(logits, dim=1)
         draw = inverse_cdf_draw(torch.exp(logp.detach()), uniforms[t])
         lps[t] = logp.gather(1, draw.unsqueeze(1)).squeeze(1)
@@ -105,31 +129,35 @@ def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True):
     return seq, torch.stack(lps, 1)
 
 
-def forward_xe(feats, captions, lengths, p, masks=None):
-    enc = refine(feats, p, masks)
-    B, _, Hd = enc.shape
-    meanf, st = enc.mean(1), _zero(B, Hd)
+def forward_xe(feats, captions, lengths, p, masks=None, lens=None):
+    enc = refine(feats, p, masks, lens)
+    B, R, Hd = enc.shape
+    bu = key_mask(lens, R)
+    meanf, st = masked_mean(enc, bu), _zero(B, Hd)
     rows = []
     for t in range(max(lengths)):
         bt = sum(l > t for l in lengths)
-        logits, _, st = dec_step(captions[:bt, t], tuple(s[:bt] for s in st), enc[:bt], meanf[:bt], p, _step_masks(masks, t, bt))
+        logits, _, st = dec_step(captions[:bt, t], tuple(s[:bt] for s in st), enc[:bt], meanf[:bt], p, _step_masks(masks, t, bt),
+                                 None if bu is None else bu[:bt])
         rows.append(logits)
     return torch.cat(rows, 0)
 
 
-def beam_search(feats1, p, k, max_steps=50):
-    """AoA_Decoder.beam_search_sample, AoA_Model.py:403-502 (state h, m, ctx re-indexed by the source beam)."""
+def beam_search(feats1, p, k, max_steps=50, lens=None):
+    """AoA_Decoder.beam_search_sample, AoA_Model.py:403-502 (state h, m, ctx re-indexed by the source beam; the one
+    image's bu_mask broadcasts over the beams)."""
     V = p["decoder.predict.bias"].shape[0]
-    enc1 = refine(feats1, p)
+    enc1 = refine(feats1, p, lens=lens)
+    bu = key_mask(lens, enc1.shape[1])
     enc = enc1.expand(k, -1, -1)
-    meanf = enc.mean(1)
+    meanf = masked_mean(enc1, bu).expand(k, -1)
     st = _zero(k, enc.shape[2])
     prev = torch.full((k,), STA, dtype=torch.long)
     seqs = prev.view(k, 1)
     run = torch.zeros(k, 1)
     done, done_scores = [], []
     for stp in range(1, max_steps + 1):
-        logits, _, st = dec_step(prev, st, enc, meanf, p)
+        logits, _, st = dec_step(prev, st, enc, meanf, p, bu_mask=bu)
         sc = run.expand(-1, V) + torch.log_softmax(logits, dim=1)
         top, idx = (sc[0] if stp == 1 else sc.reshape(-1)).topk(k, 0, True, True)
         src, nxt = torch.div(idx, V, rounding_mode="floor"), idx % V

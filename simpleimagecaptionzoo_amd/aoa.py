@@ -1,6 +1,9 @@
 """Host-side owner of one libicz AoA handle (Models/AoA_Model.py) and the AoADetection Captioner on top of it.
 
-Fixed-region bottom-up features only (`bu_masks` must be None: 36 regions per image, AoA_Model.py's `'fixed'` mode)."""
+Region sets: `'fixed'` (36 boxes, `bu_masks` None), the 7x7 grid (49) and `'adaptive'` (10..100 boxes per image, padded to
+the batch's largest count with prefix `bu_masks`, AoA_Engine.py:33-46) -- the handle is created for the largest region
+count it will see (`num_regions`) and every batch may be narrower."""
+import collections
 import copy
 import ctypes as C
 
@@ -38,6 +41,21 @@ def make_aoa_rng(seed=0, uniforms=None, masks=None):
     return r
 
 
+# features [B, R, D] + the valid region count of each image (host ints; None = all R valid)
+RegionBatch = collections.namedtuple("RegionBatch", "feats counts")
+
+
+def counts_from_masks(bu_masks):
+    """bu_masks [B, R] (1 = valid) -> per-image counts.  The reference builds prefix masks (AoA_Engine.py:37-40) and itself
+    reads them as lengths (pack_wrapper, AoA_Model.py:652); anything else is rejected."""
+    m = bu_masks.detach()
+    counts = m.long().sum(1)
+    prefix = torch.arange(m.shape[1], device=m.device).unsqueeze(0) < counts.unsqueeze(1)
+    if not bool(((m != 0) == prefix).all()):
+        raise ValueError("bu_masks must mark a leading run of valid regions per image (AoA_Engine.py:37-40)")
+    return counts.tolist()
+
+
 class AoaHandle:
     def __init__(self, R, D, Hd, E, V, NH, max_rows, max_len=20, device="cuda:0"):
         self.R, self.D, self.Hd, self.E, self.V, self.NH = R, D, Hd, E, V, NH
@@ -45,6 +63,8 @@ class AoaHandle:
         self._h = C.c_void_p()
         self._params = None
         self._persistent = False
+        self._regions = (R, None)
+        self._counts_dev = None
         with torch.cuda.device(self.device):
             check(lib().icz_aoa_create(C.byref(AoaDims(R, D, Hd, E, V, NH, max_rows, max_len)), C.byref(self._h)))
 
@@ -89,14 +109,35 @@ class AoaHandle:
                 setattr(st, "p%d" % i, grads[key].data_ptr())
         return st
 
+    def set_regions(self, regions, counts=None):
+        """icz_aoa_set_regions: the batches that follow are [B, regions, D]; counts = valid regions per image or None."""
+        if counts is None:
+            if self._regions != (regions, None):
+                check(lib().icz_aoa_set_regions(self._h, int(regions), None, None, 0))
+                self._regions, self._counts_dev = (regions, None), None
+            return
+        counts = [int(c) for c in counts]
+        host = (C.c_int32 * len(counts))(*counts)
+        dev = torch.tensor(counts, dtype=torch.int32, device=self.device)
+        check(lib().icz_aoa_set_regions(self._h, int(regions), ptr(dev), host, len(counts)))
+        # the kernels of the following calls read `dev`: it stays referenced until the next set_regions, and torch's
+        # caching allocator hands its memory out again only in stream order
+        self._regions, self._counts_dev = (regions, tuple(counts)), dev
+
     def _feats(self, f):
-        if f.dtype != torch.float32 or not f.is_cuda or f.dim() != 3 or tuple(f.shape[1:]) != (self.R, self.D):
-            raise _lib.IczError("bu_feats must be an fp32 CUDA tensor (B,%d,%d)" % (self.R, self.D))
+        counts = None
+        if isinstance(f, RegionBatch):
+            f, counts = f
+        if f.dtype != torch.float32 or not f.is_cuda or f.dim() != 3 or f.shape[2] != self.D or not 1 <= f.shape[1] <= self.R:
+            raise _lib.IczError("bu_feats must be an fp32 CUDA tensor (B, 1..%d, %d)" % (self.R, self.D))
+        if counts is not None and len(counts) != f.shape[0]:
+            raise _lib.IczError("%d region counts for %d images" % (len(counts), f.shape[0]))
+        self.set_regions(f.shape[1], counts)
         return f.contiguous()
 
     def refine(self, feats):
         feats = self._feats(feats)
-        out = torch.empty(feats.shape[0], self.R, self.Hd, device=feats.device)
+        out = torch.empty(feats.shape[0], feats.shape[1], self.Hd, device=feats.device)
         check(lib().icz_aoa_refine(self._h, ptr(feats), feats.shape[0], ptr(out), stream_ptr()))
         return out
 
@@ -255,9 +296,14 @@ class AoADetection_Captioner(nn.Module):
 
     @staticmethod
     def _feats(visual_inputs):
-        if visual_inputs.get("bu_masks") is not None:
-            raise NotImplementedError("adaptive bottom-up features (bu_masks) are outside the HIP path: fixed 36 regions only")
-        return visual_inputs["bu_feats"].detach()
+        """bu_feats (+ the region counts behind bu_masks: `bu_counts` when the Engine supplies them, else read back from the
+        mask)."""
+        feats = visual_inputs["bu_feats"].detach()
+        masks = visual_inputs.get("bu_masks")
+        if masks is None:
+            return feats
+        counts = visual_inputs.get("bu_counts")
+        return RegionBatch(feats, list(counts) if counts is not None else counts_from_masks(masks))
 
     def get_param_groups(self, lr_dict):
         """AoA_Model.py:669-674: only the decoder is optimised."""

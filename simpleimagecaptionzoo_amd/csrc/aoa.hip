@@ -8,13 +8,15 @@ int Aoa::init(const icz_aoa_dims& d) {
     dims = d;
     ICZ_REQUIRE(d.NH > 0 && d.Hd % d.NH == 0 && (d.Hd / d.NH) % 4 == 0, "aoa: hidden size %d must split into %d heads of a multiple of 4 columns", d.Hd, d.NH);
     ICZ_REQUIRE(d.E % 4 == 0 && d.Hd % 4 == 0 && d.D % 4 == 0 && d.V > 3 && d.max_rows > 0 && d.max_len > 0, "aoa: bad dimensions");
-    ICZ_REQUIRE(d.R >= 1 && d.R <= 64, "aoa: %d regions per image (supported: 1..64)", d.R);
+    ICZ_REQUIRE(d.R >= 1 && d.R <= 128, "aoa: %d regions per image (supported: 1..128)", d.R);
     const size_t dh = d.Hd / d.NH;
-    // per-(image, head) tiles live in LDS: Q, K, V [R][dh+1] + P [R][R+1] in the refiner, K, V in the decoder.  gfx950 has
-    // 160 KB per CU; above the 64 KB default the kernels need the explicit opt-in below (49 regions x 128 columns: 86 KB)
-    const size_t lds_self = (3 * d.R * (dh + 1) + d.R * (d.R + 1)) * sizeof(float);
-    const size_t lds_dec = (2 * d.R * (dh + 1) + dh + 64) * sizeof(float);
-    ICZ_REQUIRE(lds_self <= 156 * 1024, "aoa: head tile (%zu bytes) does not fit the LDS budget", lds_self);
+    // per-(image, head) tiles live in LDS: K, V [R][dh+1] + a chunk of queries with its P rows in the refiner, K, V in the
+    // decoder.  gfx950 has 160 KB per CU; above the 64 KB default the kernels need the explicit opt-in below (49 regions x
+    // 128 columns: 86 KB; 100 regions: K and V take 103 KB and the queries go through in chunks, see self_qc())
+    cur_R = d.R;
+    ICZ_REQUIRE(self_qc(d.R) >= 1, "aoa: K and V head tiles of %d regions do not fit the LDS budget", d.R);
+    const size_t lds_self = self_lds(d.R, self_qc(d.R));
+    const size_t lds_dec = (2 * d.R * (dh + 1) + dh + 128) * sizeof(float);
     if (lds_self > 48 * 1024)
         ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_self_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_self));
     if (lds_dec > 48 * 1024)
@@ -99,13 +101,15 @@ int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, in
 // img_feats_porjection + AoA_Refine_Core (AoA_Model.py:661-665, 140-162) -> refined [n_img,R,Hd], its region mean, and the
 // decoder block's linear_K / linear_V of it (time-invariant, hoisted out of the decoding loop)
 int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
-    const int R = dims.R, Hd = dims.Hd, NH = dims.NH, dh = Hd / NH;
+    const int R = cur_R, Hd = dims.Hd, NH = dims.NH;
+    ICZ_REQUIRE(!lens || lens_n == n_img, "aoa: region counts were set for %d images, the batch has %d (icz_aoa_set_regions)", lens_n, n_img);
     const int rows = n_img * R;
     const size_t nel = (size_t)rows * Hd;
     const unsigned eb = (unsigned)((nel + 255) / 256);
     ICZ_TRY(lin(feats, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
-    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f));
-    const size_t lds = sizeof(float) * (3 * R * (dh + 1) + R * (R + 1));
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), lens, R, Hd);
+    const int qc = self_qc(R);
+    const size_t lds = self_lds(R, qc);
     float *cur = xa, *nxt = xb;
     for (int l = 0; l < NL; ++l) {
         const icz_aoa_block& b = P.layer[l];
@@ -113,7 +117,7 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
         ICZ_TRY(lin(ln, rows, Hd, b.q_w, b.q_b, Hd, q, st));
         ICZ_TRY(lin(ln, rows, Hd, b.k_w, b.k_b, Hd, k, st));
         ICZ_TRY(lin(ln, rows, Hd, b.v_w, b.v_b, Hd, v, st));
-        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH,
+        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH, qc, lens,
                            dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f));
         const float *xo = o, *xn = ln;
         if (train) {
@@ -132,7 +136,7 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
         float* t_ = cur; cur = nxt; nxt = t_;
     }
     hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, P.ref_ln_g, P.ref_ln_b, refined, rows, Hd, (float*)nullptr);
-    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, R, Hd);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, R, Hd, lens);
     ICZ_TRY(lin(refined, rows, Hd, P.dec.k_w, P.dec.k_b, Hd, Kd, st));
     ICZ_TRY(lin(refined, rows, Hd, P.dec.v_w, P.dec.v_b, Hd, Vd, st));
     ICZ_CHECK_HIP(hipGetLastError());
@@ -141,7 +145,7 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
 
 // One decoder step (AoA_Model.py:319-336)
 int Aoa::step(const AoaStepIO& s, hipStream_t st) {
-    const int rows = s.rows, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = dims.R, dh = Hd / NH;
+    const int rows = s.rows, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = cur_R, dh = Hd / NH;
     const unsigned eb = (unsigned)(((size_t)rows * Hd + 255) / 256);
     if (!s.emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb, rows, E, s.d_emb, 1);
     hipLaunchKernelGGL(aoa_u_kernel, dim3(eb), dim3(256), 0, st, meanf, s.img_of_row, s.ctx_in, s.u, rows, Hd, s.d_ctx);
@@ -159,9 +163,9 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(Hd, 256), rows), dim3(256), 0, st, a, off);
     hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
     ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
-    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 64);
+    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128);
     hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(64), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
-                       s.d_att);
+                       lens, s.d_att);
     GemmArgs zg = {};
     zg.nseg = 2;
     zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};
@@ -318,8 +322,22 @@ int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_o
     ICZ_REQUIRE(n->fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     n->use_bank(0);
     ICZ_TRY(n->refine(feats, B, false, (hipStream_t)stream));
-    ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, sizeof(float) * (size_t)B * n->dims.R * n->dims.Hd, hipMemcpyDeviceToDevice,
+    ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, sizeof(float) * (size_t)B * n->cur_R * n->dims.Hd, hipMemcpyDeviceToDevice,
                                  (hipStream_t)stream));
+    return ICZ_OK;
+}
+int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev, const int32_t* counts_host, int32_t n_img) {
+    ICZ_REQUIRE(h, "null handle");
+    Aoa* n = reinterpret_cast<Aoa*>(h);
+    ICZ_REQUIRE(regions >= 1 && regions <= n->dims.R, "icz_aoa_set_regions: %d regions outside 1..%d (the handle's capacity)", regions, n->dims.R);
+    ICZ_REQUIRE((counts_dev == nullptr) == (counts_host == nullptr), "icz_aoa_set_regions: pass the counts on both sides or on neither");
+    if (counts_host) {
+        ICZ_REQUIRE(n_img >= 1 && n_img <= n->dims.max_rows, "icz_aoa_set_regions: %d images out of range", n_img);
+        for (int i = 0; i < n_img; ++i)
+            ICZ_REQUIRE(counts_host[i] >= 1 && counts_host[i] <= regions, "icz_aoa_set_regions: image %d has %d regions (1..%d)", i, counts_host[i], regions);
+    }
+    n->cur_R = regions; n->lens = counts_dev; n->lens_n = counts_dev ? n_img : 0;
+    n->mode = 0;
     return ICZ_OK;
 }
 int icz_aoa_greedy(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out, void* stream) {

@@ -73,6 +73,21 @@ struct Aoa {
     size_t xfloats = 0;
     icz_aoa_rng rng = {};
     int mode = 0, cur_B = 0, cur_T = 0, cur_L = 0, n_tokens = 0;
+    // regions per image of the current batch: row stride cur_R <= dims.R and, for the 'adaptive' bottom-up features
+    // (10..100 boxes, AoA_Engine.py:37-44), the valid count per image (device, caller-owned; null = all cur_R)
+    int cur_R = 0, lens_n = 0;
+    const int32_t* lens = nullptr;
+    static constexpr size_t LDS_BUDGET = 156 * 1024;
+    size_t self_lds(int R, int qc) const {
+        const size_t dh = dims.Hd / dims.NH;
+        return sizeof(float) * (2 * (size_t)R * (dh + 1) + (size_t)qc * (dh + 1) + (size_t)qc * (R + 1));
+    }
+    int self_qc(int R) const {       // query rows per pass of mha_self_kernel: all of them when the tiles fit
+        const size_t dh = dims.Hd / dims.NH, kv = sizeof(float) * 2 * (size_t)R * (dh + 1);
+        if (kv >= LDS_BUDGET) return 0;
+        const size_t qc = (LDS_BUDGET - kv) / (sizeof(float) * (dh + 1 + R + 1));
+        return (int)(qc < (size_t)R ? qc : (size_t)R);
+    }
     bool cur_train = false;
     const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr;
     const int64_t* cur_captions = nullptr;

@@ -1,5 +1,5 @@
 // Kernels specific to the AoA model family (Models/AoA_Model.py): custom LayerNorm, multi-head dot-product attention
-// (36 x 36 self-attention in the refiner, 1 x 36 in the decoder), GLU gate, general-p dropout.
+// (R x R self-attention in the refiner, 1 x R in the decoder; R = 36, 49, or up to 128 with per-image counts), GLU gate, general-p dropout.
 #pragma once
 #include "butd_kernels.h"
 
@@ -30,10 +30,17 @@ struct DropP {
     }
 };
 
-// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665)
-__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp) {
+// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665).  With per-image region counts the rows
+// past an image's count come out as zeros: the reference projects the packed valid rows only and pads the result
+// (pack_wrapper, AoA_Model.py:650-653).
+__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp, const int32_t* __restrict__ lens, int R,
+                                                        int Hd) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
+    if (lens) {
+        const size_t row = i / Hd;
+        if ((int)(row % R) >= lens[row / R]) { x[i] = 0.f; return; }
+    }
     x[i] = dp.apply(fmaxf(x[i], 0.f), i);
 }
 
@@ -96,50 +103,65 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
 }
 
 // Refiner self-attention (AoA_Model.py:41-69,113-117), one workgroup per (image, head):
-//   S = Q_h K_h^T / sqrt(d);  P = softmax_rows(S);  P = drop(P, 0.1);  O_h = P V_h
-// Q, K, V: [n_img, R, Hd] with head h in columns [h*d, (h+1)*d).  R <= 64.
+//   S = Q_h K_h^T / sqrt(d);  S[:, r] = -1e9 where bu_mask[r] == 0;  P = softmax_rows(S);  P = drop(P, 0.1);  O_h = P V_h
+// Q, K, V: [n_img, R, Hd] with head h in columns [h*d, (h+1)*d).  R <= 128.  The K and V head tiles stay in LDS while the
+// queries go through in chunks of QC rows (QC = R when everything fits: 36 and 49 regions).  bu_masks are prefix masks
+// (AoA_Engine.py:37-40), given as the valid count per image: exp(-1e9 - max) is exactly 0 in fp32, so the masked keys are
+// skipped rather than computed.
 __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                       float* __restrict__ O, int R, int Hd, int NH, DropP dp) {
-    extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // Q,K,V tiles [R][d+1], P [R][R+1]
+                                                       float* __restrict__ O, int R, int Hd, int NH, int QC, const int32_t* __restrict__ lens,
+                                                       DropP dp) {
+    extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // K,V tiles [R][d+1], Q chunk [QC][d+1], P [QC][R+1]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int d = Hd / NH, ld = d + 1, lp = R + 1;
-    float* sq = sm_mha;
-    float* sk = sq + R * ld;
+    const int len = lens ? lens[img] : R;
+    float* sk = sm_mha;
     float* sv = sk + R * ld;
-    float* sp = sv + R * ld;
+    float* sq = sv + R * ld;
+    float* sp = sq + QC * ld;
     const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
-    for (int i = tid; i < R * d; i += 256) {
+    for (int i = tid; i < len * d; i += 256) {
         const int r = i / d, j = i % d;
         const size_t g = base + (size_t)r * Hd + j;
-        sq[r * ld + j] = Q[g]; sk[r * ld + j] = K[g]; sv[r * ld + j] = V[g];
+        sk[r * ld + j] = K[g]; sv[r * ld + j] = V[g];
     }
-    __syncthreads();
     const float scale = 1.0f / sqrtf((float)d);
-    for (int i = tid; i < R * R; i += 256) {
-        const int q = i / R, r = i % R;
-        float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += sq[q * ld + j] * sk[r * ld + j];
-        sp[q * lp + r] = acc * scale;
-    }
-    __syncthreads();
-    // softmax per query row: one wave per row (R <= 64)
     const int lane = tid & 63, wave = tid >> 6;
-    for (int q = wave; q < R; q += 4) {
-        const float v = lane < R ? sp[q * lp + lane] : -INFINITY;
-        const float mx = wave_max(v);
-        const float ex = lane < R ? expf(v - mx) : 0.f;
-        const float sum = wave_sum(ex);
-        if (lane < R) {
-            const uint64_t idx = (((uint64_t)img * NH + hd) * R + q) * R + lane;
-            sp[q * lp + lane] = dp.apply(ex / sum, idx);
+    for (int q0 = 0; q0 < R; q0 += QC) {
+        const int nq = min(QC, R - q0);
+        for (int i = tid; i < nq * d; i += 256) {
+            const int r = i / d, j = i % d;
+            sq[r * ld + j] = Q[base + (size_t)(q0 + r) * Hd + j];
         }
-    }
-    __syncthreads();
-    for (int i = tid; i < R * d; i += 256) {
-        const int q = i / d, j = i % d;
-        float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += sp[q * lp + r] * sv[r * ld + j];
-        O[base + (size_t)q * Hd + j] = acc;
+        __syncthreads();
+        for (int i = tid; i < nq * len; i += 256) {
+            const int q = i / len, r = i % len;
+            float acc = 0.f;
+            for (int j = 0; j < d; ++j) acc += sq[q * ld + j] * sk[r * ld + j];
+            sp[q * lp + r] = acc * scale;
+        }
+        __syncthreads();
+        // softmax per query row: one wave per row, two keys per lane
+        for (int q = wave; q < nq; q += 4) {
+            const int r1 = lane + 64;
+            const float v0 = lane < len ? sp[q * lp + lane] : -INFINITY;
+            const float v1 = r1 < len ? sp[q * lp + r1] : -INFINITY;
+            const float mx = wave_max(fmaxf(v0, v1));
+            const float e0 = lane < len ? expf(v0 - mx) : 0.f;
+            const float e1 = r1 < len ? expf(v1 - mx) : 0.f;
+            const float sum = wave_sum(e0 + e1);
+            const uint64_t idx = (((uint64_t)img * NH + hd) * R + (q0 + q)) * R;
+            if (lane < len) sp[q * lp + lane] = dp.apply(e0 / sum, idx + lane);
+            if (r1 < len) sp[q * lp + r1] = dp.apply(e1 / sum, idx + r1);
+        }
+        __syncthreads();
+        for (int i = tid; i < nq * d; i += 256) {
+            const int q = i / d, j = i % d;
+            float acc = 0.f;
+            for (int r = 0; r < len; ++r) acc += sp[q * lp + r] * sv[r * ld + j];
+            O[base + (size_t)(q0 + q) * Hd + j] = acc;
+        }
+        __syncthreads();
     }
 }
 
@@ -201,13 +223,14 @@ __device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const 
 
 // Decoder attention, one query per row (AoA_Model.py:329-334 -> :90-120), one wave per (row, head):
 //   s_r = Qp_h . Kd_h[r] / sqrt(d);  P = softmax_R(s);  Pd = drop(P, 0.1);  x_h = sum_r Pd_r Vd_h[r]
-// Kd / Vd: [n_img, R, Hd] (linear_K / linear_V of the refined features, hoisted: time-invariant).
+// Kd / Vd: [n_img, R, Hd] (linear_K / linear_V of the refined features, hoisted: time-invariant).  R <= 128 (two keys per lane);
+// with region counts only the image's valid rows are staged and the masked keys get P = 0 (see mha_self_kernel).
 // Saves P and Pd ([rows, NH, R]) when requested (backward).
 __global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
                                                           const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
                                                           float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
-                                                          int R, int Hd, int NH, DropP dp) {
-    extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [64]
+                                                          int R, int Hd, int NH, const int32_t* __restrict__ lens, DropP dp) {
+    extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128]
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_da;
@@ -215,31 +238,45 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restric
     float* sq = sv + R * ld;
     float* sp = sq + d;
     const int img = img_of_row ? img_of_row[row] : row;
+    const int len = lens ? lens[img] : R;
     const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
-    aoa_stage_kv(Kd + base, Vd + base, sk, sv, R, d, Hd, lane);
+    aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
     for (int j = lane; j < d; j += 64) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
     __syncthreads();
-    float s = -INFINITY;
-    if (lane < R) {
+    const int r1 = lane + 64;
+    const float rs = sqrtf((float)d);
+    float s0 = -INFINITY, s1 = -INFINITY;
+    if (lane < len) {
         float acc = 0.f;
         for (int j = 0; j < d; ++j) acc += sq[j] * sk[lane * ld + j];
-        s = acc / sqrtf((float)d);
+        s0 = acc / rs;
     }
-    const float mx = wave_max(s);
-    const float ex = lane < R ? expf(s - mx) : 0.f;
-    const float sum = wave_sum(ex);
-    const float p = ex / sum;
-    const uint64_t pidx = ((uint64_t)row * NH + hd) * R + lane;
-    const float pd = lane < R ? dp.apply(p, pidx) : 0.f;
+    if (r1 < len) {
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) acc += sq[j] * sk[r1 * ld + j];
+        s1 = acc / rs;
+    }
+    const float mx = wave_max(fmaxf(s0, s1));
+    const float e0 = lane < len ? expf(s0 - mx) : 0.f;
+    const float e1 = r1 < len ? expf(s1 - mx) : 0.f;
+    const float sum = wave_sum(e0 + e1);
+    const float p0 = e0 / sum, p1 = e1 / sum;
+    const uint64_t pidx = ((uint64_t)row * NH + hd) * R;
+    const float pd0 = lane < len ? dp.apply(p0, pidx + lane) : 0.f;
+    const float pd1 = r1 < len ? dp.apply(p1, pidx + r1) : 0.f;
+    sp[lane] = pd0; sp[r1] = pd1;
     if (lane < R) {
-        sp[lane] = pd;
-        if (P_out) P_out[pidx] = p;
-        if (Pd_out) Pd_out[pidx] = pd;
+        if (P_out) P_out[pidx + lane] = p0;
+        if (Pd_out) Pd_out[pidx + lane] = pd0;
+    }
+    if (r1 < R) {
+        if (P_out) P_out[pidx + r1] = p1;
+        if (Pd_out) Pd_out[pidx + r1] = pd1;
     }
     __syncthreads();
     for (int j = lane; j < d; j += 64) {
         float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += sp[r] * sv[r * ld + j];
+        for (int r = 0; r < len; ++r) acc += sp[r] * sv[r * ld + j];
         xatt[(size_t)row * Hd + (size_t)hd * d + j] = acc;
     }
 }
@@ -261,14 +298,16 @@ __global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ 
     ctxdrop[i] = dp.apply(y, i);
 }
 
-// mean over regions of [n_img, R, Hd]
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ m, int R, int Hd) {
+// mean over the (valid) regions of [n_img, R, Hd]  (AoA_Model.py:250-253)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ m, int R, int Hd,
+                                                        const int32_t* __restrict__ lens) {
     const int img = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Hd) return;
+    const int len = lens ? lens[img] : R;
     float s = 0.f;
-    for (int r = 0; r < R; ++r) s += x[((size_t)img * R + r) * Hd + c];
-    m[(size_t)img * Hd + c] = s / (float)R;
+    for (int r = 0; r < len; ++r) s += x[((size_t)img * R + r) * Hd + c];
+    m[(size_t)img * Hd + c] = s / (float)len;
 }
 
 }  // namespace

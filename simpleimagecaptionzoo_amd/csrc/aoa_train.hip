@@ -41,8 +41,8 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
                                                               const float* __restrict__ Pdm, const float* __restrict__ Qp,
                                                               const float* __restrict__ Kd, const float* __restrict__ Vd,
                                                               float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
-                                                              int NH, float keep_scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [64]
+                                                              int NH, const int32_t* __restrict__ lens, float keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [128]
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_db;
@@ -50,69 +50,85 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
     float* sq = sv + R * ld;
     float* sdx = sq + d;
     float* sds = sdx + d;
+    const int len = lens ? lens[row] : R;
     const size_t base = (size_t)row * R * Hd + (size_t)hd * d;
-    aoa_stage_kv(Kd + base, Vd + base, sk, sv, R, d, Hd, lane);
+    aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
     const size_t MN = (size_t)rows * 2 * Hd;
     for (int j = lane; j < d; j += 64) {
         sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
         sdx[j] = sum_slabs1(dxq, ns, MN, (size_t)row * 2 * Hd + (size_t)hd * d + j);
     }
     __syncthreads();
-    const size_t pidx = ((size_t)row * NH + hd) * R + lane;
-    float p = 0.f, pd = 0.f, dP = 0.f;
-    if (lane < R) {
-        p = Pm[pidx]; pd = Pdm[pidx];
+    const size_t pidx = ((size_t)row * NH + hd) * R;
+    const int r1 = lane + 64;
+    float p0 = 0.f, p1 = 0.f, dP0 = 0.f, dP1 = 0.f;
+    if (lane < len) {
+        p0 = Pm[pidx + lane];
         float acc = 0.f;
         for (int j = 0; j < d; ++j) acc += sdx[j] * sv[lane * ld + j];
-        dP = pd != 0.f ? acc * keep_scale : 0.f;
+        dP0 = Pdm[pidx + lane] != 0.f ? acc * keep_scale : 0.f;
     }
-    const float dot = wave_sum(p * dP);
-    const float dS = p * (dP - dot) / sqrtf((float)d);
-    sds[lane] = lane < R ? dS : 0.f;
-    if (lane < R) dS_out[pidx] = dS;
+    if (r1 < len) {
+        p1 = Pm[pidx + r1];
+        float acc = 0.f;
+        for (int j = 0; j < d; ++j) acc += sdx[j] * sv[r1 * ld + j];
+        dP1 = Pdm[pidx + r1] != 0.f ? acc * keep_scale : 0.f;
+    }
+    const float dot = wave_sum(p0 * dP0 + p1 * dP1);
+    const float rs = sqrtf((float)d);
+    const float dS0 = p0 * (dP0 - dot) / rs, dS1 = p1 * (dP1 - dot) / rs;
+    sds[lane] = dS0; sds[r1] = dS1;
+    if (lane < R) dS_out[pidx + lane] = dS0;
+    if (r1 < R) dS_out[pidx + r1] = dS1;
     __syncthreads();
     for (int j = lane; j < d; j += 64) {
         float acc = 0.f;
-        for (int r = 0; r < R; ++r) acc += sds[r] * sk[r * ld + j];
+        for (int r = 0; r < len; ++r) acc += sds[r] * sk[r * ld + j];
         dQp[(size_t)row * Hd + (size_t)hd * d + j] = acc;
         dx_out[(size_t)row * Hd + (size_t)hd * d + j] = sdx[j];
     }
 }
 
-// dKd[img, r, head cols] = sum_t dS_t[img, head, r] Qp_t[img, head cols];  dVd = sum_t Pd_t[r] dx_t   (grid (B, NH), 256 threads)
+// dKd[img, r, head cols] = sum_t dS_t[img, head, r] Qp_t[img, head cols];  dVd = sum_t Pd_t[r] dx_t   (grid (B, NH), 256 threads).
+// The steps go through LDS in chunks of TC (all of them at the usual 20 steps x 36 regions).
 __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ dS_all, const float* __restrict__ Pd_all,
                                                       const float* __restrict__ Qp_all, const float* __restrict__ dx_all,
-                                                      float* __restrict__ dKd, float* __restrict__ dVd, int B, int T, int R, int Hd, int NH) {
-    extern __shared__ __attribute__((aligned(16))) float sm_kv[];       // dS [T][R], Pd [T][R], Qp [T][d], dx [T][d]
+                                                      float* __restrict__ dKd, float* __restrict__ dVd, int B, int T, int TC, int R, int Hd, int NH) {
+    extern __shared__ __attribute__((aligned(16))) float sm_kv[];       // dS [TC][R], Pd [TC][R], Qp [TC][d], dx [TC][d]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int d = Hd / NH;
     float* sds = sm_kv;
-    float* spd = sds + T * R;
-    float* sq = spd + T * R;
-    float* sdx = sq + T * d;
-    for (int i = tid; i < T * R; i += 256) {
-        const int t = i / R, r = i % R;
-        const size_t g = (((size_t)t * B + img) * NH + hd) * R + r;
-        sds[i] = dS_all[g];
-        spd[i] = Pd_all[g];
-    }
-    for (int i = tid; i < T * d; i += 256) {
-        const int t = i / d, j = i % d;
-        const size_t g = ((size_t)t * B + img) * Hd + (size_t)hd * d + j;
-        sq[i] = Qp_all[g];
-        sdx[i] = dx_all[g];
-    }
-    __syncthreads();
+    float* spd = sds + TC * R;
+    float* sq = spd + TC * R;
+    float* sdx = sq + TC * d;
     const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
-    for (int i = tid; i < R * d; i += 256) {
-        const int r = i / d, j = i % d;
-        float dk = 0.f, dv = 0.f;
-        for (int t = 0; t < T; ++t) {
-            dk += sds[t * R + r] * sq[t * d + j];
-            dv += spd[t * R + r] * sdx[t * d + j];
+    for (int t0 = 0; t0 < T; t0 += TC) {
+        const int nt = min(TC, T - t0);
+        for (int i = tid; i < nt * R; i += 256) {
+            const int t = t0 + i / R, r = i % R;
+            const size_t g = (((size_t)t * B + img) * NH + hd) * R + r;
+            sds[i] = dS_all[g];
+            spd[i] = Pd_all[g];
         }
-        dKd[base + (size_t)r * Hd + j] = dk;
-        dVd[base + (size_t)r * Hd + j] = dv;
+        for (int i = tid; i < nt * d; i += 256) {
+            const int t = t0 + i / d, j = i % d;
+            const size_t g = ((size_t)t * B + img) * Hd + (size_t)hd * d + j;
+            sq[i] = Qp_all[g];
+            sdx[i] = dx_all[g];
+        }
+        __syncthreads();
+        for (int i = tid; i < R * d; i += 256) {
+            const int r = i / d, j = i % d;
+            const size_t o = base + (size_t)r * Hd + j;
+            float dk = t0 ? dKd[o] : 0.f, dv = t0 ? dVd[o] : 0.f;
+            for (int t = 0; t < nt; ++t) {
+                dk += sds[t * R + r] * sq[t * d + j];
+                dv += spd[t * R + r] * sdx[t * d + j];
+            }
+            dKd[o] = dk;
+            dVd[o] = dv;
+        }
+        __syncthreads();
     }
 }
 
@@ -221,7 +237,7 @@ int Aoa::ensure_train() {
 
 // step t of a training-mode pass over cur_B rows: inputs / outputs are slots of the saved [T, B, ...] tensors
 AoaStepIO Aoa::train_io(int rows, int t, bool train) {
-    const size_t B = cur_B, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = dims.R;
+    const size_t B = cur_B, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = cur_R;
     const size_t s0 = (size_t)t * B, s1 = s0 + B;
     AoaStepIO s = {};
     s.rows = rows; s.img_of_row = nullptr; s.it = tok + s0; s.emb_ready = false;
@@ -386,7 +402,7 @@ int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, in
 
 int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     use_bank(1);
-    const int B = cur_B, T = cur_T, Hd = dims.Hd, E = dims.E, V = dims.V, NH = dims.NH, R = dims.R, dh = Hd / NH;
+    const int B = cur_B, T = cur_T, Hd = dims.Hd, E = dims.E, V = dims.V, NH = dims.NH, R = cur_R, dh = Hd / NH;
     const int TB = T * B;
     const size_t sH = (size_t)B * Hd;
     int ns = 1;
@@ -422,7 +438,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         int ns2 = 1, nsq = 1;
         ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
-                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, io.d_att.mode ? io.d_att.scale : 1.0f);
+                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, lens, io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(64), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
                            P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
@@ -459,8 +475,11 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
     ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st));
     ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));
-    hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)T * 2 * (R + dh), st, tdS, tPd, tQp, tdX, dKd, dVd, B, T, R,
-                       Hd, NH);
+    {
+        const int tc_fit = (int)(48 * 1024 / (sizeof(float) * 2 * (R + dh))), tc = T < tc_fit ? T : tc_fit;
+        hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)tc * 2 * (R + dh), st, tdS, tPd, tQp, tdX, dKd, dVd, B, T,
+                           tc, R, Hd, NH);
+    }
     ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.k_w, Hd, 0, st));
     ICZ_TRY(colsum(dKd, B * R, Hd, Hd, G.dec.k_b, st));
     ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.v_w, Hd, 0, st));

@@ -156,26 +156,32 @@ class BUTDDetection_Eng(Engine):
             return {"bu_feats": supp_info_datas["bu_feats"], "bu_bboxes": supp_info_datas.get("bu_bboxes"), "bu_masks": None}
         bu_feats = [s["bu_feat"] for s in supp_info_datas]
         bu_bboxes = [s["bu_bbox"] for s in supp_info_datas]
-        max_len = max(f.shape[0] for f in bu_feats)
+        counts = [int(f.shape[0]) for f in bu_feats]
+        max_len = max(counts)
         B, D = len(bu_feats), bu_feats[0].shape[1]
-        if self._pinned is None or self._pinned.shape[0] < B or tuple(self._pinned.shape[1:]) != (max_len, D):
-            self._pinned = torch.zeros(max(B, 1), max_len, D, dtype=torch.float32).pin_memory()
-        host = self._pinned[:B]
+        # flat staging buffers sized for the largest batch seen: 'adaptive' batches change max_len every step
+        need = B * max_len * D
+        if self._pinned is None or self._pinned.numel() < need:
+            self._pinned = torch.zeros(need, dtype=torch.float32).pin_memory()
+            self._dev_feats = torch.empty(need, dtype=torch.float32, device=self.device)
+        if getattr(self, "_h2d_done", None) is not None:
+            self._h2d_done.synchronize()         # the previous batch's copy has left the pinned buffer
+        host = self._pinned[:need].view(B, max_len, D)
         hv = host.numpy()
-        masks = np.zeros((B, max_len), dtype="float32")
         for i, f in enumerate(bu_feats):
-            n = f.shape[0]
-            hv[i, :n] = f
-            if n < max_len:
-                hv[i, n:] = 0
-            masks[i, :n] = 1
-        bu_masks = None if masks.sum() == masks.size else torch.from_numpy(masks).float().to(self.device)
-        # copy into a persistent device buffer: a stable address lets the captured graphs be replayed
-        if self._dev_feats is None or self._dev_feats.shape[0] < B or tuple(self._dev_feats.shape[1:]) != (max_len, D):
-            self._dev_feats = torch.empty(max(B, 1), max_len, D, dtype=torch.float32, device=self.device)
-        feats = self._dev_feats[:B]
+            hv[i, :counts[i]] = f
+            if counts[i] < max_len:
+                hv[i, counts[i]:] = 0
+        # a persistent device buffer: a stable address lets the captured graphs be replayed
+        feats = self._dev_feats[:need].view(B, max_len, D)
         feats.copy_(host, non_blocking=True)
-        return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": bu_masks}
+        self._h2d_done = torch.cuda.Event()
+        self._h2d_done.record()
+        if min(counts) == max_len:
+            return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": None}
+        masks = (torch.arange(max_len).unsqueeze(0) < torch.tensor(counts).unsqueeze(1)).float().to(self.device)
+        # `bu_counts` (extension): the counts behind the prefix mask, so that the Captioner need not read the mask back
+        return {"bu_feats": feats, "bu_bboxes": bu_bboxes, "bu_masks": masks, "bu_counts": counts}
 
     # ---- helpers ------------------------------------------------------------------------------------------
     # Gradient groups in the order the backward pass completes them (include/icz.h: icz_butd_set_grad_callback); the flat
@@ -383,15 +389,21 @@ class BUTDDetection_Eng(Engine):
 
 
 class AoADetection_Eng(BUTDDetection_Eng):
-    """ModelEngines/AoA_Engine.py (same visual-input handling as the BUTD engine) + the three hot Engine methods."""
+    """ModelEngines/AoA_Engine.py (same visual-input handling as the BUTD engine) + the three hot Engine methods.
+    `use_bu='adaptive'` (10..100 boxes per image, Main.py:158): the handle is sized for 100 regions and every batch carries
+    its region counts (AoA_Engine.py:37-46 builds the equivalent prefix masks)."""
 
     def model_construction(self, max_batch):
         from .aoa import AoADetection_Captioner
         s = self.settings
         assert s["model_type"] in ("AoADetection", "AoASpatial")
+        regions = s.get("num_regions", 100 if self.use_bu == "adaptive" else 36)
         return AoADetection_Captioner(vocab_size=len(self.caption_vocab), num_heads=s.get("num_heads", 8), hidden_dim=s["hidden_dim"],
-                                      embed_dim=s["embed_dim"], device=str(self.device), num_regions=s.get("num_regions", 36),
+                                      embed_dim=s["embed_dim"], device=str(self.device), num_regions=regions,
                                       enc_dim=s.get("enc_dim", 2048), max_batch=max_batch)
+
+    def _features(self, visual_inputs):
+        return self.model._feats(visual_inputs)
 
 
 class NIC_Eng(BUTDDetection_Eng):

@@ -442,16 +442,17 @@ def gen_nic_decoder(tag, B, H, E, V, seed):
 
 
 # ------------------------------------------------------------------------------------------------
-def gen_aoa(tag, B, Hd, E, V, seed):
+def gen_aoa(tag, B, Hd, E, V, seed, counts=None):
     """AoADetection_Captioner (Models/AoA_Model.py:657-753): feature projection + 6-layer AoA refiner (eval and train
     mode), decoder greedy / beam / XE / sample_rl with REINFORCE gradients of the decoder parameters (the only ones the
-    reference optimises, AoA_Model.py:669-674)."""
-    from Models.AoA_Model import AoADetection_Captioner
+    reference optimises, AoA_Model.py:669-674).  counts = regions per image of an 'adaptive' batch: features padded with
+    zero rows to max(counts) and prefix bu_masks, as AoA_Engine.modify_visual_inputs builds them (AoA_Engine.py:33-46)."""
+    from Models.AoA_Model import AoADetection_Captioner, pack_wrapper
     from Utils import LabelSmoothingLoss, RewardCriterion
     from torch.nn.utils.rnn import pack_padded_sequence
     torch.manual_seed(seed)
     rng = np.random.RandomState(seed)
-    R, D, NH = 36, 2048, 8
+    R, D, NH = (max(counts) if counts else 36), 2048, 8
     m = AoADetection_Captioner(vocab_size=V, num_heads=NH, hidden_dim=Hd, embed_dim=E)
     dec = m.decoder
     with torch.no_grad():
@@ -468,11 +469,17 @@ def gen_aoa(tag, B, Hd, E, V, seed):
     fseed = seed * 1000 + 1
     feats = torch.from_numpy(feats_from_seed(fseed, B, R, D))
     out = {"dims": np.array([B, R, D, Hd, E, V, NH], dtype=np.int64), "feats_seed": np.int64(fseed)}
+    bu_masks = None
+    if counts:
+        assert len(counts) == B and len(set(counts)) == B       # distinct: the reference's length sort has no tie rule
+        bu_masks = (torch.arange(R).unsqueeze(0) < torch.tensor(counts).view(-1, 1)).float()
+        feats = feats * bu_masks.unsqueeze(-1)
+        out["region_counts"] = np.array(counts, dtype=np.int32)
     out.update({"sd." + k: v for k, v in sd_to_np(m.state_dict()).items()})
-    vi = {"bu_feats": feats, "bu_bboxes": None, "bu_masks": None}
+    vi = {"bu_feats": feats, "bu_bboxes": None, "bu_masks": bu_masks}
     m.eval()
     with torch.no_grad():
-        refined = m.aoa_refine(m.img_feats_porjection(feats))
+        refined = m.aoa_refine(pack_wrapper(m.img_feats_porjection, feats, bu_masks), bu_masks)
     out["refined_eval"] = refined.numpy()
     rec = []
     hk = dec.predict.register_forward_hook(lambda mod, i, o: rec.append(o.detach().clone()))
@@ -496,7 +503,8 @@ def gen_aoa(tag, B, Hd, E, V, seed):
                 dec.predict.bias[2] = dec.predict.bias[tok] - 0.2
         for k in (1, 3, 5):
             for img in range(min(B, 3)):
-                one = {"bu_feats": feats[img:img + 1], "bu_bboxes": None, "bu_masks": None}
+                # beam search runs one image at a time: its batch is never padded, so bu_masks is None there (AoA_Engine.py:41-42)
+                one = {"bu_feats": feats[img:img + 1, :counts[img]] if counts else feats[img:img + 1], "bu_bboxes": None, "bu_masks": None}
                 with torch.no_grad(), legacy_int_div():
                     seq = m.beam_search_sampler(one, beam_size=k)
                 out["beam_%s_k%d_i%d" % (regime, k, img)] = np.asarray(seq.numpy(), dtype=np.float32)
@@ -509,6 +517,17 @@ def gen_aoa(tag, B, Hd, E, V, seed):
         """recorded (p, mask) list in call order -> named arrays (bit-packed along the last axis)."""
         it = iter(recs)
         d = {"proj": next(it)[1]}
+        if counts:      # the projection ran on the packed valid rows (pack_wrapper): region-major over the images sorted by
+            order = np.argsort(-np.asarray(counts), kind="stable")        # decreasing count -> back to the padded [B, R, Hd]
+            padded = np.zeros((B, R, Hd), dtype=np.uint8)
+            row = 0
+            for r in range(R):
+                for b in order:
+                    if counts[b] > r:
+                        padded[b, r] = d["proj"][row]
+                        row += 1
+            assert row == d["proj"].shape[0] == sum(counts)
+            d["proj"] = padded
         ra, rg, rs = [], [], []
         for _ in range(6):
             ra.append(next(it)[1]); rg.append(next(it)[1]); rs.append(next(it)[1])
@@ -899,6 +918,7 @@ if __name__ == "__main__":
         gen_nic_decoder("nic_dec_odd", B=3, H=48, E=16, V=70, seed=32)
     if "aoa" in which:
         gen_aoa("aoa_tiny", B=4, Hd=32, E=16, V=53, seed=41)
+        gen_aoa("aoa_adaptive", B=4, Hd=32, E=16, V=53, seed=43, counts=[70, 23, 66, 41])
     if "cider" in which:
         gen_cider("ciderd_cases", seed=5)
     if "corpus" in which:

@@ -287,13 +287,24 @@ def aoa_masks(g, prefix):
     return {k: np.unpackbits(g[prefix + k], axis=-1)[..., :w[k]] for k in w}
 
 
-@pytest.fixture(scope="module")
-def aoa(golden_dir):
-    from oracle import aoa as oa
-    g = load(golden_dir, "aoa_tiny")
+def aoa_inputs(g):
+    """(features [B, R, D], region counts or None): the 'adaptive' fixture pads every image to the largest count with
+    zero rows (AoA_Engine.py:33-40)."""
     B, R, D, Hd, E, V, NH = [int(x) for x in g["dims"]]
     feats = torch.from_numpy(feats_from_seed(int(g["feats_seed"]), B, R, D))
-    return oa, g, feats
+    if "region_counts" not in g:
+        return feats, None
+    counts = [int(x) for x in g["region_counts"]]
+    keep = (torch.arange(R).unsqueeze(0) < torch.tensor(counts).view(-1, 1)).float()
+    return feats * keep.unsqueeze(-1), counts
+
+
+@pytest.fixture(scope="module", params=["aoa_tiny", "aoa_adaptive"])
+def aoa(golden_dir, request):
+    from oracle import aoa as oa
+    g = load(golden_dir, request.param)
+    feats, counts = aoa_inputs(g)
+    return oa, g, feats, counts
 
 
 def aoa_params(g, requires_grad=False):
@@ -307,10 +318,10 @@ def aoa_params(g, requires_grad=False):
 
 
 def test_aoa_refiner_greedy_beam(aoa):
-    oa, g, feats = aoa
+    oa, g, feats, counts = aoa
     p = aoa_params(g)
-    np.testing.assert_allclose(oa.refine(feats, p).numpy(), g["refined_eval"], atol=2e-5, rtol=1e-5)
-    ids, logits = oa.greedy(feats, p, 20)
+    np.testing.assert_allclose(oa.refine(feats, p, lens=counts).numpy(), g["refined_eval"], atol=2e-5, rtol=1e-5)
+    ids, logits = oa.greedy(feats, p, 20, lens=counts)
     assert np.array_equal(ids.numpy(), g["greedy_ids"])
     np.testing.assert_allclose(logits.numpy(), g["greedy_logits"], atol=1e-4)
     for regime, k, img in BEAM_CASES:
@@ -325,15 +336,19 @@ def test_aoa_refiner_greedy_beam(aoa):
             q["decoder.predict.weight_g"][2] = q["decoder.predict.weight_g"][tok]
             q["decoder.predict.bias"][2] = q["decoder.predict.bias"][tok] - 0.2
         want = g["beam_%s_k%d_i%d" % (regime, k, img)]
-        got = oa.beam_search(feats[img:img + 1], q, k).numpy()
+        one = feats[img:img + 1] if counts is None else feats[img:img + 1, :counts[img]]       # beam: one unpadded image at a time
+        got = oa.beam_search(one, q, k).numpy()
         assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img)
+        if counts is not None and k == 3:        # the padded image with its mask decodes the same
+            got = oa.beam_search(feats[img:img + 1], q, k, lens=counts[img:img + 1]).numpy()
+            assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img, "masked")
 
 
 def test_aoa_xe_and_rl_decoder_grads(aoa):
-    oa, g, feats = aoa
+    oa, g, feats, counts = aoa
     p = aoa_params(g, True)
     lengths = g["xe_lengths"].tolist()
-    logits = oa.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p, aoa_masks(g, "xe_mask."))
+    logits = oa.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p, aoa_masks(g, "xe_mask."), lens=counts)
     np.testing.assert_allclose(logits.detach().numpy(), g["xe_packed_logits"], atol=1e-4)
     tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
     loss = ob.label_smoothing_loss(logits, tgt, 0.1)
@@ -345,7 +360,7 @@ def test_aoa_xe_and_rl_decoder_grads(aoa):
     p = aoa_params(g, True)
     with torch.no_grad():
         p["decoder.predict.bias"][2] = float(g["rl_end_bias"])
-    seq, lp = oa.sample_rl(feats, p, g["rl_u"], aoa_masks(g, "rl_mask."), 20)
+    seq, lp = oa.sample_rl(feats, p, g["rl_u"], aoa_masks(g, "rl_mask."), 20, lens=counts)
     assert np.array_equal(seq.numpy(), g["rl_seq"])
     np.testing.assert_allclose(lp.detach().numpy(), g["rl_logprobs"], atol=1e-5)
     loss = ob.reward_criterion(lp, seq, torch.from_numpy(g["rl_reward"]))
