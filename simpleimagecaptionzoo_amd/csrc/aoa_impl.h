@@ -78,15 +78,15 @@ struct Aoa {
     int cur_R = 0, lens_n = 0;
     const int32_t* lens = nullptr;
     static constexpr size_t LDS_BUDGET = 156 * 1024;
-    size_t self_lds(int R, int qc) const {
-        const size_t dh = dims.Hd / dims.NH;
-        return sizeof(float) * (2 * (size_t)R * (dh + 1) + (size_t)qc * (dh + 1) + (size_t)qc * (R + 1));
+    size_t self_lds(int R, int qc) const {       // mha_self_kernel: K, V [R4][ld] + Q chunk [qc4][ld] + P [qc4][lp]
+        const size_t ld = aoa_pitch(dims.Hd / dims.NH), lp = aoa_pitch(R), R4 = (R + 3) & ~3, q4 = (qc + 3) & ~3;
+        return sizeof(float) * (2 * R4 * ld + q4 * ld + q4 * lp);
     }
     int self_qc(int R) const {       // query rows per pass of mha_self_kernel: all of them when the tiles fit
-        const size_t dh = dims.Hd / dims.NH, kv = sizeof(float) * 2 * (size_t)R * (dh + 1);
-        if (kv >= LDS_BUDGET) return 0;
-        const size_t qc = (LDS_BUDGET - kv) / (sizeof(float) * (dh + 1 + R + 1));
-        return (int)(qc < (size_t)R ? qc : (size_t)R);
+        if (self_lds(R, R) <= LDS_BUDGET) return R;
+        int qc = R & ~3;
+        while (qc >= 4 && self_lds(R, qc) > LDS_BUDGET) qc -= 4;
+        return qc >= 4 ? qc : 0;
     }
     bool cur_train = false;
     const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr;

@@ -102,46 +102,92 @@ __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict
     if (stats && lane == 0) { stats[2 * row] = mean; stats[2 * row + 1] = inv; }
 }
 
+// LDS row pitches of the attention tiles, in floats: a multiple of 4 (16-byte row reads) whose count of 16-byte slots is
+// odd, so that consecutive rows start in different bank groups
+__host__ __device__ __forceinline__ int aoa_pitch(int n) {
+    int n4 = (n + 3) / 4;
+    if ((n4 & 1) == 0) ++n4;
+    return 4 * n4;
+}
+
 // Refiner self-attention (AoA_Model.py:41-69,113-117), one workgroup per (image, head):
 //   S = Q_h K_h^T / sqrt(d);  S[:, r] = -1e9 where bu_mask[r] == 0;  P = softmax_rows(S);  P = drop(P, 0.1);  O_h = P V_h
 // Q, K, V: [n_img, R, Hd] with head h in columns [h*d, (h+1)*d).  R <= 128.  The K and V head tiles stay in LDS while the
 // queries go through in chunks of QC rows (QC = R when everything fits: 36 and 49 regions).  bu_masks are prefix masks
 // (AoA_Engine.py:37-40), given as the valid count per image: exp(-1e9 - max) is exactly 0 in fp32, so the masked keys are
 // skipped rather than computed.
+// Both products are register-blocked: a thread owns a 4 x 4 block of S (rows q, q + nq/4, ...; keys r, r + len/4, ...) or a
+// 4 x 4 block of O (4 strided rows x 4 adjacent columns) and walks the reduction dimension four at a time with 16-byte LDS
+// reads -- 8 reads per 64 FMAs, where one element per thread needs 2 reads per FMA and leaves the kernel LDS-bound.
 __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
                                                        float* __restrict__ O, int R, int Hd, int NH, int QC, const int32_t* __restrict__ lens,
                                                        DropP dp) {
-    extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // K,V tiles [R][d+1], Q chunk [QC][d+1], P [QC][R+1]
+    extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // K,V tiles [R4][ld], Q chunk [QC4][ld], P [QC4][lp]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
-    const int d = Hd / NH, ld = d + 1, lp = R + 1;
-    const int len = lens ? lens[img] : R;
+    const int d = Hd / NH, d4 = d >> 2, ld = aoa_pitch(d), lp = aoa_pitch(R);
+    const int R4 = (R + 3) & ~3, QC4 = (QC + 3) & ~3;
+    const int len = lens ? lens[img] : R, len4 = (len + 3) & ~3;
     float* sk = sm_mha;
-    float* sv = sk + R * ld;
-    float* sq = sv + R * ld;
-    float* sp = sq + QC * ld;
+    float* sv = sk + R4 * ld;
+    float* sq = sv + R4 * ld;
+    float* sp = sq + QC4 * ld;
     const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
-    for (int i = tid; i < len * d; i += 256) {
-        const int r = i / d, j = i % d;
-        const size_t g = base + (size_t)r * Hd + j;
-        sk[r * ld + j] = K[g]; sv[r * ld + j] = V[g];
+    for (int i = tid; i < len4 * d4; i += 256) {
+        const int r = i / d4, j = (i % d4) * 4;
+        f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;              // rows [len, len4) are read by the last block of four: zeros
+        if (r < len) {
+            kk = *reinterpret_cast<const f32x4*>(K + base + (size_t)r * Hd + j);
+            vv = *reinterpret_cast<const f32x4*>(V + base + (size_t)r * Hd + j);
+        }
+        *reinterpret_cast<f32x4*>(sk + r * ld + j) = kk;
+        *reinterpret_cast<f32x4*>(sv + r * ld + j) = vv;
     }
     const float scale = 1.0f / sqrtf((float)d);
     const int lane = tid & 63, wave = tid >> 6;
+    const int nrt = len4 >> 2;
     for (int q0 = 0; q0 < R; q0 += QC) {
-        const int nq = min(QC, R - q0);
-        for (int i = tid; i < nq * d; i += 256) {
-            const int r = i / d, j = i % d;
-            sq[r * ld + j] = Q[base + (size_t)(q0 + r) * Hd + j];
+        const int nq = min(QC, R - q0), nqt = (nq + 3) >> 2;
+        for (int i = tid; i < nq * d4; i += 256) {
+            const int r = i / d4, j = (i % d4) * 4;
+            *reinterpret_cast<f32x4*>(sq + r * ld + j) = *reinterpret_cast<const f32x4*>(Q + base + (size_t)(q0 + r) * Hd + j);
         }
         __syncthreads();
-        for (int i = tid; i < nq * len; i += 256) {
-            const int q = i / len, r = i % len;
-            float acc = 0.f;
-            for (int j = 0; j < d; ++j) acc += sq[q * ld + j] * sk[r * ld + j];
-            sp[q * lp + r] = acc * scale;
+        for (int i = tid; i < nqt * nrt; i += 256) {
+            const int qt = i / nrt, rt = i % nrt;
+            const float *qp[4], *kp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+                qp[c] = sq + min(qt + c * nqt, nq - 1) * ld;
+                kp[c] = sk + min(rt + c * nrt, len - 1) * ld;
+            }
+            float acc[4][4] = {};
+            for (int j = 0; j < d; j += 4) {
+                f32x4 qv[4], kv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    qv[c] = *reinterpret_cast<const f32x4*>(qp[c] + j);
+                    kv[c] = *reinterpret_cast<const f32x4*>(kp[c] + j);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) acc[a][b] += qv[a][e] * kv[b][e];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int q = qt + a * nqt;
+                if (q >= nq) continue;
+#pragma unroll
+                for (int b = 0; b < 4; ++b) {
+                    const int r = rt + b * nrt;
+                    if (r < len) sp[q * lp + r] = acc[a][b] * scale;
+                }
+            }
         }
         __syncthreads();
-        // softmax per query row: one wave per row, two keys per lane
+        // softmax per query row: one wave per row, two keys per lane; columns [len, len4) are zeroed for the blocked P V
         for (int q = wave; q < nq; q += 4) {
             const int r1 = lane + 64;
             const float v0 = lane < len ? sp[q * lp + lane] : -INFINITY;
@@ -151,15 +197,33 @@ __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__
             const float e1 = r1 < len ? expf(v1 - mx) : 0.f;
             const float sum = wave_sum(e0 + e1);
             const uint64_t idx = (((uint64_t)img * NH + hd) * R + (q0 + q)) * R;
-            if (lane < len) sp[q * lp + lane] = dp.apply(e0 / sum, idx + lane);
-            if (r1 < len) sp[q * lp + r1] = dp.apply(e1 / sum, idx + r1);
+            if (lane < len4) sp[q * lp + lane] = lane < len ? dp.apply(e0 / sum, idx + lane) : 0.f;
+            if (r1 < len4) sp[q * lp + r1] = r1 < len ? dp.apply(e1 / sum, idx + r1) : 0.f;
         }
         __syncthreads();
-        for (int i = tid; i < nq * d; i += 256) {
-            const int q = i / d, j = i % d;
-            float acc = 0.f;
-            for (int r = 0; r < len; ++r) acc += sp[q * lp + r] * sv[r * ld + j];
-            O[base + (size_t)(q0 + q) * Hd + j] = acc;
+        for (int i = tid; i < nqt * d4; i += 256) {
+            const int qt = i / d4, j = (i % d4) * 4;
+            const float* pp[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c) pp[c] = sp + min(qt + c * nqt, nq - 1) * lp;
+            f32x4 acc[4] = {};
+            for (int r = 0; r < len4; r += 4) {
+                f32x4 pv[4], vv[4];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                    pv[c] = *reinterpret_cast<const f32x4*>(pp[c] + r);
+                    vv[c] = *reinterpret_cast<const f32x4*>(sv + (r + c) * ld + j);
+                }
+#pragma unroll
+                for (int a = 0; a < 4; ++a)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[a] += pv[a][e] * vv[e];
+            }
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const int q = qt + a * nqt;
+                if (q < nq) *reinterpret_cast<f32x4*>(O + base + (size_t)(q0 + q) * Hd + j) = acc[a];
+            }
         }
         __syncthreads();
     }
