@@ -152,8 +152,13 @@ class BUTDDetection_Eng(Engine):
         """BUTD_Engine.py:23-47: stack per-image (n_i, D) features into (B, max_n, D) fp32 + mask (None if all
         rows are full).  Staged through a reusable pinned buffer and copied asynchronously."""
         if isinstance(supp_info_datas, dict) and torch.is_tensor(supp_info_datas.get("bu_feats")):
-            # extension: a batch already resident in HBM (prefetching loaders, bench.py)
-            return {"bu_feats": supp_info_datas["bu_feats"], "bu_bboxes": supp_info_datas.get("bu_bboxes"), "bu_masks": None}
+            # extension: a batch already resident in HBM (prefetching loaders, bench.py); padded batches carry their counts
+            feats, counts = supp_info_datas["bu_feats"], supp_info_datas.get("bu_counts")
+            out = {"bu_feats": feats, "bu_bboxes": supp_info_datas.get("bu_bboxes"), "bu_masks": None}
+            if counts is not None:
+                out["bu_masks"] = (torch.arange(feats.shape[1]).unsqueeze(0) < torch.tensor(counts).unsqueeze(1)).float().to(self.device)
+                out["bu_counts"] = list(counts)
+            return out
         bu_feats = [s["bu_feat"] for s in supp_info_datas]
         bu_bboxes = [s["bu_bbox"] for s in supp_info_datas]
         counts = [int(f.shape[0]) for f in bu_feats]

@@ -11,7 +11,10 @@ features are packed once into one flat, memory-mapped fp32 file and streamed to 
                         buffer and copies it on a side stream while batch i is being decoded; it yields the same tuples with
                         `supp_info_datas` replaced by {'bu_feats': device tensor, 'bu_bboxes': [...]}, which the Engines'
                         `modify_visual_inputs` passes through unchanged.
-The bytes are the reference's (fp32, no re-quantisation), so results do not change.  Fixed 36-region features only.
+The bytes are the reference's (fp32, no re-quantisation), so results do not change.  'fixed' feature sets (36 rows per image)
+are stored as one [N, R, D] array; 'adaptive' ones (10..100 rows per image, Datasets.py:59-61) as the concatenation of the
+images' rows with an offset table, and a batch is padded with zero rows to its largest count exactly as
+AoA_Engine.modify_visual_inputs does (AoA_Engine.py:33-40), the counts travelling with it as `bu_counts`.
 """
 import json
 import os
@@ -20,18 +23,43 @@ import numpy as np
 import torch
 
 
+def _feat_path(supp_dir, kind, i):
+    return os.path.join(supp_dir, "%s_bu_feat/%s.npz" % (kind, i))
+
+
 def pack_npz_dir(supp_dir, img_ids, out_prefix, kind="fixed"):
     """Pack `<supp_dir>/<kind>_bu_feat/<id>.npz['feat']` (and `<kind>_bu_bbox/<id>.npy`) of `img_ids` into
-    `<out_prefix>.feats.npy`, `<out_prefix>.boxes.npy`, `<out_prefix>.index.json`.  All images must have the same (R, D)."""
+    `<out_prefix>.feats.npy`, `<out_prefix>.boxes.npy`, `<out_prefix>.index.json`.  kind='fixed': every image has the same
+    (R, D) -> [N, R, D]; kind='adaptive': (n_i, D) per image -> [sum n_i, D] + offsets."""
     img_ids = list(img_ids)
-    first = np.load(os.path.join(supp_dir, "%s_bu_feat/%s.npz" % (kind, img_ids[0])))["feat"]
+    if kind == "adaptive":
+        counts = [int(np.load(_feat_path(supp_dir, kind, i))["feat"].shape[0]) for i in img_ids]
+        offsets = np.concatenate([[0], np.cumsum(counts)]).astype(np.int64)
+        D = int(np.load(_feat_path(supp_dir, kind, img_ids[0]))["feat"].shape[1])
+        feats = np.lib.format.open_memmap(out_prefix + ".feats.npy", mode="w+", dtype=np.float32, shape=(int(offsets[-1]), D))
+        boxes = np.zeros((int(offsets[-1]), 4), dtype=np.float32)
+        for n, i in enumerate(img_ids):
+            f = np.load(_feat_path(supp_dir, kind, i))["feat"]
+            if f.shape != (counts[n], D):
+                raise ValueError("image %s changed shape while packing: %s" % (i, f.shape))
+            feats[offsets[n]:offsets[n + 1]] = f
+            bpath = os.path.join(supp_dir, "%s_bu_bbox/%s.npy" % (kind, i))
+            if os.path.exists(bpath):
+                boxes[offsets[n]:offsets[n + 1]] = np.load(bpath)
+        feats.flush()
+        del feats
+        np.save(out_prefix + ".boxes.npy", boxes)
+        with open(out_prefix + ".index.json", "w") as fh:
+            json.dump({"ids": [str(i) for i in img_ids], "D": D, "offsets": [int(x) for x in offsets]}, fh)
+        return out_prefix
+    first = np.load(_feat_path(supp_dir, kind, img_ids[0]))["feat"]
     R, D = first.shape
     feats = np.lib.format.open_memmap(out_prefix + ".feats.npy", mode="w+", dtype=np.float32, shape=(len(img_ids), R, D))
     boxes = np.zeros((len(img_ids), R, 4), dtype=np.float32)
     for n, i in enumerate(img_ids):
-        f = np.load(os.path.join(supp_dir, "%s_bu_feat/%s.npz" % (kind, i)))["feat"]
+        f = np.load(_feat_path(supp_dir, kind, i))["feat"]
         if f.shape != (R, D):
-            raise ValueError("image %s has %s features, expected %s: only fixed-size feature sets can be packed" % (i, f.shape, (R, D)))
+            raise ValueError("image %s has %s features, expected %s: pack variable-size feature sets with kind='adaptive'" % (i, f.shape, (R, D)))
         feats[n] = f
         bpath = os.path.join(supp_dir, "%s_bu_bbox/%s.npy" % (kind, i))
         if os.path.exists(bpath):
@@ -45,15 +73,21 @@ def pack_npz_dir(supp_dir, img_ids, out_prefix, kind="fixed"):
 
 
 class PackedFeatureStore:
-    """Read side of pack_npz_dir(): `store[img_id]` -> {'bu_feat': (R, D) fp32 view, 'bu_bbox': (R, 4)} -- the dict the
-    reference's datasets put into `supp_info_data` (Datasets.py:54-58)."""
+    """Read side of pack_npz_dir(): `store[img_id]` -> {'bu_feat': (n, D) fp32 view, 'bu_bbox': (n, 4)} -- the dict the
+    reference's datasets put into `supp_info_data` (Datasets.py:54-62).  `ragged` stores hold a different n per image."""
 
     def __init__(self, prefix):
         meta = json.load(open(prefix + ".index.json"))
-        self.R, self.D = meta["R"], meta["D"]
+        self.D = meta["D"]
         self.row = {k: n for n, k in enumerate(meta["ids"])}
         self.feats = np.load(prefix + ".feats.npy", mmap_mode="r")
         self.boxes = np.load(prefix + ".boxes.npy", mmap_mode="r")
+        self.ragged = "offsets" in meta
+        if self.ragged:
+            self.offsets = np.asarray(meta["offsets"], dtype=np.int64)
+            self.R = int(np.diff(self.offsets).max())          # the largest count: capacity of a padded batch
+        else:
+            self.R = meta["R"]
 
     def __len__(self):
         return len(self.row)
@@ -61,14 +95,33 @@ class PackedFeatureStore:
     def __contains__(self, img_id):
         return str(img_id) in self.row
 
+    def _rows(self, img_id):
+        n = self.row[str(img_id)]
+        return (self.offsets[n], self.offsets[n + 1]) if self.ragged else None
+
     def __getitem__(self, img_id):
+        if self.ragged:
+            lo, hi = self._rows(img_id)
+            return {"bu_feat": self.feats[lo:hi], "bu_bbox": self.boxes[lo:hi]}
         n = self.row[str(img_id)]
         return {"bu_feat": self.feats[n], "bu_bbox": self.boxes[n]}
 
+    def counts(self, img_ids):
+        """Rows per image (the batch is padded to their maximum)."""
+        if not self.ragged:
+            return [self.R] * len(img_ids)
+        return [int(self.offsets[self.row[str(i)] + 1] - self.offsets[self.row[str(i)]]) for i in img_ids]
+
     def gather_into(self, img_ids, out):
-        """out[j] = features of img_ids[j] (out: (B, R, D) fp32 numpy view of a pinned buffer)."""
+        """out[j, :n_j] = features of img_ids[j], zero rows after them (out: (B, R, D) fp32 numpy view of a pinned buffer)."""
+        if not self.ragged:
+            for j, i in enumerate(img_ids):
+                out[j] = self.feats[self.row[str(i)]]
+            return
         for j, i in enumerate(img_ids):
-            out[j] = self.feats[self.row[str(i)]]
+            lo, hi = self._rows(i)
+            out[j, :hi - lo] = self.feats[lo:hi]
+            out[j, hi - lo:] = 0
 
 
 class DevicePrefetcher:
@@ -85,31 +138,37 @@ class DevicePrefetcher:
     def _stage(self, slot, batch):
         img_ids, supp = batch[0], batch[-1]
         if self.store is not None:
-            B, R, D = len(img_ids), self.store.R, self.store.D
+            counts = self.store.counts(img_ids)
+            D = self.store.D
         else:
-            B, (R, D) = len(supp), supp[0]["bu_feat"].shape
-        if self._pinned[slot] is None or self._pinned[slot].shape[0] < B or tuple(self._pinned[slot].shape[1:]) != (R, D):
-            self._pinned[slot] = torch.empty(B, R, D, dtype=torch.float32).pin_memory()
-            self._dev[slot] = torch.empty(B, R, D, dtype=torch.float32, device=self.device)
+            counts, D = [int(s["bu_feat"].shape[0]) for s in supp], supp[0]["bu_feat"].shape[1]
+        B, R = len(counts), max(counts)
+        need = B * R * D
+        if self._pinned[slot] is None or self._pinned[slot].numel() < need:      # flat: ragged batches change R every step
+            self._pinned[slot] = torch.empty(need, dtype=torch.float32).pin_memory()
+            self._dev[slot] = torch.empty(need, dtype=torch.float32, device=self.device)
             self._free[slot] = None
         if self._free[slot] is not None:
             self._free[slot].synchronize()          # the consumer is done with this slot's device buffer
-        host = self._pinned[slot][:B].numpy()
+        pinned, dev = self._pinned[slot][:need].view(B, R, D), self._dev[slot][:need].view(B, R, D)
+        host = pinned.numpy()
         if self.store is not None:
             self.store.gather_into(img_ids, host)
             boxes = [self.store[i]["bu_bbox"] for i in img_ids]
         else:
             for j, s in enumerate(supp):
-                if s["bu_feat"].shape != (R, D):
-                    raise NotImplementedError("adaptive (variable-size) feature sets are outside the packed pipeline")
-                host[j] = s["bu_feat"]
+                host[j, :counts[j]] = s["bu_feat"]
+                host[j, counts[j]:] = 0
             boxes = [s["bu_bbox"] for s in supp]
         with torch.cuda.stream(self.copy_stream):
-            self._dev[slot][:B].copy_(self._pinned[slot][:B], non_blocking=True)
+            dev.copy_(pinned, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[slot] = ev
-        return batch[:-1] + ({"bu_feats": self._dev[slot][:B], "bu_bboxes": boxes},)
+        out = {"bu_feats": dev, "bu_bboxes": boxes}
+        if min(counts) < R:
+            out["bu_counts"] = counts
+        return batch[:-1] + (out,)
 
     def __iter__(self):
         """Batches are staged by a worker thread (the gather is a numpy copy that releases the GIL) up to depth - 1 ahead of

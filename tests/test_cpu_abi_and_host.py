@@ -164,3 +164,25 @@ def test_packed_feature_store_roundtrip(tmp_path):
     out = np.zeros((2, 36, 64), np.float32)
     store.gather_into([184613, 391895], out)
     assert np.array_equal(out[0], data[184613][0]) and np.array_equal(out[1], data[391895][0])
+
+
+def test_packed_feature_store_adaptive_roundtrip(tmp_path):
+    """'adaptive' feature sets (10..100 rows per image, Datasets.py:59-61): ragged store, batches padded with zero rows."""
+    import numpy as np
+    from simpleimagecaptionzoo_amd.features import PackedFeatureStore, pack_npz_dir
+    root = str(tmp_path / "supp")
+    os.makedirs(os.path.join(root, "adaptive_bu_feat"))
+    os.makedirs(os.path.join(root, "adaptive_bu_bbox"))
+    rng = np.random.RandomState(3)
+    data = {}
+    for i, n in ((11, 10), (12, 100), (13, 37)):
+        data[i] = (rng.rand(n, 32).astype(np.float32), rng.rand(n, 4).astype(np.float32))
+        np.savez_compressed(os.path.join(root, "adaptive_bu_feat", "%d.npz" % i), feat=data[i][0])
+        np.save(os.path.join(root, "adaptive_bu_bbox", "%d.npy" % i), data[i][1])
+    store = PackedFeatureStore(pack_npz_dir(root, [11, 12, 13], str(tmp_path / "packed"), kind="adaptive"))
+    assert store.ragged and len(store) == 3 and (store.R, store.D) == (100, 32) and store.counts([13, 11]) == [37, 10]
+    for i in data:
+        assert np.array_equal(store[i]["bu_feat"], data[i][0]) and np.array_equal(store[i]["bu_bbox"], data[i][1])
+    out = np.full((2, 37, 32), 7.0, np.float32)
+    store.gather_into([13, 11], out)
+    assert np.array_equal(out[0], data[13][0]) and np.array_equal(out[1, :10], data[11][0]) and not out[1, 10:].any()
