@@ -132,36 +132,56 @@ __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ 
     }
 }
 
-// Custom LayerNorm backward (AoA_Model.py:14-25: unbiased std, eps outside the sqrt), one wave per row.
+// Custom LayerNorm backward (AoA_Model.py:14-25: unbiased std, eps outside the sqrt), one workgroup per row.
 //   dq = dq_a (slabs [ns_a][rows][Hd], linear_Q dgrad) + dq_b (slabs [ns_b][rows][2Hd] at column offset Hd, GLU-input dgrad)
 //   y = g (x - mean) inv + b, inv = 1/(std + eps):  dy = dq g;  dstd = -inv^2 sum(dy xh);
 //   dxh = dy inv + dstd xh / (std (n-1));  dx = dxh - mean(dxh)
 __global__ __launch_bounds__(256) void aoa_ln_bwd_kernel(const float* __restrict__ dq_a, int ns_a, const float* __restrict__ dq_b, int ns_b, int rows,
                                                          const float* __restrict__ x, const float* __restrict__ stats,
                                                          const float* __restrict__ gain, float* __restrict__ dq_tot, float* __restrict__ dx, int n) {
-    const int lane = threadIdx.x & 63;
-    const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row
-    if (row >= rows) return;
+    // one workgroup per row; a thread keeps its columns (4 adjacent ones per 1024) in registers between the two passes
+    __shared__ float sm_red[4];
+    constexpr int NV = 4;                         // n <= 4096, n % 4 == 0 (checked by the host)
+    const int row = blockIdx.x, tid = threadIdx.x;
     const float mean = stats[2 * row], inv = stats[2 * row + 1];
     const float stdv = 1.0f / inv - 1e-6f;
     const float* xr = x + (size_t)row * n;
+    f32x4 dy[NV], xc[NV];
     float s1 = 0.f, s2 = 0.f;
-    for (int c = lane; c < n; c += 64) {
-        const float dq = sum_slabs1(dq_a, ns_a, (size_t)rows * n, (size_t)row * n + c) +
-                         sum_slabs1(dq_b, ns_b, (size_t)rows * 2 * n, (size_t)row * 2 * n + n + c);
-        dq_tot[(size_t)row * n + c] = dq;
-        const float dy = dq * gain[c];
-        s1 += dy;
-        s2 += dy * (xr[c] - mean);
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = 4 * tid + 1024 * u;
+        dy[u] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        xc[u] = dy[u];
+        if (c < n) {
+            const f32x4 dq = sum_slabs4(dq_a, ns_a, (size_t)rows * n, (size_t)row * n + c) +
+                             sum_slabs4(dq_b, ns_b, (size_t)rows * 2 * n, (size_t)row * 2 * n + n + c);
+            *reinterpret_cast<f32x4*>(dq_tot + (size_t)row * n + c) = dq;
+            const f32x4 g = *reinterpret_cast<const f32x4*>(gain + c);
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(xr + c);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                dy[u][j] = dq[j] * g[j];
+                xc[u][j] = xv[j] - mean;
+                s1 += dy[u][j];
+                s2 += dy[u][j] * xc[u][j];
+            }
+        }
     }
-    s1 = wave_sum(s1);
-    s2 = wave_sum(s2);
+    s1 = block_sum_256(s1, sm_red);
+    s2 = block_sum_256(s2, sm_red);
     const float dstd = -inv * inv * s2;
     const float kx = dstd / (stdv * (float)(n - 1));
     const float mdx = inv * s1 / (float)n;
-    for (int c = lane; c < n; c += 64) {
-        const float dy = dq_tot[(size_t)row * n + c] * gain[c];
-        dx[(size_t)row * n + c] = dy * inv + kx * (xr[c] - mean) - mdx;
+#pragma unroll
+    for (int u = 0; u < NV; ++u) {
+        const int c = 4 * tid + 1024 * u;
+        if (c < n) {
+            f32x4 o;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = dy[u][j] * inv + kx * xc[u][j] - mdx;
+            *reinterpret_cast<f32x4*>(dx + (size_t)row * n + c) = o;
+        }
     }
 }
 
@@ -191,6 +211,7 @@ __global__ void aoa_gather_packed_kernel(const float* __restrict__ logit, int V,
 
 int Aoa::ensure_train() {
     if (tready) return ICZ_OK;
+    ICZ_REQUIRE(dims.Hd <= 4096, "aoa: training paths keep a LayerNorm row in registers (hidden size %d > 4096)", dims.Hd);
     const size_t B = dims.max_rows, T = dims.max_len, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
     {
         const size_t dh = Hd / NH, lds_bwd = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
@@ -440,7 +461,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
                            tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, lens, io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
-        hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(64), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
+        hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
                            P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
         LstmBwdArgs a = {};
         a.dh_a = bnext ? X + Hd : nullptr; a.ns_a = nsx; a.lda_a = 2 * Hd; a.rows_a = bnext;

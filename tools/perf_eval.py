@@ -1,4 +1,5 @@
-"""Evaluation-path timing at BASELINE dims: greedy and beam-5 decode of 64 images (dev tool)."""
+"""Evaluation-path timing at BASELINE dims: greedy and beam-5 decode of B images (dev tool; BASELINE config 3 is B = 128).
+usage: perf_eval.py [B]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -8,10 +9,11 @@ from simpleimagecaptionzoo_amd.synth import random_butd_params
 R, D, H, E, A, V = 36, 2048, 1024, 1024, 1024, 10102
 torch.manual_seed(1234)
 params = random_butd_params(R, D, H, E, A, V, "cuda")
-h = ButdHandle(R, D, H, E, A, V, 320, 20)
+B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+h = ButdHandle(R, D, H, E, A, V, 5 * B, 20)
 h.bind(params)
 h.enable_graphs(True)
-feats = torch.relu(torch.randn(64, R, D, device="cuda"))
+feats = torch.relu(torch.randn(B, R, D, device="cuda"))
 st = torch.cuda.Stream()
 
 
@@ -28,7 +30,7 @@ def timed(fn, n=5):
 
 
 t = timed(lambda: h.greedy(feats, 20))
-print("greedy 64 x 20 steps: %.2f ms -> %.0f captions/s" % (t, 64 / t * 1e3))
+print("greedy %d x 20 steps: %.2f ms -> %.0f captions/s" % (B, t, B / t * 1e3))
 for steps in (20, 50):
     t = timed(lambda: h.beam_search(feats, 5, steps))
-    print("beam-5 64 images x %d steps: %.2f ms -> %.0f captions/s" % (steps, t, 64 / t * 1e3))
+    print("beam-5 %d images x %d steps: %.2f ms -> %.0f captions/s" % (B, steps, t, B / t * 1e3))
