@@ -224,10 +224,12 @@ int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream);
  * regions of each image, i.e. bu_masks.sum(1) of the reference's prefix masks (AoA_Engine.py:37-40), in device memory
  * (read by the kernels of the following calls -- keep it alive until they have run) and in host memory (validated here:
  * 1 <= counts[i] <= regions); both NULL = every region valid (bu_masks = None).  Masked keys get attention weight 0
- * (masked_fill(-1e9) before the softmax, AoA_Model.py:63-64), the projection of a padded row is 0 (pack_wrapper,
- * :650-653) and mean_features averages the valid rows (:253). */
+ * (masked_fill(-1e9) before the softmax, AoA_Model.py:63-64), the projection runs on the valid rows only (pack_wrapper,
+ * :650-653 -- here the whole refiner does: the padded rows the reference carries along never reach a result) and
+ * mean_features averages the valid rows (:253). */
 int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev, const int32_t* counts_host, int32_t n_img);
-/* eval-mode refined features [B,regions,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests */
+/* eval-mode refined features [B,regions,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests.  With
+ * region counts the refiner runs on the packed valid rows; rows past an image's count come back as zeros. */
 int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_out, void* stream);
 /* AoADetection_Captioner.sampler / beam_search_sampler / sampler_rl / forward (:698-753, :676-696) */
 int icz_aoa_greedy(icz_aoa_t* h, const float* feats, int32_t B, int32_t max_len, int64_t* ids_out, void* stream);

@@ -36,6 +36,8 @@ int Aoa::init(const icz_aoa_dims& d) {
         ICZ_TRY(alloc((void**)&s.z, sizeof(float) * RR * 2 * Hd));
         ICZ_TRY(alloc((void**)&s.meanf, sizeof(float) * rows * Hd));
         ICZ_TRY(alloc((void**)&s.ws, sizeof(float) * ws_floats));
+        ICZ_TRY(alloc((void**)&s.off, sizeof(int32_t) * (rows + 1)));
+        ICZ_TRY(alloc((void**)&s.rowmap, sizeof(int32_t) * RR));
     }
     use_bank(0);
     for (int i = 0; i < 2; ++i) {
@@ -103,11 +105,23 @@ int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, in
 int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
     const int R = cur_R, Hd = dims.Hd, NH = dims.NH;
     ICZ_REQUIRE(!lens || lens_n == n_img, "aoa: region counts were set for %d images, the batch has %d (icz_aoa_set_regions)", lens_n, n_img);
-    const int rows = n_img * R;
+    const int rows = (int)region_row_count(n_img);
+    const RegionRows rr = region_rows();
     const size_t nel = (size_t)rows * Hd;
     const unsigned eb = (unsigned)((nel + 255) / 256);
-    ICZ_TRY(lin(feats, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
-    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), lens, R, Hd);
+    const float* xin = feats;
+    if (lens) {      // 'adaptive' features: the refiner runs on the valid rows only (packed)
+        if (!bank[0].featp)
+            for (int b = 0; b < 2; ++b) ICZ_TRY(alloc((void**)&bank[b].featp, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.D));
+        float* featp = bank[cur_bank].featp;
+        hipLaunchKernelGGL(aoa_offsets_kernel, dim3(1), dim3(256), 0, st, lens, n_img, R, off, rowmap);
+        const size_t n4 = (size_t)rows * (dims.D / 4);
+        hipLaunchKernelGGL(aoa_pack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, feats, (const int32_t*)rowmap, featp,
+                           (size_t)rows, dims.D);
+        xin = featp;
+    }
+    ICZ_TRY(lin(xin, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), rr, Hd);
     const int qc = self_qc(R);
     const size_t lds = self_lds(R, qc);
     float *cur = xa, *nxt = xb;
@@ -117,12 +131,12 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
         ICZ_TRY(lin(ln, rows, Hd, b.q_w, b.q_b, Hd, q, st));
         ICZ_TRY(lin(ln, rows, Hd, b.k_w, b.k_b, Hd, k, st));
         ICZ_TRY(lin(ln, rows, Hd, b.v_w, b.v_b, Hd, v, st));
-        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH, qc, lens,
+        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH, qc, rr,
                            dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f));
         const float *xo = o, *xn = ln;
         if (train) {
-            hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, o, ln, od, nd, (size_t)rows, Hd,
-                               dropp(true, rng.ref_aoa_mask, (size_t)l * rows * 2 * Hd, AOA_RNG_REF_AOA, l, 0.3f));
+            hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, o, ln, od, nd, (size_t)rows, Hd, rr,
+                               dropp(true, rng.ref_aoa_mask, (size_t)l * n_img * R * 2 * Hd, AOA_RNG_REF_AOA, l, 0.3f));
             xo = od; xn = nd;
         }
         GemmArgs g = {};
@@ -131,12 +145,12 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
         g.seg[1] = {xn, b.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
         g.M = rows; g.N = 2 * Hd;
         ICZ_TRY(aoa_linear(*this, g, b.aoa_b, z, st));
-        hipLaunchKernelGGL(glu_residual_kernel, dim3(eb), dim3(256), 0, st, z, cur, nxt, (size_t)rows, Hd,
-                           dropp(train, rng.ref_sc_mask, (size_t)l * rows * Hd, AOA_RNG_REF_SC, l, 0.1f));
+        hipLaunchKernelGGL(glu_residual_kernel, dim3(eb), dim3(256), 0, st, z, cur, nxt, (size_t)rows, Hd, rr,
+                           dropp(train, rng.ref_sc_mask, (size_t)l * n_img * R * Hd, AOA_RNG_REF_SC, l, 0.1f));
         float* t_ = cur; cur = nxt; nxt = t_;
     }
     hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, P.ref_ln_g, P.ref_ln_b, refined, rows, Hd, (float*)nullptr);
-    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, R, Hd, lens);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, Hd, rr);
     ICZ_TRY(lin(refined, rows, Hd, P.dec.k_w, P.dec.k_b, Hd, Kd, st));
     ICZ_TRY(lin(refined, rows, Hd, P.dec.v_w, P.dec.v_b, Hd, Vd, st));
     ICZ_CHECK_HIP(hipGetLastError());
@@ -165,7 +179,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128);
     hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(64), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
-                       lens, s.d_att);
+                       region_rows(), s.d_att);
     GemmArgs zg = {};
     zg.nseg = 2;
     zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};
@@ -321,9 +335,17 @@ int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_o
     ICZ_REQUIRE(B > 0 && B <= n->dims.max_rows, "icz_aoa_refine: B out of range");
     ICZ_REQUIRE(n->fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     n->use_bank(0);
-    ICZ_TRY(n->refine(feats, B, false, (hipStream_t)stream));
-    ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, sizeof(float) * (size_t)B * n->cur_R * n->dims.Hd, hipMemcpyDeviceToDevice,
-                                 (hipStream_t)stream));
+    hipStream_t st = (hipStream_t)stream;
+    ICZ_TRY(n->refine(feats, B, false, st));
+    const size_t bytes = sizeof(float) * (size_t)B * n->cur_R * n->dims.Hd;
+    if (!n->lens) {
+        ICZ_CHECK_HIP(hipMemcpyAsync(refined_out, n->refined, bytes, hipMemcpyDeviceToDevice, st));
+    } else {         // packed rows back to [B, regions, Hd]; the padding rows (never computed) are zero
+        ICZ_CHECK_HIP(hipMemsetAsync(refined_out, 0, bytes, st));
+        const size_t rows = n->region_row_count(B), n4 = rows * (n->dims.Hd / 4);
+        hipLaunchKernelGGL(aoa_unpack_rows_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, (const float*)n->refined,
+                           (const int32_t*)n->rowmap, refined_out, rows, n->dims.Hd);
+    }
     return ICZ_OK;
 }
 int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev, const int32_t* counts_host, int32_t n_img) {
@@ -337,6 +359,8 @@ int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev
             ICZ_REQUIRE(counts_host[i] >= 1 && counts_host[i] <= regions, "icz_aoa_set_regions: image %d has %d regions (1..%d)", i, counts_host[i], regions);
     }
     n->cur_R = regions; n->lens = counts_dev; n->lens_n = counts_dev ? n_img : 0;
+    n->cur_total = 0;
+    for (int i = 0; counts_host && i < n_img; ++i) n->cur_total += counts_host[i];
     n->mode = 0;
     return ICZ_OK;
 }

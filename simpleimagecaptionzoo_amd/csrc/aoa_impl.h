@@ -42,12 +42,14 @@ struct Aoa {
     // refiner scratch / per-image tensors (rows = max_rows * R).  Two banks: bank 0 serves the evaluation-mode paths (greedy,
     // beam), bank 1 the training-mode ones (sample, XE, backward), so that the greedy baseline and the sampled rollout of
     // one SCST step can be in flight together; use_bank() points the members below at a bank before a chain is enqueued.
-    struct Bank { float *xa, *xb, *ln, *q, *k, *v, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; };
+    struct Bank { float *xa, *xb, *ln, *q, *k, *v, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; int32_t *off, *rowmap; float* featp; };
     Bank bank[2] = {};
+    int cur_bank = 0;
     void use_bank(int b) {
+        cur_bank = b;
         const Bank& s = bank[b];
         xa = s.xa; xb = s.xb; ln = s.ln; q = s.q; k = s.k; v = s.v; o = s.o; od = s.od; nd = s.nd; z = s.z;
-        refined = s.refined; meanf = s.meanf; Kd = s.Kd; Vd = s.Vd; ws = s.ws;
+        refined = s.refined; meanf = s.meanf; Kd = s.Kd; Vd = s.Vd; ws = s.ws; off = s.off; rowmap = s.rowmap;
     }
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
@@ -75,8 +77,11 @@ struct Aoa {
     int mode = 0, cur_B = 0, cur_T = 0, cur_L = 0, n_tokens = 0;
     // regions per image of the current batch: row stride cur_R <= dims.R and, for the 'adaptive' bottom-up features
     // (10..100 boxes, AoA_Engine.py:37-44), the valid count per image (device, caller-owned; null = all cur_R)
-    int cur_R = 0, lens_n = 0;
+    int cur_R = 0, lens_n = 0, cur_total = 0;      // cur_total = sum of the counts = rows of the packed refiner tensors
     const int32_t* lens = nullptr;
+    int32_t *off = nullptr, *rowmap = nullptr;     // per bank: row offsets / padded indices of the packed rows (RegionRows)
+    RegionRows region_rows() const { return lens ? RegionRows{off, rowmap, lens, cur_R} : RegionRows{nullptr, nullptr, nullptr, cur_R}; }
+    size_t region_row_count(int n_img) const { return lens ? (size_t)cur_total : (size_t)n_img * cur_R; }
     static constexpr size_t LDS_BUDGET = 156 * 1024;
     size_t self_lds(int R, int qc) const {       // mha_self_kernel: K, V [R4][ld] + Q chunk [qc4][ld] + P [qc4][lp]
         const size_t ld = aoa_pitch(dims.Hd / dims.NH), lp = aoa_pitch(R), R4 = (R + 3) & ~3, q4 = (qc + 3) & ~3;

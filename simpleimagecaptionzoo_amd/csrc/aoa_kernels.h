@@ -30,18 +30,60 @@ struct DropP {
     }
 };
 
-// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665).  With per-image region counts the rows
-// past an image's count come out as zeros: the reference projects the packed valid rows only and pads the result
-// (pack_wrapper, AoA_Model.py:650-653).
-__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp, const int32_t* __restrict__ lens, int R,
-                                                        int Hd) {
+// Region rows of a batch.  Fixed region sets: row (img, r) of the [n_img, R, *] tensors is img * R + r.  With per-image
+// region counts ('adaptive' features) the refiner works on the PACKED valid rows only -- image img owns rows
+// off[img] .. off[img] + count[img] -- as the reference does for the projection (pack_wrapper, AoA_Model.py:650-653); the
+// padded rows it carries through the refiner never reach a result (their keys are masked everywhere).  rowmap[packed row] =
+// img * R + r is the row's padded index, which still addresses the dropout masks / Philox counters.
+struct RegionRows {
+    const int32_t* off;        // [n_img + 1] or null (fixed)
+    const int32_t* rowmap;     // [total rows] or null (fixed)
+    const int32_t* lens;       // [n_img] or null (fixed)
+    int R;
+    __device__ __forceinline__ size_t first(int img) const { return off ? (size_t)off[img] : (size_t)img * R; }
+    __device__ __forceinline__ int count(int img) const { return lens ? lens[img] : R; }
+    __device__ __forceinline__ size_t padded(size_t row) const { return rowmap ? (size_t)rowmap[row] : row; }
+};
+
+// off = exclusive prefix sum of the counts, rowmap = padded index of every packed row (one workgroup)
+__global__ __launch_bounds__(256) void aoa_offsets_kernel(const int32_t* __restrict__ lens, int n_img, int R, int32_t* __restrict__ off,
+                                                          int32_t* __restrict__ rowmap) {
+    if (threadIdx.x == 0) {
+        int acc = 0;
+        for (int i = 0; i < n_img; ++i) { off[i] = acc; acc += lens[i]; }
+        off[n_img] = acc;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < n_img * R; i += 256) {
+        const int img = i / R, r = i % R;
+        if (r < lens[img]) rowmap[off[img] + r] = i;
+    }
+}
+
+// packed[row] = padded[rowmap[row]]   (rows of n floats, n % 4 == 0)
+__global__ __launch_bounds__(256) void aoa_pack_rows_kernel(const float* __restrict__ padded, const int32_t* __restrict__ rowmap,
+                                                            float* __restrict__ packed, size_t rows, int n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = n >> 2;
+    if (i >= rows * n4) return;
+    const size_t row = i / n4, c = (i % n4) * 4;
+    *reinterpret_cast<f32x4*>(packed + row * n + c) = *reinterpret_cast<const f32x4*>(padded + (size_t)rowmap[row] * n + c);
+}
+
+// padded[rowmap[row]] = packed[row]   (the padded tensor is zeroed beforehand)
+__global__ __launch_bounds__(256) void aoa_unpack_rows_kernel(const float* __restrict__ packed, const int32_t* __restrict__ rowmap,
+                                                              float* __restrict__ padded, size_t rows, int n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x, n4 = n >> 2;
+    if (i >= rows * n4) return;
+    const size_t row = i / n4, c = (i % n4) * 4;
+    *reinterpret_cast<f32x4*>(padded + (size_t)rowmap[row] * n + c) = *reinterpret_cast<const f32x4*>(packed + row * n + c);
+}
+
+// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665)
+__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp, RegionRows rr, int Hd) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    if (lens) {
-        const size_t row = i / Hd;
-        if ((int)(row % R) >= lens[row / R]) { x[i] = 0.f; return; }
-    }
-    x[i] = dp.apply(fmaxf(x[i], 0.f), i);
+    const size_t row = i / Hd;
+    x[i] = dp.apply(fmaxf(x[i], 0.f), rr.padded(row) * Hd + i % Hd);
 }
 
 // Custom LayerNorm (AoA_Model.py:14-25): y = gain * (x - mean) / (std_unbiased + eps) + bias.  One wave per row; the row is
@@ -120,18 +162,18 @@ __host__ __device__ __forceinline__ int aoa_pitch(int n) {
 // 4 x 4 block of O (4 strided rows x 4 adjacent columns) and walks the reduction dimension four at a time with 16-byte LDS
 // reads -- 8 reads per 64 FMAs, where one element per thread needs 2 reads per FMA and leaves the kernel LDS-bound.
 __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                       float* __restrict__ O, int R, int Hd, int NH, int QC, const int32_t* __restrict__ lens,
-                                                       DropP dp) {
+                                                       float* __restrict__ O, int R, int Hd, int NH, int QC, RegionRows rr, DropP dp) {
     extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // K,V tiles [R4][ld], Q chunk [QC4][ld], P [QC4][lp]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int d = Hd / NH, d4 = d >> 2, ld = aoa_pitch(d), lp = aoa_pitch(R);
     const int R4 = (R + 3) & ~3, QC4 = (QC + 3) & ~3;
-    const int len = lens ? lens[img] : R, len4 = (len + 3) & ~3;
+    const int len = rr.count(img), len4 = (len + 3) & ~3;
+    const int nrow = rr.off ? len : R;                       // query rows of this image: the packed layout has no padded ones
     float* sk = sm_mha;
     float* sv = sk + R4 * ld;
     float* sq = sv + R4 * ld;
     float* sp = sq + QC4 * ld;
-    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    const size_t base = rr.first(img) * Hd + (size_t)hd * d;
     for (int i = tid; i < len4 * d4; i += 256) {
         const int r = i / d4, j = (i % d4) * 4;
         f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;              // rows [len, len4) are read by the last block of four: zeros
@@ -145,8 +187,8 @@ __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__
     const float scale = 1.0f / sqrtf((float)d);
     const int lane = tid & 63, wave = tid >> 6;
     const int nrt = len4 >> 2;
-    for (int q0 = 0; q0 < R; q0 += QC) {
-        const int nq = min(QC, R - q0), nqt = (nq + 3) >> 2;
+    for (int q0 = 0; q0 < nrow; q0 += QC) {
+        const int nq = min(QC, nrow - q0), nqt = (nq + 3) >> 2;
         for (int i = tid; i < nq * d4; i += 256) {
             const int r = i / d4, j = (i % d4) * 4;
             *reinterpret_cast<f32x4*>(sq + r * ld + j) = *reinterpret_cast<const f32x4*>(Q + base + (size_t)(q0 + r) * Hd + j);
@@ -231,24 +273,24 @@ __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__
 
 // dropout over the concatenation [a | b] (each [rows, Hd]) with one mask of width 2*Hd (dropout_aoa, AoA_Model.py:118)
 __global__ __launch_bounds__(256) void drop_concat_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ ad,
-                                                          float* __restrict__ bd, size_t rows, int Hd, DropP dp) {
+                                                          float* __restrict__ bd, size_t rows, int Hd, RegionRows rr, DropP dp) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * Hd) return;
-    const size_t row = i / Hd;
+    const size_t prow = rr.padded(i / Hd);
     const int c = (int)(i % Hd);
-    ad[i] = dp.apply(a[i], row * 2 * Hd + c);
-    bd[i] = dp.apply(b[i], row * 2 * Hd + Hd + c);
+    ad[i] = dp.apply(a[i], prow * 2 * Hd + c);
+    bd[i] = dp.apply(b[i], prow * 2 * Hd + Hd + c);
 }
 
 // GLU gate + sublayer residual (AoA_Model.py:83,39): x_out = x + drop(z[:, :Hd] * sigmoid(z[:, Hd:]), p)
 __global__ __launch_bounds__(256) void glu_residual_kernel(const float* __restrict__ z, const float* __restrict__ x, float* __restrict__ out,
-                                                           size_t rows, int Hd, DropP dp) {
+                                                           size_t rows, int Hd, RegionRows rr, DropP dp) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= rows * Hd) return;
     const size_t row = i / Hd;
     const int c = (int)(i % Hd);
     const float y = z[row * 2 * Hd + c] * sigmoidf_(z[row * 2 * Hd + Hd + c]);
-    out[i] = x[i] + dp.apply(y, i);
+    out[i] = x[i] + dp.apply(y, rr.padded(row) * Hd + c);
 }
 
 // Decoder: u = mean_feat[img] + drop(ctx_prev, 0.5)   (AoA_Model.py:321-323)
@@ -293,7 +335,7 @@ __device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const 
 __global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
                                                           const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
                                                           float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
-                                                          int R, int Hd, int NH, const int32_t* __restrict__ lens, DropP dp) {
+                                                          int R, int Hd, int NH, RegionRows rr, DropP dp) {
     extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128]
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int d = Hd / NH, ld = d + 1;
@@ -302,8 +344,8 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restric
     float* sq = sv + R * ld;
     float* sp = sq + d;
     const int img = img_of_row ? img_of_row[row] : row;
-    const int len = lens ? lens[img] : R;
-    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    const int len = rr.count(img);
+    const size_t base = rr.first(img) * Hd + (size_t)hd * d;
     aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
     for (int j = lane; j < d; j += 64) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
     __syncthreads();
@@ -362,15 +404,15 @@ __global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ 
     ctxdrop[i] = dp.apply(y, i);
 }
 
-// mean over the (valid) regions of [n_img, R, Hd]  (AoA_Model.py:250-253)
-__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ m, int R, int Hd,
-                                                        const int32_t* __restrict__ lens) {
+// mean over the (valid) regions of an image  (AoA_Model.py:250-253)
+__global__ __launch_bounds__(256) void mean_rows_kernel(const float* __restrict__ x, float* __restrict__ m, int Hd, RegionRows rr) {
     const int img = blockIdx.y;
     const int c = blockIdx.x * 256 + threadIdx.x;
     if (c >= Hd) return;
-    const int len = lens ? lens[img] : R;
+    const int len = rr.count(img);
+    const size_t r0 = rr.first(img);
     float s = 0.f;
-    for (int r = 0; r < len; ++r) s += x[((size_t)img * R + r) * Hd + c];
+    for (int r = 0; r < len; ++r) s += x[(r0 + r) * Hd + c];
     m[(size_t)img * Hd + c] = s / (float)len;
 }
 

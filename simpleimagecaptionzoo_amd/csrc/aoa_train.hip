@@ -41,7 +41,7 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
                                                               const float* __restrict__ Pdm, const float* __restrict__ Qp,
                                                               const float* __restrict__ Kd, const float* __restrict__ Vd,
                                                               float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
-                                                              int NH, const int32_t* __restrict__ lens, float keep_scale) {
+                                                              int NH, RegionRows rr, float keep_scale) {
     extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [128]
     const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
     const int d = Hd / NH, ld = d + 1;
@@ -50,8 +50,8 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
     float* sq = sv + R * ld;
     float* sdx = sq + d;
     float* sds = sdx + d;
-    const int len = lens ? lens[row] : R;
-    const size_t base = (size_t)row * R * Hd + (size_t)hd * d;
+    const int len = rr.count(row);
+    const size_t base = rr.first(row) * Hd + (size_t)hd * d;
     aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
     const size_t MN = (size_t)rows * 2 * Hd;
     for (int j = lane; j < d; j += 64) {
@@ -93,7 +93,8 @@ __global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __res
 // The steps go through LDS in chunks of TC (all of them at the usual 20 steps x 36 regions).
 __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ dS_all, const float* __restrict__ Pd_all,
                                                       const float* __restrict__ Qp_all, const float* __restrict__ dx_all,
-                                                      float* __restrict__ dKd, float* __restrict__ dVd, int B, int T, int TC, int R, int Hd, int NH) {
+                                                      float* __restrict__ dKd, float* __restrict__ dVd, int B, int T, int TC, int R, int Hd, int NH,
+                                                      RegionRows rr) {
     extern __shared__ __attribute__((aligned(16))) float sm_kv[];       // dS [TC][R], Pd [TC][R], Qp [TC][d], dx [TC][d]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int d = Hd / NH;
@@ -101,7 +102,8 @@ __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ 
     float* spd = sds + TC * R;
     float* sq = spd + TC * R;
     float* sdx = sq + TC * d;
-    const size_t base = (size_t)img * R * Hd + (size_t)hd * d;
+    const size_t base = rr.first(img) * Hd + (size_t)hd * d;
+    const int len = rr.count(img);
     for (int t0 = 0; t0 < T; t0 += TC) {
         const int nt = min(TC, T - t0);
         for (int i = tid; i < nt * R; i += 256) {
@@ -117,7 +119,7 @@ __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ 
             sdx[i] = dx_all[g];
         }
         __syncthreads();
-        for (int i = tid; i < R * d; i += 256) {
+        for (int i = tid; i < len * d; i += 256) {
             const int r = i / d, j = i % d;
             const size_t o = base + (size_t)r * Hd + j;
             float dk = t0 ? dKd[o] : 0.f, dv = t0 ? dVd[o] : 0.f;
@@ -459,7 +461,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         int ns2 = 1, nsq = 1;
         ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
-                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, lens, io.d_att.mode ? io.d_att.scale : 1.0f);
+                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, region_rows(), io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
                            P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
@@ -499,12 +501,13 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     {
         const int tc_fit = (int)(48 * 1024 / (sizeof(float) * 2 * (R + dh))), tc = T < tc_fit ? T : tc_fit;
         hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)tc * 2 * (R + dh), st, tdS, tPd, tQp, tdX, dKd, dVd, B, T,
-                           tc, R, Hd, NH);
+                           tc, R, Hd, NH, region_rows());
     }
-    ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.k_w, Hd, 0, st));
-    ICZ_TRY(colsum(dKd, B * R, Hd, Hd, G.dec.k_b, st));
-    ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, B * R, G.dec.v_w, Hd, 0, st));
-    ICZ_TRY(colsum(dVd, B * R, Hd, Hd, G.dec.v_b, st));
+    const int rrows = (int)region_row_count(B);      // region rows of the batch (packed valid rows with per-image counts)
+    ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.k_w, Hd, 0, st));
+    ICZ_TRY(colsum(dKd, rrows, Hd, Hd, G.dec.k_b, st));
+    ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.v_w, Hd, 0, st));
+    ICZ_TRY(colsum(dVd, rrows, Hd, Hd, G.dec.v_b, st));
     // ---- h_norm gain / bias
     {
         const size_t n = (size_t)TB * Hd;
