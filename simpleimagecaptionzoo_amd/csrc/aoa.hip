@@ -16,7 +16,7 @@ int Aoa::init(const icz_aoa_dims& d) {
     cur_R = d.R;
     ICZ_REQUIRE(self_qc(d.R) >= 1, "aoa: K and V head tiles of %d regions do not fit the LDS budget", d.R);
     const size_t lds_self = self_lds(d.R, self_qc(d.R));
-    const size_t lds_dec = (2 * d.R * (dh + 1) + dh + 128) * sizeof(float);
+    const size_t lds_dec = (2 * d.R * (dh + 1) + dh + 128 + 4) * sizeof(float);
     if (lds_self > 48 * 1024)
         ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(mha_self_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_self));
     if (lds_dec > 48 * 1024)
@@ -177,8 +177,8 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(Hd, 256), rows), dim3(256), 0, st, a, off);
     hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
     ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
-    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128);
-    hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(64), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
+    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128 + 4);
+    hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
                        region_rows(), s.d_att);
     GemmArgs zg = {};
     zg.nseg = 2;

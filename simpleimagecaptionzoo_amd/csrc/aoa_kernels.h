@@ -303,21 +303,22 @@ __global__ __launch_bounds__(256) void aoa_u_kernel(const float* __restrict__ me
     u[i] = meanf[(size_t)img * Hd + c] + dp.apply(ctx_prev[i], i);
 }
 
-// K and V head tiles [R][d] -> LDS [R][d+1] by one wave: 16-byte loads, eight in flight per lane (d % 4 == 0)
+// K and V head tiles [R][d] -> LDS [R][d+1] by the workgroup's NT threads: 16-byte loads, eight in flight per thread (d % 4 == 0)
+template <int NT>
 __device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const float* __restrict__ V, float* sk, float* sv, int R, int d,
-                                             int Hd, int lane) {
+                                             int Hd, int tid) {
     const int d4 = d >> 2, n = R * d4, ld = d + 1;
-    for (int i0 = lane; i0 < n; i0 += 256) {
+    for (int i0 = tid; i0 < n; i0 += 4 * NT) {
         f32x4 kk[4], vv[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = min(i0 + 64 * u, n - 1), r = i / d4, j = (i % d4) * 4;
+            const int i = min(i0 + NT * u, n - 1), r = i / d4, j = (i % d4) * 4;
             kk[u] = *reinterpret_cast<const f32x4*>(K + (size_t)r * Hd + j);
             vv[u] = *reinterpret_cast<const f32x4*>(V + (size_t)r * Hd + j);
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            const int i = i0 + 64 * u;
+            const int i = i0 + NT * u;
             if (i < n) {
                 const int r = i / d4, j = (i % d4) * 4;
 #pragma unroll
@@ -327,60 +328,58 @@ __device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const 
     }
 }
 
-// Decoder attention, one query per row (AoA_Model.py:329-334 -> :90-120), one wave per (row, head):
+// Decoder attention, one query per row (AoA_Model.py:329-334 -> :90-120), one workgroup of 256 threads per (row, head):
 //   s_r = Qp_h . Kd_h[r] / sqrt(d);  P = softmax_R(s);  Pd = drop(P, 0.1);  x_h = sum_r Pd_r Vd_h[r]
-// Kd / Vd: [n_img, R, Hd] (linear_K / linear_V of the refined features, hoisted: time-invariant).  R <= 128 (two keys per lane);
-// with region counts only the image's valid rows are staged and the masked keys get P = 0 (see mha_self_kernel).
+// Kd / Vd: region rows x Hd (linear_K / linear_V of the refined features, hoisted: time-invariant).  R <= 128: thread r of the
+// first two waves owns key r; all four waves stage the image's K / V head tiles (most of the kernel's time: each tile is
+// used by one query only); with region counts only the valid rows are staged and the masked keys get P = 0.
 // Saves P and Pd ([rows, NH, R]) when requested (backward).
-__global__ __launch_bounds__(64) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
-                                                          const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
-                                                          float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
-                                                          int R, int Hd, int NH, RegionRows rr, DropP dp) {
-    extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128]
-    const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
+                                                           const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
+                                                           float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
+                                                           int R, int Hd, int NH, RegionRows rr, DropP dp) {
+    extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128], red [4]
+    const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_da;
     float* sv = sk + R * ld;
     float* sq = sv + R * ld;
     float* sp = sq + d;
+    float* red = sp + 128;
     const int img = img_of_row ? img_of_row[row] : row;
     const int len = rr.count(img);
     const size_t base = rr.first(img) * Hd + (size_t)hd * d;
-    aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
-    for (int j = lane; j < d; j += 64) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
+    aoa_stage_kv<256>(Kd + base, Vd + base, sk, sv, len, d, Hd, tid);
+    for (int j = tid; j < d; j += 256) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
     __syncthreads();
-    const int r1 = lane + 64;
-    const float rs = sqrtf((float)d);
-    float s0 = -INFINITY, s1 = -INFINITY;
-    if (lane < len) {
+    float s = -INFINITY;
+    if (tid < len) {
         float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += sq[j] * sk[lane * ld + j];
-        s0 = acc / rs;
+        for (int j = 0; j < d; ++j) acc += sq[j] * sk[tid * ld + j];
+        s = acc / sqrtf((float)d);
     }
-    if (r1 < len) {
-        float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += sq[j] * sk[r1 * ld + j];
-        s1 = acc / rs;
-    }
-    const float mx = wave_max(fmaxf(s0, s1));
-    const float e0 = lane < len ? expf(s0 - mx) : 0.f;
-    const float e1 = r1 < len ? expf(s1 - mx) : 0.f;
-    const float sum = wave_sum(e0 + e1);
-    const float p0 = e0 / sum, p1 = e1 / sum;
-    const uint64_t pidx = ((uint64_t)row * NH + hd) * R;
-    const float pd0 = lane < len ? dp.apply(p0, pidx + lane) : 0.f;
-    const float pd1 = r1 < len ? dp.apply(p1, pidx + r1) : 0.f;
-    sp[lane] = pd0; sp[r1] = pd1;
-    if (lane < R) {
-        if (P_out) P_out[pidx + lane] = p0;
-        if (Pd_out) Pd_out[pidx + lane] = pd0;
-    }
-    if (r1 < R) {
-        if (P_out) P_out[pidx + r1] = p1;
-        if (Pd_out) Pd_out[pidx + r1] = pd1;
+    const float wmx = wave_max(s);
+    if (lane == 0) red[wave] = wmx;
+    __syncthreads();
+    const float mx = fmaxf(red[0], red[1]);
+    const float e = tid < len ? expf(s - mx) : 0.f;
+    const float wsum = wave_sum(e);
+    __syncthreads();
+    if (lane == 0) red[wave] = wsum;
+    __syncthreads();
+    const float sum = red[0] + red[1];
+    if (tid < 128) {
+        const float p = e / sum;
+        const uint64_t pidx = ((uint64_t)row * NH + hd) * R + tid;
+        const float pd = tid < len ? dp.apply(p, pidx) : 0.f;
+        sp[tid] = pd;
+        if (tid < R) {
+            if (P_out) P_out[pidx] = p;
+            if (Pd_out) Pd_out[pidx] = pd;
+        }
     }
     __syncthreads();
-    for (int j = lane; j < d; j += 64) {
+    for (int j = tid; j < d; j += 256) {
         float acc = 0.f;
         for (int r = 0; r < len; ++r) acc += sp[r] * sv[r * ld + j];
         xatt[(size_t)row * Hd + (size_t)hd * d + j] = acc;

@@ -31,57 +31,54 @@ __global__ __launch_bounds__(256) void aoa_glu_bwd_kernel(const float* __restric
     dz[row * 2 * Hd + Hd + c] = d * a * s * (1.f - s);
 }
 
-// Decoder attention backward, one wave per (row, head); row b attends image b (training paths have no beams).
+// Decoder attention backward, one workgroup per (row, head); row b attends image b (training paths have no beams).
 //   dPd_r = dx_h . V_h[r];  dP = keep/(1-p) * dPd;  dS = P (dP - sum P dP);  dQ_h = sum_r dS_r K_h[r] / sqrt(d)
 // dK_h[r] = sum_t dS_t[r] Q_t,h / sqrt(d) and dV_h[r] = sum_t Pd_t[r] dx_t,h are sums over time: the steps only record dS_t
 // (already scaled by 1/sqrt(d)) and dx_t, and aoa_dkv_kernel forms both sums once after the loop -- accumulating them
 // step by step would read-modify-write the two [B, R, Hd] tensors (38 MB) in every step.
 // dx = columns [0, Hd) of the GLU-input gradient slabs [ns][rows][2Hd].
-__global__ __launch_bounds__(64) void aoa_dec_attn_bwd_kernel(const float* __restrict__ dxq, int ns, int rows, const float* __restrict__ Pm,
-                                                              const float* __restrict__ Pdm, const float* __restrict__ Qp,
-                                                              const float* __restrict__ Kd, const float* __restrict__ Vd,
-                                                              float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
-                                                              int NH, RegionRows rr, float keep_scale) {
-    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [128]
-    const int row = blockIdx.x, hd = blockIdx.y, lane = threadIdx.x;
+__global__ __launch_bounds__(256) void aoa_dec_attn_bwd_kernel(const float* __restrict__ dxq, int ns, int rows, const float* __restrict__ Pm,
+                                                               const float* __restrict__ Pdm, const float* __restrict__ Qp,
+                                                               const float* __restrict__ Kd, const float* __restrict__ Vd,
+                                                               float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
+                                                               int NH, RegionRows rr, float keep_scale) {
+    extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [128], red [4]
+    const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_db;
     float* sv = sk + R * ld;
     float* sq = sv + R * ld;
     float* sdx = sq + d;
     float* sds = sdx + d;
+    float* red = sds + 128;
     const int len = rr.count(row);
     const size_t base = rr.first(row) * Hd + (size_t)hd * d;
-    aoa_stage_kv(Kd + base, Vd + base, sk, sv, len, d, Hd, lane);
+    aoa_stage_kv<256>(Kd + base, Vd + base, sk, sv, len, d, Hd, tid);
     const size_t MN = (size_t)rows * 2 * Hd;
-    for (int j = lane; j < d; j += 64) {
+    for (int j = tid; j < d; j += 256) {
         sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
         sdx[j] = sum_slabs1(dxq, ns, MN, (size_t)row * 2 * Hd + (size_t)hd * d + j);
     }
     __syncthreads();
-    const size_t pidx = ((size_t)row * NH + hd) * R;
-    const int r1 = lane + 64;
-    float p0 = 0.f, p1 = 0.f, dP0 = 0.f, dP1 = 0.f;
-    if (lane < len) {
-        p0 = Pm[pidx + lane];
+    const size_t pidx = ((size_t)row * NH + hd) * R + tid;
+    float p = 0.f, dP = 0.f;
+    if (tid < len) {
+        p = Pm[pidx];
         float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += sdx[j] * sv[lane * ld + j];
-        dP0 = Pdm[pidx + lane] != 0.f ? acc * keep_scale : 0.f;
+        for (int j = 0; j < d; ++j) acc += sdx[j] * sv[tid * ld + j];
+        dP = Pdm[pidx] != 0.f ? acc * keep_scale : 0.f;
     }
-    if (r1 < len) {
-        p1 = Pm[pidx + r1];
-        float acc = 0.f;
-        for (int j = 0; j < d; ++j) acc += sdx[j] * sv[r1 * ld + j];
-        dP1 = Pdm[pidx + r1] != 0.f ? acc * keep_scale : 0.f;
-    }
-    const float dot = wave_sum(p0 * dP0 + p1 * dP1);
-    const float rs = sqrtf((float)d);
-    const float dS0 = p0 * (dP0 - dot) / rs, dS1 = p1 * (dP1 - dot) / rs;
-    sds[lane] = dS0; sds[r1] = dS1;
-    if (lane < R) dS_out[pidx + lane] = dS0;
-    if (r1 < R) dS_out[pidx + r1] = dS1;
+    const float wdot = wave_sum(p * dP);
+    if (lane == 0) red[wave] = wdot;
     __syncthreads();
-    for (int j = lane; j < d; j += 64) {
+    const float dot = red[0] + red[1];
+    if (tid < 128) {
+        const float dS = p * (dP - dot) / sqrtf((float)d);
+        sds[tid] = dS;
+        if (tid < R) dS_out[pidx] = dS;
+    }
+    __syncthreads();
+    for (int j = tid; j < d; j += 256) {
         float acc = 0.f;
         for (int r = 0; r < len; ++r) acc += sds[r] * sk[r * ld + j];
         dQp[(size_t)row * Hd + (size_t)hd * d + j] = acc;
@@ -216,7 +213,7 @@ int Aoa::ensure_train() {
     ICZ_REQUIRE(dims.Hd <= 4096, "aoa: training paths keep a LayerNorm row in registers (hidden size %d > 4096)", dims.Hd);
     const size_t B = dims.max_rows, T = dims.max_len, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
     {
-        const size_t dh = Hd / NH, lds_bwd = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
+        const size_t dh = Hd / NH, lds_bwd = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128 + 4);
         if (lds_bwd > 48 * 1024)
             ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(aoa_dec_attn_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                                               (int)lds_bwd));
@@ -447,7 +444,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         ICZ_CHECK_HIP(hipMemsetAsync(tdS, 0, sizeof(float) * (size_t)TB * NH * R, st));
         ICZ_CHECK_HIP(hipMemsetAsync(tdX, 0, sizeof(float) * (size_t)TB * Hd, st));
     }
-    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128);
+    const size_t lds = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128 + 4);
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     int cur = 0, nsx = 1, bnext = 0;
     for (int t = T - 1; t >= 0; --t) {
@@ -460,7 +457,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
                            io_next.d_ctx, tz + s0 * 2 * Hd, dZ + s0 * 2 * Hd, bt, Hd);
         int ns2 = 1, nsq = 1;
         ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
-        hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(64), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
+        hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(256), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
                            tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, region_rows(), io.d_att.mode ? io.d_att.scale : 1.0f);
         ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
         hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
