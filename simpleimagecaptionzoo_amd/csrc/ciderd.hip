@@ -1,10 +1,11 @@
 // CIDEr-D reward on the device (float64), replacing the per-batch pure-Python scorer of the reference:
 //   Utils.py:319-367 get_self_critical_reward -> ciderD.py:30-55 -> ciderD_scorer.py:17-32 (precook),
 //   :127-206 (compute_cider).
-// One wave per hypothesis (2B of them: B sampled, B greedy).  Hypotheses are at most T <= 60 tokens, so a
-// hypothesis has at most 4T n-gram positions; lanes work on positions in parallel (dedup, df lookup, match against
-// the cooked references) and lane 0 performs every floating-point accumulation in the reference's dict-insertion
-// order, which makes the scores bit-identical to the reference's float64 results.
+// One workgroup of CD_NW waves per hypothesis (2B of them: B sampled, B greedy).  Hypotheses are at most T <= 60 tokens,
+// so a hypothesis has at most 4T n-gram positions; threads work on positions in parallel (dedup, df lookup) and each wave
+// matches the hypothesis against one of the image's cooked references at a time.  Every floating-point accumulation is
+// performed by one lane in the reference's dict-insertion order (per reference by the wave's lane 0, across references
+// by thread 0 in reference order), which makes the scores bit-identical to the reference's float64 results.
 #include "icz_common.h"
 
 namespace icz {
@@ -19,6 +20,7 @@ struct CiderD {
 
 constexpr int CD_MAXT = 60;                 // max tokens per hypothesis
 constexpr int CD_MAXP = 4 * CD_MAXT;        // max n-gram positions
+constexpr int CD_NW = 8;                    // waves per hypothesis = references matched at a time
 
 __host__ __device__ inline uint32_t ngram_hash(int a, int b, int c, int d) {
     uint32_t h = 2166136261u;
@@ -38,14 +40,16 @@ struct CiderArgs {
     double* scores;      // [2B]
 };
 
-__global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
+__global__ __launch_bounds__(64 * CD_NW) void ciderd_kernel(CiderArgs a) {
     __shared__ int tok[CD_MAXT];
     __shared__ int pkey[CD_MAXP][4];
     __shared__ int porder[CD_MAXP];       // 1..4
     __shared__ int pcount[CD_MAXP];       // occurrences if this position is the first occurrence, else 0
     __shared__ double pw[CD_MAXP];        // tf-idf weight of the n-gram first seen at this position
-    __shared__ double pmatch[CD_MAXP];    // weight of the same n-gram in the current reference (0 if absent)
-    const int hyp = blockIdx.x, lane = threadIdx.x;
+    __shared__ double pmatch[CD_NW][CD_MAXP];    // per wave: weight of the same n-gram in the wave's current reference (0 if absent)
+    __shared__ double rval[CD_NW][4];     // per wave: the reference's contribution to the four n-gram orders
+    constexpr int NT = 64 * CD_NW;
+    const int hyp = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int b = hyp % a.B;
     const bool is_greedy = hyp >= a.B;
     const int64_t* ids = (is_greedy ? a.greedy : a.gen) + (size_t)b * a.T;
@@ -63,12 +67,12 @@ __global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
         }
         len = end + 1;
     }
-    for (int i = lane; i < len; i += 64) tok[i] = (int)ids[i];
+    for (int i = tid; i < len; i += NT) tok[i] = (int)ids[i];
     __syncthreads();
     // ---- n-gram positions in precook order: k = 1..4, i = 0..len-k
     int npos = 0, start[5];
     for (int k = 1; k <= 4; ++k) { start[k] = npos; npos += (len - k + 1 > 0) ? (len - k + 1) : 0; }
-    for (int p = lane; p < npos; p += 64) {
+    for (int p = tid; p < npos; p += NT) {
         int k = 4;
         while (k > 1 && p < start[k]) --k;
         const int i = p - start[k];
@@ -77,7 +81,7 @@ __global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
     }
     __syncthreads();
     // ---- dedup: a position is "first" if no earlier position holds the same n-gram; count = #occurrences
-    for (int p = lane; p < npos; p += 64) {
+    for (int p = tid; p < npos; p += NT) {
         const int k = porder[p];
         bool first = true;
         int cnt = 0;
@@ -103,10 +107,10 @@ __global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
         pw[p] = w;
     }
     __syncthreads();
-    // ---- hypothesis norms and length (lane 0, insertion order)   (:146-152)
+    // ---- hypothesis norms and length (thread 0, insertion order)   (:146-152)
     __shared__ double hnorm[4];
     __shared__ int hlen;
-    if (lane == 0) {
+    if (tid == 0) {
         double nn[4] = {0.0, 0.0, 0.0, 0.0};
         int l2 = 0;
         for (int p = 0; p < npos; ++p)
@@ -118,30 +122,33 @@ __global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
         hlen = l2;
     }
     __syncthreads();
-    // ---- references of this image
+    // ---- references of this image, CD_NW at a time: wave w takes reference rc + w
     const int r0 = a.img_ref_ptr[b], r1 = a.img_ref_ptr[b + 1];
     double score[4] = {0.0, 0.0, 0.0, 0.0};
-    for (int r = r0; r < r1; ++r) {
-        const int e0 = a.ref_ent_ptr[r], e1 = a.ref_ent_ptr[r + 1];
-        for (int p = lane; p < npos; p += 64) {
-            double m = 0.0;
-            if (pcount[p]) {
-                for (int e = e0; e < e1; ++e) {
-                    const int32_t* kk = a.ent_key + (size_t)e * 4;
-                    if (a.ent_order[e] == porder[p] && kk[0] == pkey[p][0] && kk[1] == pkey[p][1] && kk[2] == pkey[p][2] && kk[3] == pkey[p][3]) {
-                        m = a.ent_w[e];
-                        break;
+    for (int rc = r0; rc < r1; rc += CD_NW) {
+        const int r = rc + wave;
+        if (r < r1) {
+            const int e0 = a.ref_ent_ptr[r], e1 = a.ref_ent_ptr[r + 1];
+            for (int p = lane; p < npos; p += 64) {
+                double m = 0.0;
+                if (pcount[p]) {
+                    for (int e = e0; e < e1; ++e) {
+                        const int32_t* kk = a.ent_key + (size_t)e * 4;
+                        if (a.ent_order[e] == porder[p] && kk[0] == pkey[p][0] && kk[1] == pkey[p][1] && kk[2] == pkey[p][2] && kk[3] == pkey[p][3]) {
+                            m = a.ent_w[e];
+                            break;
+                        }
                     }
                 }
+                pmatch[wave][p] = m;
             }
-            pmatch[p] = m;
         }
         __syncthreads();
-        if (lane == 0) {
+        if (r < r1 && lane == 0) {
             double val[4] = {0.0, 0.0, 0.0, 0.0};
             for (int p = 0; p < npos; ++p)
                 if (pcount[p]) {
-                    const double h = pw[p], rr = pmatch[p];
+                    const double h = pw[p], rr = pmatch[wave][p];
                     val[porder[p] - 1] += (h < rr ? h : rr) * rr;       // min(vec_hyp, vec_ref) * vec_ref  (:172-175)
                 }
             int d = hlen - a.ref_len[r];
@@ -151,12 +158,18 @@ __global__ __launch_bounds__(64) void ciderd_kernel(CiderArgs a) {
                 const double nr = a.ref_norm[(size_t)r * 4 + n];
                 if (hnorm[n] != 0.0 && nr != 0.0) val[n] /= (hnorm[n] * nr);
                 val[n] *= pen;
-                score[n] += val[n];
+                rval[wave][n] = val[n];
             }
         }
         __syncthreads();
+        if (tid == 0) {
+            const int nr_ = r1 - rc < CD_NW ? r1 - rc : CD_NW;
+            for (int w = 0; w < nr_; ++w)
+                for (int n = 0; n < 4; ++n) score[n] += rval[w][n];       // reference order, as the scorer's loop (:186-196)
+        }
+        __syncthreads();
     }
-    if (lane == 0) {
+    if (tid == 0) {
         double s = score[0];
         s += score[1]; s += score[2]; s += score[3];
         s = s / 4.0;                      // np.mean over n
@@ -209,7 +222,7 @@ int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy
     CiderArgs a = {c->keys, c->idf, c->penalty, c->cap, c->default_idf, gen, greedy, B, T,
                    img_ref_ptr, ref_ent_ptr, ent_key, ent_order, ent_w, ref_norm, ref_len, scores_out};
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(ciderd_kernel, dim3(2 * B), dim3(64), 0, st, a);
+    hipLaunchKernelGGL(ciderd_kernel, dim3(2 * B), dim3(64 * CD_NW), 0, st, a);
     if (reward_out) hipLaunchKernelGGL(ciderd_reward_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, st, scores_out, B, T, reward_out);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
