@@ -771,26 +771,48 @@ struct AttBwdDencArgs {
 };
 template <int TT>
 __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
+    static_assert(TT <= 32, "one half-wave computes the TT Philox words of its 128-column group");
     extern __shared__ __attribute__((aligned(16))) float sds_t[];     // [T][R] ds of this row
+    // Philox keep-bits: one call covers 128 consecutive elements = the 32 lanes of a half-wave (4 columns each), so instead
+    // of every lane calling it for every time step, lane j of a half-wave calls it for step t0 + j and the words are handed
+    // round through LDS: TT calls per half-wave and region instead of 32 * TT.
+    __shared__ uint32_t sbits[4][2][TT][4];
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, hl = lane & 31;
     for (int i = tid; i < a.T * a.R; i += 256) {
         const int t = i / a.R, r = i % a.R;
         sds_t[i] = a.ds_all[((size_t)t * a.B + row) * a.R + r];
     }
     __syncthreads();
     const float sc = a.mode ? 2.0f : 1.0f;
-    for (int c = tid * 4; c < a.A; c += 1024) {
-        const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+    const bool shared_bits = a.mode == 2 && (a.A & 127) == 0;
+    for (int c0 = 0; c0 < a.A; c0 += 1024) {          // uniform over the workgroup (barriers inside)
+        const int c = c0 + tid * 4;
+        const bool cv = c < a.A;
+        const f32x4 w = cv ? *reinterpret_cast<const f32x4*>(a.w_aff + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
         f32x4 dw = {0.f, 0.f, 0.f, 0.f};
         for (int t0 = 0; t0 < a.T; t0 += TT) {
             f32x4 d[TT];
 #pragma unroll
             for (int j = 0; j < TT; ++j) {
                 const int t = min(t0 + j, a.T - 1);
-                d[j] = *reinterpret_cast<const f32x4*>(a.dec_all + ((size_t)t * a.B + row) * a.A + c);
+                d[j] = cv ? *reinterpret_cast<const f32x4*>(a.dec_all + ((size_t)t * a.B + row) * a.A + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             for (int r = part; r < a.R; r += nparts) {
                 const size_t eoff = ((size_t)row * a.R + r) * a.A + c;
+                if (shared_bits) {
+                    __syncthreads();            // the previous region's words have been read
+                    if (cv && hl < TT && t0 + hl < a.T) {
+                        const uint64_t g = (eoff - (size_t)(4 * hl)) >> 7;          // the half-wave's group: its first lane's element
+                        const uint64_t seed = *a.seed_p;
+                        uint4_ ctr = {(uint32_t)g, (uint32_t)(g >> 32), (uint32_t)(t0 + hl), a.stream};
+                        const uint4_ rr = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+                        uint32_t* o = sbits[wave][half][hl];
+                        o[0] = rr.x; o[1] = rr.y; o[2] = rr.z; o[3] = rr.w;
+                    }
+                    __syncthreads();
+                }
+                if (!cv) continue;
                 const f32x4 x = *reinterpret_cast<const f32x4*>(a.enc_ctx + eoff);
                 f32x4 de = {0.f, 0.f, 0.f, 0.f};
                 if (t0 > 0) de = *reinterpret_cast<const f32x4*>(a.denc + eoff);
@@ -803,6 +825,8 @@ __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
                         if (a.mode == 1) {
                             const uint32_t m = *reinterpret_cast<const uint32_t*>(a.mask + (size_t)t * a.mask_step + eoff);
                             k = ((m & 0xFFu) ? 1u : 0u) | ((m & 0xFF00u) ? 2u : 0u) | ((m & 0xFF0000u) ? 4u : 0u) | ((m & 0xFF000000u) ? 8u : 0u);
+                        } else if (shared_bits) {
+                            k = (sbits[wave][half][j][(eoff >> 5) & 3] >> (eoff & 31)) & 0xFu;
                         } else if (a.mode == 2) {
                             k = (rng_group_bits(*a.seed_p, a.stream, (uint32_t)t, eoff) >> (eoff & 31)) & 0xFu;
                         }
@@ -818,7 +842,7 @@ __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
                 *reinterpret_cast<f32x4*>(a.denc + eoff) = de;
             }
         }
-        *reinterpret_cast<f32x4*>(a.dwaff_part + ((size_t)row * nparts + part) * a.A + c) = dw;
+        if (cv) *reinterpret_cast<f32x4*>(a.dwaff_part + ((size_t)row * nparts + part) * a.A + c) = dw;
     }
 }
 

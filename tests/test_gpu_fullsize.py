@@ -224,3 +224,57 @@ def test_spatial_49_regions_butd_and_aoa_match_oracle():
     grads = ha.new_grads()
     ha.sample_backward(torch.ones(n, 6, device="cuda"), grads)
     assert all(torch.isfinite(g).all() for g in grads.values())
+
+
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """numpy twin of csrc/rng.h (Philox4x32-10): uint32 arrays in, four uint32 arrays out."""
+    M0, M1, W0, W1 = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), 0x9E3779B9, 0xBB67AE85
+    c = [np.asarray(x, dtype=np.uint64) for x in (c0, c1, c2, c3)]
+    k0, k1 = int(k0), int(k1)
+    for _ in range(10):
+        p0, p1 = M0 * c[0], M1 * c[2]
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & np.uint64(0xFFFFFFFF), p1 >> np.uint64(32), p1 & np.uint64(0xFFFFFFFF)
+        c = [hi1 ^ c[1] ^ np.uint64(k0), lo1, hi0 ^ c[3] ^ np.uint64(k1), lo0]
+        k0, k1 = (k0 + W0) & 0xFFFFFFFF, (k1 + W1) & 0xFFFFFFFF
+    return c
+
+
+def _keep_bits(seed, stream, step, n):
+    """keep flags of elements 0..n-1 of one dropout call: bit (idx & 31) of word (idx >> 5) & 3 of the Philox block idx >> 7."""
+    idx = np.arange(n, dtype=np.uint64)
+    g = idx >> np.uint64(7)
+    gu = np.unique(g)
+    r = _philox4x32_10(gu & np.uint64(0xFFFFFFFF), gu >> np.uint64(32), np.full(gu.shape, step), np.full(gu.shape, stream),
+                       seed & 0xFFFFFFFF, seed >> 32)
+    words = np.stack(r, 1)[g.astype(np.int64), ((idx >> np.uint64(5)) & np.uint64(3)).astype(np.int64)]
+    return ((words >> (idx & np.uint64(31))) & np.uint64(1)).astype(np.uint8)
+
+
+def test_fullsize_philox_masks_regenerated_in_backward_equal_the_forward_ones(full):
+    """Philox mode (nothing stored: forward and backward each regenerate the keep-bits, the backward kernels share one Philox
+    call among the lanes it covers) against the explicit-mask mode fed with the same bits from a numpy twin of rng.h: same
+    tokens and log-probs, bit-identical gradients."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    h, params, feats = full
+    B, T, seed = 64, 20, 0x1234ABCD5678
+    seq1, lp1 = h.sample(feats, T, make_rng(seed))
+    seq1, lp1 = seq1.clone(), lp1.clone()
+    reward = torch.randn(B, T, device="cuda")
+    g1 = h.new_grads()
+    loss1, _ = h.sample_backward(reward, g1)
+    em = np.stack([_keep_bits(seed, 1, t, B * E).reshape(B, E) for t in range(T)])
+    am = np.stack([_keep_bits(seed, 2, t, B * R * A).reshape(B, R, A) for t in range(T)])
+    om = np.stack([_keep_bits(seed, 3, t, B * H).reshape(B, H) for t in range(T)])
+    rows = np.arange(B, dtype=np.uint64)
+    u = np.stack([(_philox4x32_10(rows, np.zeros(B), np.full(B, t), np.full(B, 4), seed & 0xFFFFFFFF, seed >> 32)[0] >> np.uint64(8))
+                  .astype(np.float32) / np.float32(16777216.0) for t in range(T)])
+    assert 0.45 < am.mean() < 0.55
+    rng = make_rng(0, torch.tensor(u, device="cuda"), torch.tensor(em, device="cuda"), torch.tensor(am, device="cuda"),
+                   torch.tensor(om, device="cuda"))
+    seq2, lp2 = h.sample(feats, T, rng)
+    assert torch.equal(seq1, seq2) and torch.equal(lp1, lp2)
+    g2 = h.new_grads()
+    loss2, _ = h.sample_backward(reward, g2)
+    assert loss1.item() == loss2.item()
+    for k in g1:
+        assert torch.equal(g1[k], g2[k]), k
