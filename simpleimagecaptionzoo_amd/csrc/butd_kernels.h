@@ -178,6 +178,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
     const float baff = a.b_aff[0];
     const float sc = dc.mode ? 2.0f : 1.0f;
     constexpr int NB = 3;
+    const bool shared_bits = dc.mode == 2 && (a.A & 255) == 0;       // whole 256-column strips: every lane runs every c0 iteration
     for (int i0 = wave; part + nparts * i0 < a.R; i0 += 4 * NB) {
         int rr[NB];
         bool ok[NB];
@@ -197,6 +198,27 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int u = 0; u < 4; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(e[b] + min(c0 + 256 * u, a.A - 4));
+            // Philox keep-bits: a call covers 128 consecutive columns = one half-wave of one u; the 8 blocks of each of the NB
+            // regions are computed once (lane 8 b + block) and handed round by shuffles instead of 64 lanes calling it 4 NB times
+            uint32_t kq[NB][4];
+            if (shared_bits) {
+                const int pb = lane >> 3, pg = lane & 7;
+                const int pr = pb == 0 ? rr[0] : (pb == 1 ? rr[1] : rr[NB - 1]);
+                const uint64_t g = (((uint64_t)row * a.R + pr) * a.A + (c0 - lane * 4) + 128 * pg) >> 7;
+                const uint64_t seed = *dc.seed_p;
+                uint4_ ctr = {(uint32_t)g, (uint32_t)(g >> 32), dc.step, dc.stream};
+                const uint4_ pw = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int src = 8 * b + 2 * u + (lane >> 5);
+                        const uint32_t w0 = __shfl(pw.x, src), w1 = __shfl(pw.y, src), w2 = __shfl(pw.z, src), w3 = __shfl(pw.w, src);
+                        const int wi = (lane >> 3) & 3;
+                        const uint32_t ww = wi == 0 ? w0 : (wi == 1 ? w1 : (wi == 2 ? w2 : w3));
+                        kq[b][u] = (ww >> ((4 * lane) & 31)) & 0xFu;
+                    }
+            }
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int c = c0 + 256 * u;
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
                     const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        const uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + rr[b]) * a.A + c) : 0xFu;
+                        const uint32_t k = shared_bits ? kq[b][u] : (dc.mode ? dc.keep4(((uint64_t)row * a.R + rr[b]) * a.A + c) : 0xFu);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float zv = fmaxf(x[b][u][j] + d[j], 0.f);
@@ -728,6 +750,7 @@ __global__ __launch_bounds__(256) void att_bwd_ddec_kernel(AttBwdDdecArgs a, Dro
         const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
         const float sc = dc.mode ? 2.0f : 1.0f;
         constexpr int RB = 9;
+        const bool shared_bits = dc.mode == 2 && (a.A & 255) == 0;      // every lane of the wave is valid and takes every iteration
         for (int r0 = wq; r0 < a.R; r0 += 4 * RB) {
             f32x4 x[RB];
 #pragma unroll
@@ -735,12 +758,30 @@ __global__ __launch_bounds__(256) void att_bwd_ddec_kernel(AttBwdDdecArgs a, Dro
                 const int r = min(r0 + 4 * u, a.R - 1);
                 x[u] = *reinterpret_cast<const f32x4*>(a.enc_ctx + ((size_t)row * a.R + r) * a.A + c);
             }
+            // Philox keep-bits, shared as in att_scores_kernel: lane 2 u + half computes the block of region u's half-strip
+            uint32_t kq[RB];
+            if (shared_bits) {
+                const int pu = min(lane >> 1, RB - 1), ph = lane & 1;
+                const int pr = min(r0 + 4 * pu, a.R - 1);
+                const uint64_t g = (((uint64_t)row * a.R + pr) * a.A + blockIdx.y * 256 + 128 * ph) >> 7;
+                const uint64_t seed = *dc.seed_p;
+                uint4_ ctr = {(uint32_t)g, (uint32_t)(g >> 32), dc.step, dc.stream};
+                const uint4_ pw = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+                for (int u = 0; u < RB; ++u) {
+                    const int src = 2 * u + (lane >> 5);
+                    const uint32_t w0 = __shfl(pw.x, src), w1 = __shfl(pw.y, src), w2 = __shfl(pw.z, src), w3 = __shfl(pw.w, src);
+                    const int wi = (lane >> 3) & 3;
+                    const uint32_t ww = wi == 0 ? w0 : (wi == 1 ? w1 : (wi == 2 ? w2 : w3));
+                    kq[u] = (ww >> ((4 * lane) & 31)) & 0xFu;
+                }
+            }
 #pragma unroll
             for (int u = 0; u < RB; ++u) {
                 const int r = r0 + 4 * u;
                 if (r < a.R) {
                     const float ds = sds[r];
-                    const uint32_t k = dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu;
+                    const uint32_t k = shared_bits ? kq[u] : (dc.mode ? dc.keep4(((uint64_t)row * a.R + r) * a.A + c) : 0xFu);
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const bool on = (x[u][j] + d[j] > 0.f) && ((k >> j) & 1u);
