@@ -129,7 +129,7 @@ struct Butd {
     const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr; const int64_t* cur_captions = nullptr;
     std::vector<int> rows_t;
     int ensure_train(int B, int T);
-    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st);
+    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_mask_sum(float* out, hipStream_t st);
     int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,

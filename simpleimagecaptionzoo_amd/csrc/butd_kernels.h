@@ -418,6 +418,9 @@ struct SampleSelArgs {
     int64_t* it_next;             // [rows]
     int32_t* draw_out;            // [rows] raw draw (for backward)
     float* lse_out;               // [rows] max + log(sum exp) (for backward)
+    // optional fused epilogue: the next step's input embedding emb_next[row,:] = drop(relu(table[it_next[row],:])) (the
+    // embed_kernel of step t + 1, :77-81) with that step's dropout configuration
+    const float* emb_table; float* emb_next; int E; DropCfg emb_drop;
 };
 constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS, every pass is LDS-bound
 __device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
@@ -453,6 +456,16 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
             a.it_next[row] = 0;
             a.draw_out[row] = -1;
             a.lse_out[row] = 0.f;
+        }
+        if (a.emb_next) {           // token 0 (<pad>), as embed_kernel would produce for it_next = 0
+            const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
+            for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + e);
+                const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
+                *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
+            }
         }
         return;
     }
@@ -516,6 +529,19 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         a.draw_out[row] = d;
         a.lse_out[row] = mx + lse;
         if (unf) atomicAdd(&a.n_unfinished[a.t], 1);
+        smi[0] = (int)itv;
+    }
+    if (a.emb_next) {
+        __syncthreads();
+        const int tok = smi[0];
+        const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
+        for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + (size_t)tok * a.E + e);
+            const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
+            *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
+        }
     }
 }
 

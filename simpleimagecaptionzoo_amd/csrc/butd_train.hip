@@ -86,11 +86,12 @@ static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base
 
 // ------------------------------------------------------------------------------------------------
 // forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
-int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st) {
+int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready) {
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
     const size_t Vp = round4(dims.V);
     const size_t slot = (size_t)t * Bs;
     StepIO s = {};
+    s.emb_ready = emb_ready;         // written by the previous step's sample_select_kernel
     s.rows = rows; s.feats = feats; s.it = tb.tok + slot;
     s.h1_in = tb.h1 + slot * H; s.c1_in = tb.c1 + slot * H; s.h2_in = tb.h2 + slot * H; s.c2_in = tb.c2 + slot * H;
     s.h1_out = tb.h1 + (slot + Bs) * H; s.c1_out = tb.c1 + (slot + Bs) * H;
@@ -181,7 +182,7 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
     }
     hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok, B, T);
     for (int t = 0; t < T; ++t) {
-        ICZ_TRY(train_step(feats, B, B, t, true, st));
+        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0));
         SampleSelArgs a = {};
         a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
         a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
@@ -190,6 +191,10 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
         a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tb.tok + (size_t)(t + 1) * B;
         a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
+        if (t + 1 < T) {             // the next step's input embedding, fused (step t + 1's slot and dropout stream)
+            a.emb_table = P.embed_weight; a.emb_next = tb.emb + (size_t)(t + 1) * B * dims.E; a.E = dims.E;
+            a.emb_drop = make_drop(d_seed, true, rng.emb_mask, (size_t)B * dims.E, RNG_EMB, t + 1);
+        }
         hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
