@@ -85,10 +85,17 @@ Butd::~Butd() {
 int Butd::refresh(hipStream_t st) {
     ICZ_REQUIRE(bound, "butd: parameters not bound");
     const int A = dims.A, D = dims.D, H = dims.H, V = dims.V;
-    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, P.enc_att_v, P.enc_att_g, w_enc, n_enc, A, D);
-    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, P.dec_att_v, P.dec_att_g, w_dec, n_dec, A, H);
-    hipLaunchKernelGGL(weight_norm_kernel, dim3(1), dim3(256), 0, st, P.affine_v, P.affine_g, w_aff, n_aff, 1, A);
-    hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, P.predict_v, P.predict_g, w_pred, n_pred, V, H);
+    WeightNormTable wt = {};
+    int nb = 0;
+    auto add = [&](const float* v, const float* g, float* w, float* norm, int rows, int cols) {
+        wt.j[wt.count++] = {v, g, w, norm, rows, cols, nb};
+        nb += cdiv(rows, 4);
+    };
+    add(P.enc_att_v, P.enc_att_g, w_enc, n_enc, A, D);
+    add(P.dec_att_v, P.dec_att_g, w_dec, n_dec, A, H);
+    add(P.affine_v, P.affine_g, w_aff, n_aff, 1, A);
+    add(P.predict_v, P.predict_g, w_pred, n_pred, V, H);
+    hipLaunchKernelGGL(weight_norm_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
     ICZ_CHECK_HIP(hipGetLastError());
     fresh = true;
     return ICZ_OK;

@@ -33,6 +33,35 @@ __global__ __launch_bounds__(256) void weight_norm_kernel(const float* __restric
     if (lane == 0) norm[row] = nrm;
 }
 
+// The four weight-normed layers of the decoder in ONE launch (blocks laid out job after job, 4 rows per block).
+struct WeightNormJob { const float* v; const float* g; float* w; float* norm; int rows, cols, block0; };
+struct WeightNormTable { WeightNormJob j[4]; int count; };
+__global__ __launch_bounds__(256) void weight_norm_multi_kernel(WeightNormTable tab) {
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < tab.count; ++i)
+        if ((int)blockIdx.x >= tab.j[i].block0) k = i;
+    const WeightNormJob& jb = tab.j[k];
+    const int lane = threadIdx.x & 63;
+    const int row = ((int)blockIdx.x - jb.block0) * 4 + (threadIdx.x >> 6);
+    if (row >= jb.rows) return;
+    const float* vr = jb.v + (size_t)row * jb.cols;
+    float ss = 0.f;
+    for (int c = lane * 4; c < jb.cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        ss += x[0] * x[0] + x[1] * x[1] + x[2] * x[2] + x[3] * x[3];
+    }
+    ss = wave_sum(ss);
+    const float nrm = sqrtf(ss);
+    const float s = jb.g[row] / nrm;
+    float* wr = jb.w + (size_t)row * jb.cols;
+    for (int c = lane * 4; c < jb.cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        *reinterpret_cast<f32x4*>(wr + c) = x * s;
+    }
+    if (lane == 0) jb.norm[row] = nrm;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // mean over regions (:117,:167,:205,:251): mean[b,d] = sum_r feats[b,r,d] / R
 __global__ __launch_bounds__(256) void mean_feats_kernel(const float* __restrict__ feats, float* __restrict__ mean,
@@ -944,6 +973,43 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* __restrict__ X
     }
 }
 
+// Several column sums in ONE launch (the bias gradients at the end of BPTT): blocks laid out job after job; out2 (optional)
+// receives a copy (b_ih and b_hh have the same gradient); a job with K = 0 writes zeros.
+struct ColsumJob { const float* X; int K, N, ldx; float* out; float* out2; int block0; };
+struct ColsumTable { ColsumJob j[8]; int count; };
+__global__ __launch_bounds__(256) void colsum_multi_kernel(ColsumTable tab) {
+    __shared__ float part[8][33];
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < tab.count; ++i)
+        if ((int)blockIdx.x >= tab.j[i].block0) k = i;
+    const ColsumJob& jb = tab.j[k];
+    const int c = threadIdx.x & 31, g = threadIdx.x >> 5;
+    const int n = ((int)blockIdx.x - jb.block0) * 32 + c;
+    float s = 0.f;
+    if (n < jb.N) {
+        const float* x = jb.X + n;
+        int kk = g;
+        for (; kk + 56 < jb.K; kk += 64) {
+            float v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = x[(size_t)(kk + 8 * u) * jb.ldx];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) s += v[u];
+        }
+        for (; kk < jb.K; kk += 8) s += x[(size_t)kk * jb.ldx];
+    }
+    part[g][c] = s;
+    __syncthreads();
+    if (g == 0 && n < jb.N) {
+        float t = part[0][c];
+#pragma unroll
+        for (int q = 1; q < 8; ++q) t += part[q][c];
+        jb.out[n] = t;
+        if (jb.out2) jb.out2[n] = t;
+    }
+}
+
 // out[b, n] = sum_t X[t, b, n]   (time sum of the TD gate gradients for the hoisted mean-feature weights)
 __global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ X, int T, size_t BN, float* __restrict__ out) {
     const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
@@ -1032,8 +1098,38 @@ __global__ __launch_bounds__(256) void weight_norm_bwd_kernel(const float* __res
     if (lane == 0) dg[row] = dgv;
 }
 
-// out[a] = sum_i X[i, a]  for the affine weight gradient partials (rows*parts, A) -> (A)
-// (same as colsum; kept separate for clarity of the call sites)
+// The attention block's three weight-normed layers in ONE launch (blocks job after job, 4 rows per block).
+struct WeightNormBwdJob { const float* dw; int lddw; const float* v; const float* g; const float* norm; float* dv; float* dg; int rows, cols, block0; };
+struct WeightNormBwdTable { WeightNormBwdJob j[4]; int count; };
+__global__ __launch_bounds__(256) void weight_norm_bwd_multi_kernel(WeightNormBwdTable tab) {
+    int k = 0;
+#pragma unroll 1
+    for (int i = 1; i < tab.count; ++i)
+        if ((int)blockIdx.x >= tab.j[i].block0) k = i;
+    const WeightNormBwdJob& jb = tab.j[k];
+    const int lane = threadIdx.x & 63;
+    const int row = ((int)blockIdx.x - jb.block0) * 4 + (threadIdx.x >> 6);
+    if (row >= jb.rows) return;
+    const float* vr = jb.v + (size_t)row * jb.cols;
+    const float* dr = jb.dw + (size_t)row * jb.lddw;
+    float dot = 0.f;
+    for (int c = lane * 4; c < jb.cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+        dot += x[0] * d[0] + x[1] * d[1] + x[2] * d[2] + x[3] * d[3];
+    }
+    dot = wave_sum(dot);
+    const float nrm = jb.norm[row];
+    const float dgv = dot / nrm;
+    const float s = jb.g[row] / nrm;
+    float* o = jb.dv + (size_t)row * jb.cols;
+    for (int c = lane * 4; c < jb.cols; c += 256) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(vr + c);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dr + c);
+        *reinterpret_cast<f32x4*>(o + c) = (d - x * (dgv / nrm)) * s;
+    }
+    if (lane == 0) jb.dg[row] = dgv;
+}
 
 // ---------------------------------------------------------------------------------------------------------
 // clip_gradient + Adam over a table of tensors in ONE launch (21 parameter tensors per step otherwise cost 21 launches).

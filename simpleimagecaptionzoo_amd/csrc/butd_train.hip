@@ -569,21 +569,33 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         hipLaunchKernelGGL(att_bwd_denc_kernel<20>, dim3(B, ATT_PARTS), dim3(256), sizeof(float) * T * R, st, ea);
     }
     ICZ_TRY(wgrad(tb.dEnc, A, A, feats, D, D, B * R, tb.dWenc, D, st));
-    ICZ_TRY(colsum(tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih, st));
-    ICZ_TRY(colsum(tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih, st));
-    ICZ_CHECK_HIP(hipMemcpyAsync(G.td_b_hh, G.td_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    ICZ_CHECK_HIP(hipMemcpyAsync(G.lm_b_hh, G.lm_b_ih, sizeof(float) * 4 * H, hipMemcpyDeviceToDevice, st));
-    ICZ_TRY(colsum(tb.dDec, TB, A, A, G.dec_att_b, st));
-    ICZ_TRY(colsum(tb.dEnc, B * R, A, A, G.enc_att_b, st));
-    ICZ_TRY(colsum(tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff, st));
-    // d loss / d affine.bias is identically zero (softmax shift invariance)
-    ICZ_CHECK_HIP(hipMemsetAsync(G.affine_b, 0, sizeof(float), st));
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc,
-                       G.enc_att_v, G.enc_att_g, A, D);
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(A, 4)), dim3(256), 0, st, tb.dWdec, H, P.dec_att_v, P.dec_att_g, n_dec,
-                       G.dec_att_v, G.dec_att_g, A, H);
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(1), dim3(256), 0, st, tb.dWaff, A, P.affine_v, P.affine_g, n_aff,
-                       G.affine_v, G.affine_g, 1, A);
+    {   // bias gradients: five column sums (+ the b_hh copies, + the identically zero affine bias: softmax shift invariance) in one launch
+        ColsumTable ct = {};
+        int nb = 0;
+        auto add = [&](const float* X, int K, int N, int ldx, float* out, float* out2) {
+            ct.j[ct.count++] = {X, K, N, ldx, out, out2, nb};
+            nb += cdiv(N, 32);
+        };
+        add(tb.dGtd, TB, 4 * H, 4 * H, G.td_b_ih, G.td_b_hh);
+        add(tb.dGlm, TB, 4 * H, 4 * H, G.lm_b_ih, G.lm_b_hh);
+        add(tb.dDec, TB, A, A, G.dec_att_b, nullptr);
+        add(tb.dEnc, B * R, A, A, G.enc_att_b, nullptr);
+        add(tb.dwaff, B * ATT_PARTS, A, A, tb.dWaff, nullptr);
+        add(tb.dwaff, 0, 1, 1, G.affine_b, nullptr);
+        hipLaunchKernelGGL(colsum_multi_kernel, dim3(nb), dim3(256), 0, st, ct);
+    }
+    {   // the attention block's three weight-normed layers
+        WeightNormBwdTable wt = {};
+        int nb = 0;
+        auto add = [&](const float* dw, int lddw, const float* v, const float* g, const float* norm, float* dv, float* dg, int rows, int cols) {
+            wt.j[wt.count++] = {dw, lddw, v, g, norm, dv, dg, rows, cols, nb};
+            nb += cdiv(rows, 4);
+        };
+        add(tb.dWenc, D, P.enc_att_v, P.enc_att_g, n_enc, G.enc_att_v, G.enc_att_g, A, D);
+        add(tb.dWdec, H, P.dec_att_v, P.dec_att_g, n_dec, G.dec_att_v, G.dec_att_g, A, H);
+        add(tb.dWaff, A, P.affine_v, P.affine_g, n_aff, G.affine_v, G.affine_g, 1, A);
+        hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
+    }
     if (!joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
