@@ -482,8 +482,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         const size_t MN = (size_t)TB * E;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, E, (const float*)nullptr, dEmb);
     }
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), sizeof(int) * TB, st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E,
-                       G.embed_weight, 1);
+    ICZ_CHECK_HIP(embed_grad_launch(st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1));
     // ---- weight gradients: one TN GEMM each over all (t, b) rows
     ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st));
     ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st));

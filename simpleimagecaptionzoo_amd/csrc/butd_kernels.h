@@ -1020,52 +1020,81 @@ __global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Embedding gradient (Embedding -> ReLU -> Dropout backward), one workgroup per vocabulary row:
+// Embedding gradient (Embedding -> ReLU -> Dropout backward):
 //   dE[v,:] = sum over (t,b) with tok[t,b] == v of demb[t,b,:] * (emb[t,b,:] > 0 ? scale : 0)
-// No atomics: the (t,b) list is scanned in fixed order, rows without occurrences are written as zeros.
+// No atomics: a workgroup takes 8 vocabulary rows (two per wave); the (t,b) token list is loaded into LDS once per workgroup,
+// each wave finds the occurrences of its row by ballot in list order and adds their rows in that order; rows without
+// occurrences (almost all of them) are written as zeros.
+constexpr int EG_ROWS = 8;
 __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, int n_tok,
                                                          const float* __restrict__ demb, int ns, size_t slab_stride,
                                                          const float* __restrict__ emb, float scale, int E,
-                                                         float* __restrict__ dE, int relu = 1) {
-    extern __shared__ int hits[];     // indices of matching (t,b) entries, capacity n_tok
-    __shared__ int nhit;
-    const int v = blockIdx.x, tid = threadIdx.x;
-    if (tid == 0) nhit = 0;
+                                                         float* __restrict__ dE, int V, int relu) {
+    extern __shared__ int eg_sm[];     // tokens [n_tok], then per wave the indices of its row's occurrences [4][n_tok]
+    int* stok = eg_sm;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int* hits = eg_sm + n_tok + wave * n_tok;
+    for (int i = tid; i < n_tok; i += 256) stok[i] = (int)tok[i];
     __syncthreads();
-    // ordered compaction: each thread scans a contiguous slice, then slices are concatenated in order
-    const int per = (n_tok + 255) / 256;
-    const int i0 = tid * per, i1 = min(n_tok, i0 + per);
-    int cnt = 0;
-    for (int i = i0; i < i1; ++i) cnt += (tok[i] == v);
-    __shared__ int offs[257];
-    offs[tid + 1] = cnt;
-    if (tid == 0) offs[0] = 0;
-    __syncthreads();
-    if (tid == 0) {
-        for (int i = 0; i < 256; ++i) offs[i + 1] += offs[i];
-        nhit = offs[256];
-    }
-    __syncthreads();
-    int o = offs[tid];
-    for (int i = i0; i < i1; ++i)
-        if (tok[i] == v) hits[o++] = i;
-    __syncthreads();
-    const int nh = nhit;
-    for (int e = tid * 4; e < E; e += 1024) {
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int h = 0; h < nh; ++h) {
-            const size_t off = (size_t)hits[h] * E + e;
-            f32x4 g = sum_slabs4(demb, ns, slab_stride, off);
-            if (relu) {
-                f32x4 x = *reinterpret_cast<const f32x4*>(emb + off);
+    for (int rr = 0; rr < EG_ROWS / 4; ++rr) {
+        const int v = blockIdx.x * EG_ROWS + wave + 4 * rr;
+        int nh = 0;
+        for (int i0 = 0; i0 < n_tok; i0 += 64) {
+            const int i = i0 + lane;
+            const bool m = i < n_tok && stok[i] == v;
+            const unsigned long long bal = __ballot(m);
+            if (m) hits[nh + __popcll(bal & ((1ull << lane) - 1ull))] = i;
+            nh += __popcll(bal);
+        }
+        __syncthreads();
+        if (v < V) {
+            // the kernel lasts as long as its most frequent token (<sta> occurs once per caption): four occurrences x four
+            // 256-column strips of loads are in flight at a time; the additions stay in list order
+            for (int e0 = lane * 4; e0 < E; e0 += 1024) {
+                f32x4 s[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) s[j] += x[j] > 0.f ? g[j] * scale : 0.f;
-            } else {
-                s += g * scale;
+                for (int q = 0; q < 4; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                for (int h0 = 0; h0 < nh; h0 += 4) {
+                    f32x4 g[4][4], x[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const size_t base = (size_t)hits[min(h0 + u, nh - 1)] * E;
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const size_t off = base + min(e0 + 256 * q, E - 4);
+                            g[u][q] = sum_slabs4(demb, ns, slab_stride, off);
+                            if (relu) x[u][q] = *reinterpret_cast<const f32x4*>(emb + off);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u)
+                        if (h0 + u < nh) {
+#pragma unroll
+                            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                                for (int j = 0; j < 4; ++j) s[q][j] += (!relu || x[u][q][j] > 0.f) ? g[u][q][j] * scale : 0.f;
+                        }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (e0 + 256 * q < E) *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e0 + 256 * q) = s[q];
             }
         }
-        *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e) = s;
+        __syncthreads();
     }
+}
+// host side: grid, LDS size (above the 64 KB default the kernel needs the explicit opt-in)
+inline hipError_t embed_grad_launch(hipStream_t st, const int64_t* tok, int n_tok, const float* demb, int ns, size_t slab_stride,
+                                    const float* emb, float scale, int E, float* dE, int V, int relu) {
+    const size_t lds = sizeof(int) * 5 * (size_t)n_tok;
+    if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
+    if (lds > 48 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return e;
+    }
+    hipLaunchKernelGGL(embed_grad_kernel, dim3((V + EG_ROWS - 1) / EG_ROWS), dim3(256), lds, st, tok, n_tok, demb, ns, slab_stride, emb, scale, E, dE,
+                       V, relu);
+    return hipSuccess;
 }
 
 // ---------------------------------------------------------------------------------------------------------

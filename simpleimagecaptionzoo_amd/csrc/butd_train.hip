@@ -547,8 +547,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, E, (const float*)nullptr, tb.dEmb);
         }
         // inactive (t,b) rows have dG = 0 -> dEmb = 0; their token ids are whatever the buffer held (valid ids)
-        hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), sizeof(int) * TB, st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb,
-                           cur_train ? 2.0f : 1.0f, E, G.embed_weight);
+        ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
     const int ldtd = H + D + E, ldlm = D + H;

@@ -385,7 +385,7 @@ int Nic::bptt(const icz_nic_params& G, float* dfeats, hipStream_t st) {
     }
     // embedding gradient, image-feature gradient
     ICZ_TRY(nn(dG + (size_t)B * 4 * H, 4 * H, TB, 4 * H, P.w_ih, E, E, dEmb, nullptr, TARGET_WGS, st));
-    hipLaunchKernelGGL(embed_grad_kernel, dim3(V), dim3(256), sizeof(int) * TB, st, tok, TB, dEmb, 1, (size_t)0, temb, 1.0f, E, G.embed_weight, 0);
+    ICZ_CHECK_HIP(embed_grad_launch(st, tok, TB, dEmb, 1, (size_t)0, temb, 1.0f, E, G.embed_weight, V, 0));
     if (dfeats) ICZ_TRY(nn(dG, 4 * H, B, 4 * H, P.w_ih, E, E, dfeats, nullptr, TARGET_WGS, st));
     // weight gradients
     ICZ_TRY(tn(dG + (size_t)B * 4 * H, 4 * H, 4 * H, temb, E, E, TB, G.w_ih, E, 0, st));
