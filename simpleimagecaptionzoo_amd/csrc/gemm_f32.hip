@@ -316,6 +316,272 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// NT with split-precision operands ("x3"): C = X W^T for the skinny decoder-step shapes (M <= 64 rows per tile).
+// gfx950 runs fp32-input MFMA at the vector rate (1/16 of bf16), and at 64 rows these GEMMs wait on the matrix pipe, not on
+// memory.  Here every fp32 operand is cut into three bf16 pieces, x = x0 + x1 + x2 (each the bf16 rounding of what the
+// previous ones left: 3 x 8 = 24 mantissa bits, the pieces are exact, the remainder is below 2^-24 |x|), and a product is
+// the six piece products of order <= 2,
+//     x w  ~=  x0 w0 + (x0 w1 + x1 w0) + (x1 w1 + x0 w2 + x2 w0),       dropped: x1 w2 + x2 w1 + x2 w2 <= 3 * 2^-24 |x w|,
+// accumulated in fp32 by v_mfma_f32_32x32x16_bf16: six bf16 MFMAs do the work of sixteen fp32 ones.  The weights stay fp32
+// in memory (same bytes as before) and are split in registers on their way to the matrix pipe (VALU work in the shadow of
+// the MFMAs); the activation tile is split once per stage when it is staged into LDS.  Operands must be finite.
+// MEASURED (round 1), hence opt-in (ICZ_GEMM_X3=1): results stay inside every parity bound of the GPU suite (token-exact
+// decodes, 2e-4 gradients), the matrix work of a 128-deep stage drops from 1.86 to 0.64 us -- and the stage still takes
+// 2.1 us (fp32 kernel: 1.9-2.4): without its MFMAs the kernel runs at 1.3-1.5 us per stage, i.e. the weight stream with one
+// stage of loads in flight per wave is now the limit (6.4 TB/s at best), and the two do not overlap at one wave per SIMD.
+// Three stages in flight (256 VGPRs, ring partly in AGPRs: 2.3-2.9 us) and two workgroups per CU on one LDS buffer (52 KB)
+// were slower or equal in the SCST step: 8.2-8.7 k captions/s against 8.6 k for the fp32 kernel.
+// Workgroup = 64 rows x 64 columns; wave (cg, kh): columns 32 cg .. 32 cg + 31, k half kh of every 128-deep stage; the two
+// k halves meet in LDS at the end.  Operand maps (32x32x16 bf16): lane (r = lane & 31, h = lane >> 5) holds A[row r][8h+j],
+// B[8h+j][col r], j = 0..7;  C: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
+typedef __attribute__((ext_vector_type(2))) uint32_t u32x2;
+
+__device__ __forceinline__ uint32_t cvt_pk_bf16(float lo, float hi) {
+    uint32_t r;
+    asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
+    return r;
+}
+// (a, b) -> three packed bf16 pairs (a in the low half)
+__device__ __forceinline__ void split3(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = cvt_pk_bf16(a, b);
+    float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = cvt_pk_bf16(ra, rb);
+    ra -= __uint_as_float(p1 << 16);
+    rb -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = cvt_pk_bf16(ra, rb);
+}
+
+constexpr int X3_BK = 128, X3_PB = X3_BK + 8;                   // bf16 elements per staged activation row (272 B: 17 x 16 B)
+#ifndef ICZ_X3_NBUF
+#define ICZ_X3_NBUF 2
+#endif
+constexpr int X3_NBUF = ICZ_X3_NBUF;                            // staging buffers (1: 52 KB, two workgroups per CU)
+constexpr size_t X3_LDS = (size_t)X3_NBUF * 3 * 64 * X3_PB * 2;      // buffers x three planes x 64 rows
+
+__global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
+    unsigned short* const planes = reinterpret_cast<unsigned short*>(x3_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int cg = wave & 1, kh = wave >> 1, r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, z = blockIdx.z;
+    int tot = 0;
+#pragma unroll
+    for (int s = 0; s < GEMM_MAX_SEG; ++s)
+        if (s < a.nseg) tot += a.seg[s].K / X3_BK;
+    const int c_begin = z * a.chunks_per_split;
+    const int c_end = min(tot, c_begin + a.chunks_per_split);
+    const int ncol = n0 + 32 * cg + r;
+    const size_t ncol_c = ncol < a.N ? ncol : a.N - 1;
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
+
+    // activation staging: 64 rows x 32 float4 = 8 float4 per thread and stage
+    constexpr int XL = 8;
+    f32x4 xr[XL];
+    size_t xrow[XL];
+    int xkk[XL], xlds[XL];
+#pragma unroll
+    for (int j = 0; j < XL; ++j) {
+        const int idx = tid + 256 * j, row = idx >> 5;
+        int m = m0 + row;
+        if (m > a.M - 1) m = a.M - 1;
+        xrow[j] = (size_t)m;
+        xkk[j] = 4 * (idx & 31);
+        xlds[j] = row * X3_PB + xkk[j];
+    }
+    // two stage cursors: the activation loads run one stage ahead of the MFMAs, the weight loads three (a stage is 0.64 us
+    // of matrix work: one stage of loads in flight does not cover the memory latency)
+    struct Cur { int seg, k0, segK; };
+    Cur cx = {0, 0, 0}, cw = {0, 0, 0};
+    const float* wp = nullptr;
+    const float* xp[XL];
+    auto seek = [&](Cur& c, int stage) {
+        int q = stage;
+        c.seg = 0;
+#pragma unroll
+        for (int s = 0; s < GEMM_MAX_SEG - 1; ++s) {
+            if (c.seg == s && s < a.nseg - 1) {
+                const int nst = a.seg[s].K / X3_BK;
+                if (q >= nst) { q -= nst; c.seg = s + 1; }
+            }
+        }
+        c.k0 = q * X3_BK;
+        c.segK = a.seg[c.seg].K;
+    };
+    auto point_w = [&]() { const GemmSeg& g = a.seg[cw.seg]; wp = g.B + ncol_c * g.ldb + cw.k0 + 64 * kh + 8 * h; };
+    auto point_x = [&]() {
+        const GemmSeg& g = a.seg[cx.seg];
+#pragma unroll
+        for (int j = 0; j < XL; ++j) xp[j] = g.A + xrow[j] * g.lda + cx.k0 + xkk[j];
+    };
+    auto advance_w = [&]() {
+        cw.k0 += X3_BK;
+        if (cw.k0 >= cw.segK && cw.seg < a.nseg - 1) { ++cw.seg; cw.k0 = 0; cw.segK = a.seg[cw.seg].K; point_w(); }
+        else wp += X3_BK;
+    };
+    auto advance_x = [&]() {
+        cx.k0 += X3_BK;
+        if (cx.k0 >= cx.segK && cx.seg < a.nseg - 1) { ++cx.seg; cx.k0 = 0; cx.segK = a.seg[cx.seg].K; point_x(); }
+        else {
+#pragma unroll
+            for (int j = 0; j < XL; ++j) xp[j] += X3_BK;
+        }
+    };
+    auto load_x = [&]() {
+#pragma unroll
+        for (int j = 0; j < XL; ++j) xr[j] = *reinterpret_cast<const f32x4*>(xp[j]);
+    };
+    auto load_w = [&](f32x4 (&w)[4][2]) {
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            w[b][0] = *reinterpret_cast<const f32x4*>(wp + 16 * b);
+            w[b][1] = *reinterpret_cast<const f32x4*>(wp + 16 * b + 4);
+        }
+    };
+    auto store_stage = [&](int buf) {
+        unsigned short* base = planes + (size_t)buf * 3 * 64 * X3_PB;
+#pragma unroll
+        for (int j = 0; j < XL; ++j) {
+            uint32_t a0, a1, a2, b0, b1, b2;
+            split3(xr[j][0], xr[j][1], a0, a1, a2);
+            split3(xr[j][2], xr[j][3], b0, b1, b2);
+            *reinterpret_cast<u32x2*>(base + xlds[j]) = (u32x2){a0, b0};
+            *reinterpret_cast<u32x2*>(base + 64 * X3_PB + xlds[j]) = (u32x2){a1, b1};
+            *reinterpret_cast<u32x2*>(base + 2 * 64 * X3_PB + xlds[j]) = (u32x2){a2, b2};
+        }
+    };
+    // One 128-deep stage of this wave's k half: 4 blocks of 16.  The LDS fragments of block b + 1 are read before the MFMAs
+    // of block b (register double buffer) and, when `wnext` is given, the next stage's weight loads go out one block at a
+    // time between the MFMA groups: issued in one burst at the top of the stage they put 256 x 32 KB on the fabric at once
+    // and then leave it idle while the matrix pipe runs (memory time and MFMA time add up, see gemm_nt_kernel).
+    auto compute = [&](int buf, const f32x4 (&w)[4][2], f32x4 (&wnext)[4][2], bool do_load) {
+        const unsigned short* base = planes + (size_t)buf * 3 * 64 * X3_PB + r * X3_PB + 64 * kh + 8 * h;
+        bf16x8 xf[2][3][2];
+#pragma unroll
+        for (int p = 0; p < 3; ++p)
+#pragma unroll
+            for (int i = 0; i < 2; ++i) xf[0][p][i] = *reinterpret_cast<const bf16x8*>(base + p * 64 * X3_PB + i * 32 * X3_PB);
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+            if (b < 3) {
+#pragma unroll
+                for (int p = 0; p < 3; ++p)
+#pragma unroll
+                    for (int i = 0; i < 2; ++i)
+                        xf[(b + 1) & 1][p][i] = *reinterpret_cast<const bf16x8*>(base + p * 64 * X3_PB + i * 32 * X3_PB + 16 * (b + 1));
+            }
+            if (do_load) {
+                wnext[b][0] = *reinterpret_cast<const f32x4*>(wp + 16 * b);
+                wnext[b][1] = *reinterpret_cast<const f32x4*>(wp + 16 * b + 4);
+            }
+            uint32_t s0[4], s1[4], s2[4];
+            split3(w[b][0][0], w[b][0][1], s0[0], s1[0], s2[0]);
+            split3(w[b][0][2], w[b][0][3], s0[1], s1[1], s2[1]);
+            split3(w[b][1][0], w[b][1][1], s0[2], s1[2], s2[2]);
+            split3(w[b][1][2], w[b][1][3], s0[3], s1[3], s2[3]);
+            const u32x4 q0 = {s0[0], s0[1], s0[2], s0[3]}, q1 = {s1[0], s1[1], s1[2], s1[3]}, q2 = {s2[0], s2[1], s2[2], s2[3]};
+            const bf16x8 w0 = __builtin_bit_cast(bf16x8, q0), w1 = __builtin_bit_cast(bf16x8, q1), w2 = __builtin_bit_cast(bf16x8, q2);
+            __builtin_amdgcn_sched_barrier(0);
+            {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) {       // smallest terms first
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][2][i], w0, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w2, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][1][i], w1, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][1][i], w0, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w1, acc[i], 0, 0, 0);
+                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w0, acc[i], 0, 0, 0);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    };
+
+    const int n = c_end - c_begin;
+    // weight register ring of depth WD: stage i multiplies w[i % WD] and loads stage i + WD - 1 into w[(i + WD - 1) % WD].
+    // Depth 4 (three stages ahead) was measured slower than depth 2: at 256 VGPRs the ring lives partly in AGPRs.
+    constexpr int WD = 2;
+    f32x4 w0[4][2], w1[4][2], w2[4][2], w3[4][2];
+    if (n > 0) {
+        seek(cx, c_begin);
+        seek(cw, c_begin);
+        point_x();
+        point_w();
+        load_x();
+        load_w(w0);
+        if (WD == 4) {
+            if (n > 1) { advance_w(); load_w(w1); }
+            if (n > 2) { advance_w(); load_w(w2); }
+        }
+        store_stage(0);
+        __syncthreads();
+        // stage idx: X(idx + 1) is loaded at its top and stored at its end; W(idx + WD - 1) is loaded between its MFMA groups
+        auto stage = [&](int buf, const f32x4 (&wuse)[4][2], f32x4 (&wload)[4][2], int idx) {
+            const bool nx = idx + 1 < n, nw = idx + WD - 1 < n;
+            if (nx) { advance_x(); load_x(); }
+            if (nw) advance_w();
+            __builtin_amdgcn_sched_barrier(0);
+            compute(X3_NBUF == 2 ? buf : 0, wuse, wload, nw);
+            if (X3_NBUF == 1) __syncthreads();
+            if (nx) store_stage(X3_NBUF == 2 ? (buf ^ 1) : 0);
+            __syncthreads();
+        };
+        int i = 0;
+        if (WD == 4) {
+            for (; i + 4 <= n; i += 4) {
+                stage(0, w0, w3, i);
+                stage(1, w1, w0, i + 1);
+                stage(0, w2, w1, i + 2);
+                stage(1, w3, w2, i + 3);
+            }
+            if (i < n) stage(0, w0, w3, i);
+            if (i + 1 < n) stage(1, w1, w0, i + 1);
+            if (i + 2 < n) stage(0, w2, w1, i + 2);
+        } else {
+            for (; i + 2 <= n; i += 2) {
+                stage(0, w0, w1, i);
+                stage(1, w1, w0, i + 1);
+            }
+            if (i < n) stage(0, w0, w1, i);
+        }
+    }
+    // the two k halves meet in LDS (the staging buffers are free now): waves kh = 1 hand their tiles to waves kh = 0
+    __syncthreads();
+    float* red = reinterpret_cast<float*>(x3_smem) + cg * 64 * 32;
+    if (kh == 1) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) red[(32 * i + (q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = acc[i][q];
+    }
+    __syncthreads();
+    if (kh == 0 && ncol < a.N) {
+        const bool direct = a.nsplit == 1;
+        const float bias = (direct && a.bias) ? a.bias[ncol] : 0.f;
+        float* out = direct ? a.out : a.out + (size_t)z * a.M * a.N;
+        const int ldo = direct ? a.ldo : a.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h, m = m0 + row;
+                if (m < a.M) {
+                    float* o = out + (size_t)m * ldo + ncol;
+                    const float v = acc[i][q] + red[row * 32 + r] + bias;
+                    *o = (direct && a.accumulate) ? (*o + v) : v;
+                }
+            }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // NN: C = dY W   (A(m,k) = dY[m*lda+k], B(k,n) = W[k*ldb+n]).
 // Mirror image of NT: the B chunk (64 k x 64 n, shared by the 4 waves) goes through LDS, each wave owns 16
 // rows and all 64 columns; A fragments straight to registers.  Column tiles are interleaved: a lane's
@@ -682,6 +948,20 @@ static bool nt_spread(const GemmArgs& a) {
     // measured: -9.5 % at M = 64, -3 % at M = 2304 (refiner / prologue GEMMs), +4 % at M = 320 (beam rows)
     return force != 0 && (a.M <= 64 || a.M >= 1024);
 }
+// split-precision kernel (gemm_nt_x3_kernel) for the skinny shapes: OFF unless ICZ_GEMM_X3=1 (measured: same results within
+// the parity bounds -- the whole GPU suite passes with it -- but no faster in the SCST step, see the kernel's header);
+// ICZ_GEMM_X3_MAXM widens / narrows the row range
+static bool nt_x3(const GemmArgs& a) {
+    static int on = -1, maxm = 64;
+    if (on < 0) {
+        const char* e = getenv("ICZ_GEMM_X3"); on = e ? atoi(e) : 0;
+        const char* m = getenv("ICZ_GEMM_X3_MAXM"); if (m) maxm = atoi(m);
+    }
+    if (!on || a.M <= 32 || a.M > maxm) return false;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % 128) return false;
+    return true;
+}
 static int nt_waves(const GemmArgs& a) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_GEMM_NW"); force = e ? atoi(e) : 0; }
@@ -693,6 +973,7 @@ static int nt_waves(const GemmArgs& a) {
 static int nt_tile_n(const GemmArgs& a) { return 16 * nt_waves(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
+    if (X3_NBUF == 1 && layout == GEMM_NT && a.M > 32 && nt_x3(a)) target_wgs *= 2;       // two workgroups of the split-precision kernel per CU
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
     int tot = total_chunks(a, stage_k(layout, a));
     int s = target_wgs / (tiles > 0 ? tiles : 1);
@@ -785,7 +1066,15 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         }
 #define ICZ_NT(MT_, NTW_, BK_) do { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, true, BK_>), grid, block, 0, stream, a); \
                                     else hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, false, BK_>), grid, block, 0, stream, a); } while (0)
-        if (mt == 1) ICZ_NT(1, 1, 64);
+        if (mt == 4 && nt_x3(a)) {
+            static bool attr_done = false;
+            if (!attr_done) {
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS));
+                attr_done = true;
+            }
+            hipLaunchKernelGGL(gemm_nt_x3_kernel, grid, block, X3_LDS, stream, a);
+        }
+        else if (mt == 1) ICZ_NT(1, 1, 64);
         else if (mt == 2) ICZ_NT(2, 1, 64);
         else if (nt_stage_k(a) == 128 && nt_waves(a) == 8) {
             hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 8>), grid, dim3(512), 0, stream, a);

@@ -316,3 +316,25 @@ def test_random_shapes_match_oracle(cfg):
         want = p[k].grad.numpy()
         scale = max(1e-6, float(np.abs(want).max()))
         assert np.abs(gr.cpu().numpy() - want).max() <= 3e-4 * scale + 1e-7, (k, cfg)
+
+
+def test_split_precision_gemm_option_matches_float64():
+    """ICZ_GEMM_X3=1 selects the bf16 x 3-plane split-precision NT kernel (opt-in, csrc/gemm_f32.hip): against a float64
+    product its error stays at the fp32 kernel's level.  The switch is read once per process, hence the child process."""
+    import subprocess
+    import sys
+    code = r'''
+import torch
+from simpleimagecaptionzoo_amd.butd import gemm
+torch.manual_seed(0)
+for M, N, K, ns in ((64, 4096, 3072, 4), (64, 1024, 1024, 8), (48, 640, 2048, 1), (64, 10102, 1024, 1)):
+    X = torch.randn(M, K, device="cuda"); W = torch.randn(N, K, device="cuda") * 0.05
+    got = gemm("nt", X, W, None, ns).double()
+    want = X.double() @ W.double().t()
+    err = float((got - want).abs().max() / want.abs().max())
+    assert err < 2e-6, (M, N, K, ns, err)
+print("ok")
+'''
+    env = dict(os.environ, ICZ_GEMM_X3="1", PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0 and "ok" in out.stdout, out.stderr[-2000:]
