@@ -105,7 +105,12 @@ def main():
 
     from simpleimagecaptionzoo_amd import dist as icz_dist
     from simpleimagecaptionzoo_amd._lib import lib
-    rank, world, local = icz_dist.init_from_env()
+    # ICZ_REHEARSE_ONE_GPU=1 (development only): every rank on cuda:0 with the gloo backend, to rehearse the N > 1 control
+    # flow (normaliser all-reduce, gradient hook, barriers, rank-0 JSON) on a one-GPU box; the numbers mean nothing then
+    rehearse = os.environ.get("ICZ_REHEARSE_ONE_GPU") == "1"
+    rank, world, local = icz_dist.init_from_env("gloo" if rehearse else None)
+    if rehearse:
+        local = 0
     if args.gpus != world:
         if rank == 0:
             print("warning: --gpus %d but WORLD_SIZE %d; using WORLD_SIZE" % (args.gpus, world), file=sys.stderr)
