@@ -629,11 +629,18 @@ __global__ __launch_bounds__(256) void reinforce_dlogits_kernel(float* __restric
 //   loss_row = sum_v true_v (log true_v - logp_v),  true = 1-s at the target, s/(V-1) elsewhere
 //   dlogits  = (softmax - true) / N_tokens          (KLDiv(log_softmax) backward)
 // One workgroup per row; per-row loss goes to loss_rows (summed later in fixed order).
+// All time steps in one launch: grid (B, T), block (b, t) = row t * B + b of the saved logits, active while b < rows.n[t] (the
+// captions are sorted by decreasing length, Engine.py:178); target = captions[b, t + 1].  One launch per step left the chip
+// to at most B workgroups seventeen times per XE step.
+constexpr int XE_MAX_T = 128;
+struct XeRows { int n[XE_MAX_T]; };
 __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict__ logits, int V, int ldl,
-                                                              const int64_t* __restrict__ target, int tgt_stride,
+                                                              const int64_t* __restrict__ captions, int L, int B, XeRows rows,
                                                               float smoothing, float inv_n, float* __restrict__ loss_rows) {
     __shared__ float smf[4];
-    const int row = blockIdx.x, tid = threadIdx.x;
+    const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
+    if (b >= rows.n[t]) return;
+    const int row = t * B + b;
     float* l = logits + (size_t)row * ldl;
     float mx = -INFINITY;
     for (int v = tid; v < V; v += 256) mx = fmaxf(mx, l[v]);
@@ -642,7 +649,7 @@ __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict_
     for (int v = tid; v < V; v += 256) se += expf(l[v] - mx);
     se = block_sum_256(se, smf);
     const float lse = mx + logf(se);
-    const int tg = (int)target[(size_t)row * tgt_stride];
+    const int tg = (int)captions[(size_t)b * L + t + 1];
     const float conf = 1.f - smoothing, low = smoothing / (float)(V - 1);
     const float lconf = conf > 0.f ? logf(conf) : 0.f, llow = low > 0.f ? logf(low) : 0.f;
     float ls = 0.f;
@@ -1022,22 +1029,25 @@ __global__ __launch_bounds__(256) void timesum_kernel(const float* __restrict__ 
 // ---------------------------------------------------------------------------------------------------------
 // Embedding gradient (Embedding -> ReLU -> Dropout backward):
 //   dE[v,:] = sum over (t,b) with tok[t,b] == v of demb[t,b,:] * (emb[t,b,:] > 0 ? scale : 0)
-// No atomics: a workgroup takes 8 vocabulary rows (two per wave); the (t,b) token list is loaded into LDS once per workgroup,
-// each wave finds the occurrences of its row by ballot in list order and adds their rows in that order; rows without
-// occurrences (almost all of them) are written as zeros.
+// No atomics: a workgroup takes 8 vocabulary rows.  The (t,b) token list is loaded into LDS once per workgroup and each wave
+// finds the occurrences of two of the rows by ballot, in list order.  Then wave w adds the rows' occurrences for the columns
+// 256 w .. 256 w + 255 (+ 1024 k), in list order, eight occurrences' loads in flight: the kernel lasts as long as its most
+// frequent token (<sta> once per caption; in XE batches the most frequent word), so its chain of dependent loads is what to
+// keep short.  Rows without occurrences (almost all of them) are written as zeros.
 constexpr int EG_ROWS = 8;
 __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, int n_tok,
                                                          const float* __restrict__ demb, int ns, size_t slab_stride,
                                                          const float* __restrict__ emb, float scale, int E,
                                                          float* __restrict__ dE, int V, int relu) {
-    extern __shared__ int eg_sm[];     // tokens [n_tok], then per wave the indices of its row's occurrences [4][n_tok]
+    extern __shared__ int eg_sm[];     // tokens [n_tok], then the occurrence lists of the eight rows [8][n_tok]
+    __shared__ int snh[EG_ROWS];
     int* stok = eg_sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    int* hits = eg_sm + n_tok + wave * n_tok;
     for (int i = tid; i < n_tok; i += 256) stok[i] = (int)tok[i];
     __syncthreads();
     for (int rr = 0; rr < EG_ROWS / 4; ++rr) {
-        const int v = blockIdx.x * EG_ROWS + wave + 4 * rr;
+        const int row8 = wave + 4 * rr, v = blockIdx.x * EG_ROWS + row8;
+        int* hits = eg_sm + n_tok + row8 * n_tok;
         int nh = 0;
         for (int i0 = 0; i0 < n_tok; i0 += 64) {
             const int i = i0 + lane;
@@ -1046,47 +1056,39 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restri
             if (m) hits[nh + __popcll(bal & ((1ull << lane) - 1ull))] = i;
             nh += __popcll(bal);
         }
-        __syncthreads();
-        if (v < V) {
-            // the kernel lasts as long as its most frequent token (<sta> occurs once per caption): four occurrences x four
-            // 256-column strips of loads are in flight at a time; the additions stay in list order
-            for (int e0 = lane * 4; e0 < E; e0 += 1024) {
-                f32x4 s[4];
+        if (lane == 0) snh[row8] = nh;
+    }
+    __syncthreads();
+    for (int row8 = 0; row8 < EG_ROWS; ++row8) {
+        const int v = blockIdx.x * EG_ROWS + row8;
+        if (v >= V) break;
+        const int nh = snh[row8];
+        const int* hits = eg_sm + n_tok + row8 * n_tok;
+        for (int e = 256 * wave + lane * 4; e < E; e += 1024) {
+            f32x4 s = {0.f, 0.f, 0.f, 0.f};
+            for (int h0 = 0; h0 < nh; h0 += 8) {
+                f32x4 g[8], x[8];
 #pragma unroll
-                for (int q = 0; q < 4; ++q) s[q] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                for (int h0 = 0; h0 < nh; h0 += 4) {
-                    f32x4 g[4][4], x[4][4];
-#pragma unroll
-                    for (int u = 0; u < 4; ++u) {
-                        const size_t base = (size_t)hits[min(h0 + u, nh - 1)] * E;
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const size_t off = base + min(e0 + 256 * q, E - 4);
-                            g[u][q] = sum_slabs4(demb, ns, slab_stride, off);
-                            if (relu) x[u][q] = *reinterpret_cast<const f32x4*>(emb + off);
-                        }
-                    }
-#pragma unroll
-                    for (int u = 0; u < 4; ++u)
-                        if (h0 + u < nh) {
-#pragma unroll
-                            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                                for (int j = 0; j < 4; ++j) s[q][j] += (!relu || x[u][q][j] > 0.f) ? g[u][q][j] * scale : 0.f;
-                        }
+                for (int u = 0; u < 8; ++u) {
+                    const size_t off = (size_t)hits[min(h0 + u, nh - 1)] * E + e;
+                    g[u] = sum_slabs4(demb, ns, slab_stride, off);
+                    if (relu) x[u] = *reinterpret_cast<const f32x4*>(emb + off);
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (e0 + 256 * q < E) *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e0 + 256 * q) = s[q];
+                for (int u = 0; u < 8; ++u)
+                    if (h0 + u < nh) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) s[j] += (!relu || x[u][j] > 0.f) ? g[u][j] * scale : 0.f;
+                    }
             }
+            *reinterpret_cast<f32x4*>(dE + (size_t)v * E + e) = s;
         }
-        __syncthreads();
     }
 }
 // host side: grid, LDS size (above the 64 KB default the kernel needs the explicit opt-in)
 inline hipError_t embed_grad_launch(hipStream_t st, const int64_t* tok, int n_tok, const float* demb, int ns, size_t slab_stride,
                                     const float* emb, float scale, int E, float* dE, int V, int relu) {
-    const size_t lds = sizeof(int) * 5 * (size_t)n_tok;
+    const size_t lds = sizeof(int) * (1 + EG_ROWS) * (size_t)n_tok;
     if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(embed_grad_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);

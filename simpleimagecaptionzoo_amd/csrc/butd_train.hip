@@ -364,10 +364,12 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
     const int Vp = round4(dims.V);
     const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
     ICZ_CHECK_HIP(hipMemsetAsync(tb.loss_rows, 0, sizeof(float) * T * B, st));
-    for (int t = 0; t < T; ++t) {
-        // targets: captions[b, t+1]
-        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(rows_t[t]), dim3(256), 0, st, tb.logit + (size_t)t * B * Vp, dims.V, Vp,
-                           cur_captions + (t + 1), cur_L, smoothing, 1.0f / n, tb.loss_rows + (size_t)t * B);
+    {
+        ICZ_REQUIRE(T <= XE_MAX_T, "xe_backward: %d steps exceed %d", T, XE_MAX_T);
+        XeRows xr = {};
+        for (int t = 0; t < T; ++t) xr.n[t] = rows_t[t];
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tb.logit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n,
+                           tb.loss_rows);
     }
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, loss_out);
     ICZ_CHECK_HIP(hipGetLastError());
