@@ -162,7 +162,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     const int rows = s.rows, Hd = dims.Hd, E = dims.E, NH = dims.NH, R = cur_R, dh = Hd / NH;
     const unsigned eb = (unsigned)(((size_t)rows * Hd + 255) / 256);
     if (!s.emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, s.it, s.emb, rows, E, s.d_emb, 1);
-    hipLaunchKernelGGL(aoa_u_kernel, dim3(eb), dim3(256), 0, st, meanf, s.img_of_row, s.ctx_in, s.u, rows, Hd, s.d_ctx);
+    if (!s.u_ready) hipLaunchKernelGGL(aoa_u_kernel, dim3(eb), dim3(256), 0, st, meanf, s.img_of_row, s.ctx_in, s.u, rows, Hd, s.d_ctx);
     GemmArgs g = {};
     g.nseg = 3;
     g.seg[0] = {s.emb, P.lstm_w_ih, E, E + Hd, E, nullptr};
@@ -188,7 +188,8 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     zg.nsplit = gemm_pick_split(zg, STEP_WGS);
     ICZ_REQUIRE(gemm_slab_floats(zg.M, zg.N, zg.nsplit) <= ws_floats, "aoa: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
-    hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out);
+    hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out,
+                       (const float*)meanf, s.img_of_row, s.u_next, s.d_ctx_next);
     GemmArgs p = {};
     p.nseg = 1;
     p.seg[0] = {s.ctxdrop, w_pred, Hd, Hd, Hd, nullptr};
@@ -229,6 +230,8 @@ int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
     for (int t = 0; t < T; ++t) {
         AoaStepIO s = scratch_io(*this, B, nullptr, cur);
         s.emb_ready = t > 0;
+        s.u_ready = t > 0;                       // left by the previous step's GLU kernel (evaluation mode: no dropout)
+        if (t + 1 < T) { s.u_next = u; s.d_ctx_next = s.d_ctx; }
         ICZ_TRY(step(s, st));
         hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
         hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,

@@ -28,6 +28,9 @@ struct AoaStepIO {
     float *emb, *u, *gates_out, *ln_stats, *qn, *Qp, *P_out, *Pd_out, *xatt, *z_out, *ctxdrop, *logits;
     DropCfg d_emb;                   // embedding dropout (p = 0.5) through the BUTD embedding kernel
     DropP d_ctx, d_att, d_out;
+    bool u_ready;                    // s.u was written by the previous step's GLU kernel (skip aoa_u_kernel)
+    float* u_next;                   // where this step's GLU kernel leaves the next step's u (null: it does not)
+    DropP d_ctx_next;                // the next step's ctx dropout
 };
 
 struct Aoa {

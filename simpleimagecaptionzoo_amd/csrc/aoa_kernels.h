@@ -386,10 +386,14 @@ __global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restri
     }
 }
 
-// Decoder GLU (no residual): ctx = z[:, :Hd] * sigmoid(z[:, Hd:]);  ctxdrop = drop(ctx, 0.5) for `predict`
+// Decoder GLU (no residual): ctx = z[:, :Hd] * sigmoid(z[:, Hd:]);  ctxdrop = drop(ctx, 0.5) for `predict`.  Optionally also
+// the next step's LSTM input u_next = mean_feat[img] + drop(ctx, 0.5) with THAT step's dropout stream (aoa_u_kernel of step
+// t + 1, AoA_Model.py:321-323): the chains that feed ctx straight into the next step (greedy, sampled, teacher-forced) save a
+// launch per step; beam search re-gathers ctx by source beam first and keeps aoa_u_kernel.
 __global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ zslab, int ns, const float* __restrict__ zbias,
                                                       float* __restrict__ z_out, float* __restrict__ ctx, float* __restrict__ ctxdrop,
-                                                      int rows, int Hd, DropP dp) {
+                                                      int rows, int Hd, DropP dp, const float* __restrict__ meanf,
+                                                      const int32_t* __restrict__ img_of_row, float* __restrict__ u_next, DropP dp_u) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * Hd) return;
     const size_t row = i / Hd;
@@ -401,6 +405,10 @@ __global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ 
     const float y = a * sigmoidf_(b);
     ctx[i] = y;
     ctxdrop[i] = dp.apply(y, i);
+    if (u_next) {
+        const int img = img_of_row ? img_of_row[row] : (int)row;
+        u_next[i] = meanf[(size_t)img * Hd + c] + dp_u.apply(y, i);
+    }
 }
 
 // mean over the (valid) regions of an image  (AoA_Model.py:250-253)

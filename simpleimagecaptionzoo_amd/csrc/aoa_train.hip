@@ -292,13 +292,21 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, tok, (int64_t)1, B);
     for (int t = 0; t < T; ++t) {
         const size_t slot = (size_t)t * B;
-        ICZ_TRY(step(train_io(B, t, true), st));
+        AoaStepIO io = train_io(B, t, true);
+        io.emb_ready = t > 0;           // written by the previous step's sample_select_kernel
+        io.u_ready = t > 0;             // written by the previous step's GLU kernel
+        if (t + 1 < T) { const AoaStepIO nx = train_io(B, t + 1, true); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
+        ICZ_TRY(step(io, st));
         SampleSelArgs a = {};
         a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
         a.uniforms = rng.uniforms ? rng.uniforms + slot : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = unf; a.n_unfinished = nunf; a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tok + slot + B; a.draw_out = draw + slot; a.lse_out = lse + slot;
+        if (t + 1 < T) {                // the next step's input embedding (its slot, its dropout stream), fused
+            a.emb_table = P.embed_weight; a.emb_next = temb + (slot + B) * dims.E; a.E = dims.E;
+            a.emb_drop = dropbits(true, rng.emb_mask, (slot + B) * dims.E, RNG_EMB, t + 1);
+        }
         hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
@@ -365,7 +373,12 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
     ICZ_CHECK_HIP(hipMemsetAsync(tctx, 0, sizeof(float) * sH, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tlogit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(aoa_captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tok);
-    for (int t = 0; t < T; ++t) ICZ_TRY(step(train_io(rows_t[t], t, cur_train), st));
+    for (int t = 0; t < T; ++t) {
+        AoaStepIO io = train_io(rows_t[t], t, cur_train);
+        io.u_ready = t > 0;             // the next step's rows are a prefix of this step's: its u comes from this step's GLU kernel
+        if (t + 1 < T) { const AoaStepIO nx = train_io(rows_t[t + 1], t + 1, cur_train); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
+        ICZ_TRY(step(io, st));
+    }
     if (packed_out) {
         std::vector<int> hostv(2 * T);
         int acc = 0;
