@@ -61,6 +61,62 @@ def make_batches(n, B, words, device, rank):
     return batches
 
 
+def secondary(eng, opt, words, device, B):
+    """The other rates SURVEY.md 8d lists next to the headline metric, on the same engine and model size (N = 1, a few
+    hundred ms each): XE training step (Engine.training_epoch), greedy and beam-5 decode (eval_captions_json_generation's
+    decoders; BASELINE config 3 quotes beam 5 at batch 128)."""
+    import time as _t
+    out = {}
+    rs = np.random.RandomState(0)
+    Vn = len(words)
+    xb = []
+    for i in range(2):
+        lens = sorted(rs.randint(9, 19, size=B).tolist(), reverse=True)        # caption lengths incl. <sta>/<end>
+        caps = torch.zeros(B, max(lens), dtype=torch.int64)
+        for b, n in enumerate(lens):
+            caps[b, 0] = 1
+            caps[b, 1:n - 1] = torch.from_numpy(rs.randint(4, Vn, size=n - 2))
+            caps[b, n - 1] = 2
+        feats = torch.relu(torch.randn(B, R, D, device=device))
+        xb.append((tuple(range(B)), None, caps, lens, {"bu_feats": feats}))
+
+    class _Crit:
+        smoothing = 0.1
+
+    def xe(n):
+        eng.training_epoch([xb[i % 2] for i in range(n)], opt, _Crit(), tqdm_visible=False)
+    xe(3)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    xe(10)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / 10
+    out["xe_step"] = {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B,
+                      "note": "Engine.training_epoch, captions of 9..18 tokens, label smoothing 0.1"}
+    # decoding on freshly initialised weights (the trained-for-a-few-steps ones above may or may not emit <end>: the beam
+    # search stops early when every beam has finished, which would make the number depend on the training state)
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    h = ButdHandle(R, D, H, E, A, V, 5 * B, 20)
+    h.bind(random_butd_params(R, D, H, E, A, V, device, seed=1234))
+    h.enable_graphs(True)
+    with torch.cuda.stream(eng.stream):
+        f64 = torch.relu(torch.randn(B, R, D, device=device))
+        for name, fn, nimg in (("greedy", lambda: h.greedy(f64, 20), B), ("beam5", lambda: h.beam_search(f64, 5, 20), B)):
+            for _ in range(3):
+                fn()
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(10):
+                fn()
+            torch.cuda.synchronize()
+            dt = (_t.perf_counter() - t0) / 10
+            out[name] = {"captions_per_s": nimg / dt, "ms": dt * 1e3, "batch": nimg, "steps": 20}
+        out["beam5"]["note"] = "beam 5 = 5 decoder rows per image; random-init weights do not emit <end>, so all 20 steps run"
+    h.close()
+    return out
+
+
 def cpu_baseline(words, rows=8):
     """One SCST step of the CPU oracle (port of the reference path) at full model size on `rows` images."""
     from oracle import butd as ob
@@ -231,6 +287,13 @@ def main():
     }
     if pcie:
         out["pcie_inclusive"] = pcie
+    if world == 1 and not args.no_h2d:
+        try:
+            eng.use_graphs = True
+            eng._hot_handle().set_concurrent(True)
+            out["secondary"] = secondary(eng, opt, words, device, B)
+        except Exception as e:      # the headline line must not depend on the extras
+            out["secondary"] = {"error": repr(e)}
     if not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(words, args.cpu_rows)
     print(json.dumps(out))
