@@ -294,7 +294,7 @@ def main():
             out["secondary"] = secondary(eng, opt, words, device, B)
         except Exception as e:      # the headline line must not depend on the extras
             out["secondary"] = {"error": repr(e)}
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the N > 1 runs share the host with the other ranks
         out["cpu_baseline"] = cpu_baseline(words, args.cpu_rows)
     print(json.dumps(out))
 
