@@ -894,6 +894,144 @@ __global__ __launch_bounds__(256) void gemm_tn128_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
+// TN, large outputs, split-precision operands (see gemm_nt_x3_kernel for the arithmetic): the weight-gradient GEMMs are
+// matrix-pipe-bound with high operand reuse (128 x 128 tile: every staged element feeds 128 products), which is where six
+// bf16 MFMAs instead of sixteen fp32 ones pay.  Both operands are k-major in memory (A(m,k) = dY[k][m], B(k,n) = X[k][n]);
+// a thread loads eight consecutive k of one column with coalesced dword loads, splits them into three bf16 pieces and
+// writes 16 bytes per piece to an [column][k] LDS image, from which the 32x32x16 fragments (8 consecutive k of one row /
+// column) are plain 16-byte reads.  Wave (wr, wc) owns the 64 x 64 quadrant = 2 x 2 tiles of 32 x 32.
+constexpr int T3_KC = 32, T3_PB = T3_KC + 8;                       // bf16 per LDS row: 80 bytes, 5 x 16 B (odd: conflict-free rows)
+constexpr size_t T3_PLANE = (size_t)128 * T3_PB;                  // bf16 elements of one piece of one operand tile
+constexpr size_t t3_lds(int nbuf) { return (size_t)nbuf * 2 * 3 * T3_PLANE * 2; }      // buffers x operands x pieces, bytes
+
+// NBUF = 1: 60 KB of LDS, two workgroups per CU cover each other's barriers and waits (outputs of more than 256 tiles);
+// NBUF = 2: double-buffered stages for the one-round shapes.  NW = 4: wave (wr, wc) owns a 64 x 64 quadrant; NW = 8: a
+// 64 x 32 half quadrant (two waves per SIMD inside the workgroup).
+template <int NBUF, int NW>
+__global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
+    unsigned short* const lds = reinterpret_cast<unsigned short*>(t3_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    constexpr int NT = 64 * NW, NU = NW == 4 ? 2 : 1, IPT = 512 / NT;       // column tiles per wave; staging items per thread and operand
+    const int mbase = NW == 4 ? 64 * (wave >> 1) : 64 * (wave >> 2), nbase = NW == 4 ? 64 * (wave & 1) : 32 * (wave & 3);
+    const GemmSeg& g = a.seg[0];
+    const int nst = g.K / T3_KC;
+
+    f32x16 acc[2][NU];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int q = 0; q < 16; ++q) acc[i][u][q] = 0.f;
+
+    // staging: item = tid + NT j -> k block kb = item >> 7 (8 consecutive k), column c = item & 127
+    const float* ap[IPT];
+    const float* bp[IPT];
+    int so[IPT];
+#pragma unroll
+    for (int j = 0; j < IPT; ++j) {
+        const int item = tid + NT * j, kb = item >> 7, c = item & 127;
+        int mc = m0 + c, nc = n0 + c;
+        if (mc > a.M - 1) mc = a.M - 1;                            // clamped columns feed only never-stored outputs
+        if (nc > a.N - 1) nc = a.N - 1;
+        ap[j] = g.A + (size_t)(8 * kb) * g.lda + mc;
+        bp[j] = g.B + (size_t)(8 * kb) * g.ldb + nc;
+        so[j] = c * T3_PB + 8 * kb;
+    }
+    const size_t astep = (size_t)T3_KC * g.lda, bstep = (size_t)T3_KC * g.ldb;
+    // register ring of two stages: iteration st multiplies LDS buffer st & 1, stores stage st + 1 (loaded one iteration
+    // earlier) into the other buffer at its end and issues the loads of stage st + 2 at its top -- a stage is 48 MFMAs
+    // (0.64 us), one stage of loads in flight does not cover the memory latency
+    float ar0[IPT][8], br0[IPT][8], ar1[IPT][8], br1[IPT][8];
+    auto load_stage = [&](float (&ar)[IPT][8], float (&br)[IPT][8]) {
+#pragma unroll
+        for (int j = 0; j < IPT; ++j)
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { ar[j][e] = ap[j][(size_t)e * g.lda]; br[j][e] = bp[j][(size_t)e * g.ldb]; }
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) { ap[j] += astep; bp[j] += bstep; }
+    };
+    auto put = [&](unsigned short* base, const float (&v)[8]) {
+        uint32_t s0[4], s1[4], s2[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split3(v[2 * e], v[2 * e + 1], s0[e], s1[e], s2[e]);
+        *reinterpret_cast<u32x4*>(base) = (u32x4){s0[0], s0[1], s0[2], s0[3]};
+        *reinterpret_cast<u32x4*>(base + T3_PLANE) = (u32x4){s1[0], s1[1], s1[2], s1[3]};
+        *reinterpret_cast<u32x4*>(base + 2 * T3_PLANE) = (u32x4){s2[0], s2[1], s2[2], s2[3]};
+    };
+    auto store_stage = [&](int buf, const float (&ar)[IPT][8], const float (&br)[IPT][8]) {
+        unsigned short* bA = lds + (size_t)buf * 6 * T3_PLANE;
+        unsigned short* bB = bA + 3 * T3_PLANE;
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) { put(bA + so[j], ar[j]); put(bB + so[j], br[j]); }
+    };
+    auto compute = [&](int buf) {
+        const unsigned short* pa = lds + (size_t)buf * 6 * T3_PLANE + (mbase + r) * T3_PB + 8 * h;
+        const unsigned short* pb = lds + (size_t)buf * 6 * T3_PLANE + 3 * T3_PLANE + (nbase + r) * T3_PB + 8 * h;
+#pragma unroll
+        for (int blk = 0; blk < T3_KC / 16; ++blk) {
+            bf16x8 af[3][2], bf[3][NU];
+#pragma unroll
+            for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(pa + p * T3_PLANE + i * 32 * T3_PB + 16 * blk);
+#pragma unroll
+                for (int u = 0; u < NU; ++u) bf[p][u] = *reinterpret_cast<const bf16x8*>(pb + p * T3_PLANE + u * 32 * T3_PB + 16 * blk);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int u = 0; u < NU; ++u) {       // smallest terms first
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][u], acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][u], acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][u], acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][u], acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][u], acc[i][u], 0, 0, 0);
+                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][u], acc[i][u], 0, 0, 0);
+                }
+        }
+    };
+    load_stage(ar0, br0);
+    store_stage(0, ar0, br0);
+    if (nst > 1) load_stage(ar1, br1);
+    __syncthreads();
+    // iteration st (even: registers 0 are free, 1 hold stage st + 1; odd: the other way round)
+    auto iter = [&](int st, float (&arF)[IPT][8], float (&brF)[IPT][8], const float (&arN)[IPT][8], const float (&brN)[IPT][8]) {
+        if (st + 2 < nst) load_stage(arF, brF);
+        __builtin_amdgcn_sched_barrier(0);
+        compute(NBUF == 2 ? (st & 1) : 0);
+        if (NBUF == 1) __syncthreads();          // every wave has read this stage's fragments
+        if (st + 1 < nst) store_stage(NBUF == 2 ? ((st + 1) & 1) : 0, arN, brN);
+        __syncthreads();
+    };
+    int st = 0;
+    for (; st + 2 <= nst; st += 2) {
+        iter(st, ar0, br0, ar1, br1);
+        iter(st + 1, ar1, br1, ar0, br0);
+    }
+    if (st < nst) iter(st, ar0, br0, ar1, br1);
+    // acc[i][u][q] <-> row m0 + mbase + 32 i + (q & 3) + 8 (q >> 2) + 4 h, column n0 + nbase + 32 u + r
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int n = n0 + nbase + 32 * u + r;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int m = m0 + mbase + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
+                if (m < a.M) {
+                    float* o = a.out + (size_t)m * a.ldo + n;
+                    *o = a.accumulate ? (*o + acc[i][u][q]) : acc[i][u][q];
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // Optional timing of every gemm_nt_kernel<4> launch with HIP events on the launch stream (bench.py's live
 // roofline measurement).  Off by default; nothing is recorded or allocated unless enabled.
 struct GemmProf {
@@ -1099,7 +1237,24 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         if (big < 0) { const char* e = getenv("ICZ_GEMM_TN128"); big = e ? atoi(e) : 1; }
         // at least one 128 x 128 tile per CU, else the 64 x 64 kernel (4x the workgroups) fills the chip better
         if (big && a.nsplit == 1 && a.nseg == 1 && cdiv(a.M, 128) * cdiv(a.N, 128) >= 256 && a.seg[0].K % 32 == 0 && a.seg[0].K >= 64) {
-            hipLaunchKernelGGL(gemm_tn128_kernel, dim3(cdiv(a.N, 128), cdiv(a.M, 128), 1), block, 0, stream, a);
+            static int x3 = -1;
+            if (x3 < 0) {
+                const char* e = getenv("ICZ_GEMM_TN_X3"); x3 = e ? atoi(e) : 2;       // 0: fp32-MFMA kernel; 1 / 2 / 3: variants of the split-precision one
+                if (x3) {
+                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));
+                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
+                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
+                }
+            }
+            const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), 1);
+            const int tiles = (int)(g128.x * g128.y);
+            if (x3 == 0) hipLaunchKernelGGL(gemm_tn128_kernel, g128, block, 0, stream, a);
+            // measured (4096 x {1024, 3072, 4096} x 1280, 10112 x 1024 x 1280): more than one round of tiles -> one LDS buffer and
+            // two workgroups per CU (251 us / 171 TFLOP/s-equivalent at 4096 x 4096 against 369 us for the fp32 kernel); one
+            // round -> two buffers and eight waves (73 against 100 us at 4096 x 1024)
+            else if (tiles > 256 && x3 != 3) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4>), g128, block, t3_lds(1), stream, a);
+            else if (x3 == 2 || x3 == 3) hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8>), g128, dim3(512), t3_lds(2), stream, a);
+            else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 4>), g128, block, t3_lds(2), stream, a);
             ICZ_CHECK_HIP(hipGetLastError());
             return ICZ_OK;
         }
