@@ -907,7 +907,9 @@ constexpr size_t t3_lds(int nbuf) { return (size_t)nbuf * 2 * 3 * T3_PLANE * 2; 
 // NBUF = 1: 60 KB of LDS, two workgroups per CU cover each other's barriers and waits (outputs of more than 256 tiles);
 // NBUF = 2: double-buffered stages for the one-round shapes.  NW = 4: wave (wr, wc) owns a 64 x 64 quadrant; NW = 8: a
 // 64 x 32 half quadrant (two waves per SIMD inside the workgroup).
-template <int NBUF, int NW>
+// AROW = false: TN (A(m,k) = A[k lda + m]);  AROW = true: NN (A(m,k) = A[m lda + k], the batched dgrad GEMMs over all time
+// steps): the A tile then comes in as two float4 per thread along k.  blockIdx.z = split-K part (slabs [z][M][N] in a.out).
+template <int NBUF, int NW, bool AROW = false>
 __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
     unsigned short* const lds = reinterpret_cast<unsigned short*>(t3_smem);
@@ -917,7 +919,10 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     constexpr int NT = 64 * NW, NU = NW == 4 ? 2 : 1, IPT = 512 / NT;       // column tiles per wave; staging items per thread and operand
     const int mbase = NW == 4 ? 64 * (wave >> 1) : 64 * (wave >> 2), nbase = NW == 4 ? 64 * (wave & 1) : 32 * (wave & 3);
     const GemmSeg& g = a.seg[0];
-    const int nst = g.K / T3_KC;
+    // K range of this split: a.chunks_per_split counts 128-deep chunks (gemm_f32), a stage here is 32 deep
+    const int kbeg = a.nsplit > 1 ? (int)blockIdx.z * a.chunks_per_split * 128 : 0;
+    const int kend = a.nsplit > 1 ? min(g.K, kbeg + a.chunks_per_split * 128) : g.K;
+    const int nst = (kend - kbeg) / T3_KC;
 
     f32x16 acc[2][NU];
 #pragma unroll
@@ -927,21 +932,31 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][u][q] = 0.f;
 
-    // staging: item = tid + NT j -> k block kb = item >> 7 (8 consecutive k), column c = item & 127
+    // staging: item = tid + NT j -> k block kb = item >> 7 (8 consecutive k), column c = item & 127  (k-major operands);
+    // for a row-major A: row c = item >> 2, k block kb = item & 3 (four lanes read 128 contiguous bytes of a row)
     const float* ap[IPT];
     const float* bp[IPT];
-    int so[IPT];
+    int so[IPT], soa[IPT];
 #pragma unroll
     for (int j = 0; j < IPT; ++j) {
         const int item = tid + NT * j, kb = item >> 7, c = item & 127;
         int mc = m0 + c, nc = n0 + c;
         if (mc > a.M - 1) mc = a.M - 1;                            // clamped columns feed only never-stored outputs
         if (nc > a.N - 1) nc = a.N - 1;
-        ap[j] = g.A + (size_t)(8 * kb) * g.lda + mc;
-        bp[j] = g.B + (size_t)(8 * kb) * g.ldb + nc;
+        bp[j] = g.B + (size_t)(kbeg + 8 * kb) * g.ldb + nc;
         so[j] = c * T3_PB + 8 * kb;
+        if (AROW) {
+            const int ra = item >> 2, ka = item & 3;
+            int mr = m0 + ra;
+            if (mr > a.M - 1) mr = a.M - 1;
+            ap[j] = g.A + (size_t)mr * g.lda + kbeg + 8 * ka;
+            soa[j] = ra * T3_PB + 8 * ka;
+        } else {
+            ap[j] = g.A + (size_t)(kbeg + 8 * kb) * g.lda + mc;
+            soa[j] = so[j];
+        }
     }
-    const size_t astep = (size_t)T3_KC * g.lda, bstep = (size_t)T3_KC * g.ldb;
+    const size_t astep = AROW ? (size_t)T3_KC : (size_t)T3_KC * g.lda, bstep = (size_t)T3_KC * g.ldb;
     // register ring of two stages: iteration st multiplies LDS buffer st & 1, stores stage st + 1 (loaded one iteration
     // earlier) into the other buffer at its end and issues the loads of stage st + 2 at its top -- a stage is 48 MFMAs
     // (0.64 us), one stage of loads in flight does not cover the memory latency
@@ -950,7 +965,18 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
 #pragma unroll
         for (int j = 0; j < IPT; ++j)
 #pragma unroll
-            for (int e = 0; e < 8; ++e) { ar[j][e] = ap[j][(size_t)e * g.lda]; br[j][e] = bp[j][(size_t)e * g.ldb]; }
+            for (int e = 0; e < 8; ++e) br[j][e] = bp[j][(size_t)e * g.ldb];
+#pragma unroll
+        for (int j = 0; j < IPT; ++j) {
+            if (AROW) {
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(ap[j]), hi = *reinterpret_cast<const f32x4*>(ap[j] + 4);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { ar[j][e] = lo[e]; ar[j][4 + e] = hi[e]; }
+            } else {
+#pragma unroll
+                for (int e = 0; e < 8; ++e) ar[j][e] = ap[j][(size_t)e * g.lda];
+            }
+        }
 #pragma unroll
         for (int j = 0; j < IPT; ++j) { ap[j] += astep; bp[j] += bstep; }
     };
@@ -966,7 +992,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
         unsigned short* bA = lds + (size_t)buf * 6 * T3_PLANE;
         unsigned short* bB = bA + 3 * T3_PLANE;
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) { put(bA + so[j], ar[j]); put(bB + so[j], br[j]); }
+        for (int j = 0; j < IPT; ++j) { put(bA + soa[j], ar[j]); put(bB + so[j], br[j]); }
     };
     auto compute = [&](int buf) {
         const unsigned short* pa = lds + (size_t)buf * 6 * T3_PLANE + (mbase + r) * T3_PB + 8 * h;
@@ -1014,6 +1040,9 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     }
     if (st < nst) iter(st, ar0, br0, ar1, br1);
     // acc[i][u][q] <-> row m0 + mbase + 32 i + (q & 3) + 8 (q >> 2) + 4 h, column n0 + nbase + 32 u + r
+    const bool direct = a.nsplit == 1;
+    float* const outp = direct ? a.out : a.out + (size_t)blockIdx.z * a.M * a.N;
+    const int ldo = direct ? a.ldo : a.N;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -1024,8 +1053,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
             for (int q = 0; q < 16; ++q) {
                 const int m = m0 + mbase + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (m < a.M) {
-                    float* o = a.out + (size_t)m * a.ldo + n;
-                    *o = a.accumulate ? (*o + acc[i][u][q]) : acc[i][u][q];
+                    float* o = outp + (size_t)m * ldo + n;
+                    *o = (direct && a.accumulate) ? (*o + acc[i][u][q]) : acc[i][u][q];
                 }
             }
         }
@@ -1073,6 +1102,13 @@ static int nn_stage_k(const GemmArgs& a) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return 64;
     return 128;
+}
+// NN shapes that go to the split-precision 128 x 128-tile kernel: one segment, at least 128 rows and columns, K in whole
+// 128-deep chunks, plain output (ICZ_GEMM_NN_X3=0: the fp32-MFMA kernel)
+static bool nn_x3(const GemmArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ICZ_GEMM_NN_X3"); on = e ? atoi(e) : 1; }
+    return on && a.nseg == 1 && a.M >= 128 && a.N >= 128 && a.seg[0].K % 128 == 0 && !a.bias && a.N % 4 == 0;
 }
 static int stage_k(GemmLayout layout, const GemmArgs& a) {
     return layout == GEMM_NT ? nt_stage_k(a) : (layout == GEMM_NN ? nn_stage_k(a) : GEMM_BK);
@@ -1128,6 +1164,14 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
 // (about 6 us = 2.4 stages of 128); s is chosen to minimise rounds * (chunks per split + fixed) under the slab capacity.
 // E.g. 320 tiles x 79 chunks: s = 1 needs 2 rounds of 79 (the second a quarter full), s = 4 needs 5 full rounds of 20.
 int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_capacity_floats) {
+    if (layout == GEMM_NN && nn_x3(a)) {      // 128 x 128 tiles: about two workgroups per CU, at least 8 chunks of 128 per split
+        const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128), tot = a.seg[0].K / 128;
+        int s = 512 / (tiles > 0 ? tiles : 1);
+        if (s > tot / 8) s = tot / 8;
+        if (s < 1) s = 1;
+        while (s > 1 && (size_t)s * a.M * a.N > slab_capacity_floats) --s;
+        return cdiv(tot, cdiv(tot, s));
+    }
     const int bk = stage_k(layout, a);
     const int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
     const int tot = total_chunks(a, bk);
@@ -1229,7 +1273,18 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
             if (sp < 0) { const char* e = getenv("ICZ_GEMM_NN_SPREAD"); sp = e ? atoi(e) : 1; }
             a.spread = sp;
         }
-        if (nn_stage_k(a) == 128) hipLaunchKernelGGL((gemm_nn_kernel<false, 128>), grid, block, 0, stream, a);
+        if (nn_x3(a)) {      // batched dgrad GEMMs (all time steps at once): split-precision 128 x 128 tiles
+            static bool attr = false;
+            if (!attr) {
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 8, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
+                attr = true;
+            }
+            const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), a.nsplit);
+            if ((int)(g128.x * g128.y * g128.z) > 256) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4, true>), g128, block, t3_lds(1), stream, a);
+            else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8, true>), g128, dim3(512), t3_lds(2), stream, a);
+        }
+        else if (nn_stage_k(a) == 128) hipLaunchKernelGGL((gemm_nn_kernel<false, 128>), grid, block, 0, stream, a);
         else if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
     } else {
