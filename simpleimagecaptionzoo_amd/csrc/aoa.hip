@@ -79,7 +79,7 @@ int Aoa::refresh(hipStream_t st) {
 // C = sum_s A_s W_s^T + bias, dense [M,N]; split-K slabs through `ws` when one pass would leave most CUs idle
 static int aoa_linear(Aoa& a, GemmArgs& g, const float* bias, float* out, hipStream_t st) {
     g.out = out; g.ldo = g.N;
-    g.nsplit = gemm_pick_split(g, Aoa::STEP_WGS);
+    g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, Aoa::STEP_WGS), a.ws_floats);
     if (g.nsplit == 1) {
         g.bias = bias;
         return gemm_f32(GEMM_NT, g, st);

@@ -103,7 +103,7 @@ int Butd::refresh(hipStream_t st) {
 
 // generic "y = x W^T" with automatic split-K into the workspace; returns the split used (1 = direct into out)
 int Butd::gemm_nt(GemmArgs& g, int* nsplit_out, hipStream_t st) {
-    g.nsplit = gemm_pick_split(g, TARGET_WGS);
+    g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, TARGET_WGS), ws_floats);
     if (g.nsplit > 1) {
         ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "butd: workspace too small for %dx%dx%d slabs", g.nsplit, g.M, g.N);
         g.out = ws;
@@ -364,7 +364,7 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
     g.nseg = 1;
     g.seg[0] = {X, W, ldx, ldw, K, nullptr};
     g.M = M; g.N = N; g.out = C; g.ldo = ldc; g.bias = bias;
-    g.nsplit = nsplit > 0 ? nsplit : gemm_pick_split(g, Butd::TARGET_WGS, (GemmLayout)layout);
+    g.nsplit = nsplit > 0 ? nsplit : gemm_fit_split((GemmLayout)layout, g, gemm_pick_split(g, Butd::TARGET_WGS, (GemmLayout)layout), workspace_floats);
     g.nsplit = gemm_normalize_split((GemmLayout)layout, g, g.nsplit);   // no empty splits
     hipStream_t st = (hipStream_t)stream;
     if (g.nsplit > 1) {

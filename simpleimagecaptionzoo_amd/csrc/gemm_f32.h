@@ -65,5 +65,7 @@ int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_c
 size_t gemm_slab_floats(int M, int N, int nsplit);
 // clamp a caller-chosen split so that no split is empty (stage depth depends on layout and shape)
 int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit);
+// the largest split <= nsplit whose slabs fit the given capacity
+int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capacity_floats);
 
 }  // namespace icz

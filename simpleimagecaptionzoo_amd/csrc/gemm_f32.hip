@@ -908,8 +908,10 @@ constexpr size_t t3_lds(int nbuf) { return (size_t)nbuf * 2 * 3 * T3_PLANE * 2; 
 // NBUF = 2: double-buffered stages for the one-round shapes.  NW = 4: wave (wr, wc) owns a 64 x 64 quadrant; NW = 8: a
 // 64 x 32 half quadrant (two waves per SIMD inside the workgroup).
 // AROW = false: TN (A(m,k) = A[k lda + m]);  AROW = true: NN (A(m,k) = A[m lda + k], the batched dgrad GEMMs over all time
-// steps): the A tile then comes in as two float4 per thread along k.  blockIdx.z = split-K part (slabs [z][M][N] in a.out).
-template <int NBUF, int NW, bool AROW = false>
+// steps): the A tile then comes in as two float4 per thread along k.  BROW = true as well: NT (B(k,n) = B[n ldb + k], every
+// forward Linear with many rows: AoA refiner, beam-search steps), several K segments allowed when there is no split.
+// blockIdx.z = split-K part (slabs [z][M][N] in a.out).
+template <int NBUF, int NW, bool AROW = false, bool BROW = false>
 __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
     unsigned short* const lds = reinterpret_cast<unsigned short*>(t3_smem);
@@ -918,12 +920,6 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
     constexpr int NT = 64 * NW, NU = NW == 4 ? 2 : 1, IPT = 512 / NT;       // column tiles per wave; staging items per thread and operand
     const int mbase = NW == 4 ? 64 * (wave >> 1) : 64 * (wave >> 2), nbase = NW == 4 ? 64 * (wave & 1) : 32 * (wave & 3);
-    const GemmSeg& g = a.seg[0];
-    // K range of this split: a.chunks_per_split counts 128-deep chunks (gemm_f32), a stage here is 32 deep
-    const int kbeg = a.nsplit > 1 ? (int)blockIdx.z * a.chunks_per_split * 128 : 0;
-    const int kend = a.nsplit > 1 ? min(g.K, kbeg + a.chunks_per_split * 128) : g.K;
-    const int nst = (kend - kbeg) / T3_KC;
-
     f32x16 acc[2][NU];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
@@ -932,113 +928,140 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][u][q] = 0.f;
 
-    // staging: item = tid + NT j -> k block kb = item >> 7 (8 consecutive k), column c = item & 127  (k-major operands);
-    // for a row-major A: row c = item >> 2, k block kb = item & 3 (four lanes read 128 contiguous bytes of a row)
-    const float* ap[IPT];
-    const float* bp[IPT];
-    int so[IPT], soa[IPT];
-#pragma unroll
-    for (int j = 0; j < IPT; ++j) {
-        const int item = tid + NT * j, kb = item >> 7, c = item & 127;
-        int mc = m0 + c, nc = n0 + c;
-        if (mc > a.M - 1) mc = a.M - 1;                            // clamped columns feed only never-stored outputs
-        if (nc > a.N - 1) nc = a.N - 1;
-        bp[j] = g.B + (size_t)(kbeg + 8 * kb) * g.ldb + nc;
-        so[j] = c * T3_PB + 8 * kb;
-        if (AROW) {
-            const int ra = item >> 2, ka = item & 3;
-            int mr = m0 + ra;
-            if (mr > a.M - 1) mr = a.M - 1;
-            ap[j] = g.A + (size_t)mr * g.lda + kbeg + 8 * ka;
-            soa[j] = ra * T3_PB + 8 * ka;
-        } else {
-            ap[j] = g.A + (size_t)(kbeg + 8 * kb) * g.lda + mc;
-            soa[j] = so[j];
-        }
-    }
-    const size_t astep = AROW ? (size_t)T3_KC : (size_t)T3_KC * g.lda, bstep = (size_t)T3_KC * g.ldb;
-    // register ring of two stages: iteration st multiplies LDS buffer st & 1, stores stage st + 1 (loaded one iteration
-    // earlier) into the other buffer at its end and issues the loads of stage st + 2 at its top -- a stage is 48 MFMAs
-    // (0.64 us), one stage of loads in flight does not cover the memory latency
-    float ar0[IPT][8], br0[IPT][8], ar1[IPT][8], br1[IPT][8];
-    auto load_stage = [&](float (&ar)[IPT][8], float (&br)[IPT][8]) {
-#pragma unroll
-        for (int j = 0; j < IPT; ++j)
-#pragma unroll
-            for (int e = 0; e < 8; ++e) br[j][e] = bp[j][(size_t)e * g.ldb];
+    // one K segment (all of it, or this split's range when there is a single segment)
+    auto run_segment = [&](const GemmSeg& g, int kbeg, int kend) {
+        const int nst = (kend - kbeg) / T3_KC;
+        if (nst <= 0) return;
+        // staging: item = tid + NT j -> k block kb = item >> 7 (8 consecutive k), column c = item & 127  (k-major operands);
+        // for a row-major A: row c = item >> 2, k block kb = item & 3 (four lanes read 128 contiguous bytes of a row)
+        const float* ap[IPT];
+        const float* bp[IPT];
+        int so[IPT], soa[IPT];
 #pragma unroll
         for (int j = 0; j < IPT; ++j) {
-            if (AROW) {
-                const f32x4 lo = *reinterpret_cast<const f32x4*>(ap[j]), hi = *reinterpret_cast<const f32x4*>(ap[j] + 4);
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { ar[j][e] = lo[e]; ar[j][4 + e] = hi[e]; }
+            const int item = tid + NT * j, kb = item >> 7, c = item & 127;
+            int mc = m0 + c, nc = n0 + c;
+            if (mc > a.M - 1) mc = a.M - 1;                            // clamped columns feed only never-stored outputs
+            if (nc > a.N - 1) nc = a.N - 1;
+            so[j] = c * T3_PB + 8 * kb;
+            if (BROW) {
+                const int rb = item >> 2, kq = item & 3;
+                int nr = n0 + rb;
+                if (nr > a.N - 1) nr = a.N - 1;
+                bp[j] = g.B + (size_t)nr * g.ldb + kbeg + 8 * kq;
+                so[j] = rb * T3_PB + 8 * kq;
             } else {
-#pragma unroll
-                for (int e = 0; e < 8; ++e) ar[j][e] = ap[j][(size_t)e * g.lda];
+                bp[j] = g.B + (size_t)(kbeg + 8 * kb) * g.ldb + nc;
+            }
+            if (AROW) {
+                const int ra = item >> 2, ka = item & 3;
+                int mr = m0 + ra;
+                if (mr > a.M - 1) mr = a.M - 1;
+                ap[j] = g.A + (size_t)mr * g.lda + kbeg + 8 * ka;
+                soa[j] = ra * T3_PB + 8 * ka;
+            } else {
+                ap[j] = g.A + (size_t)(kbeg + 8 * kb) * g.lda + mc;
+                soa[j] = so[j];
             }
         }
+        const size_t astep = AROW ? (size_t)T3_KC : (size_t)T3_KC * g.lda, bstep = BROW ? (size_t)T3_KC : (size_t)T3_KC * g.ldb;
+        // register ring of two stages: iteration st multiplies LDS buffer st & 1, stores stage st + 1 (loaded one iteration
+        // earlier) into the other buffer at its end and issues the loads of stage st + 2 at its top -- a stage is 48 MFMAs
+        // (0.64 us), one stage of loads in flight does not cover the memory latency
+        float ar0[IPT][8], br0[IPT][8], ar1[IPT][8], br1[IPT][8];
+        auto load_stage = [&](float (&ar)[IPT][8], float (&br)[IPT][8]) {
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) { ap[j] += astep; bp[j] += bstep; }
-    };
-    auto put = [&](unsigned short* base, const float (&v)[8]) {
-        uint32_t s0[4], s1[4], s2[4];
+            for (int j = 0; j < IPT; ++j)
 #pragma unroll
-        for (int e = 0; e < 4; ++e) split3(v[2 * e], v[2 * e + 1], s0[e], s1[e], s2[e]);
-        *reinterpret_cast<u32x4*>(base) = (u32x4){s0[0], s0[1], s0[2], s0[3]};
-        *reinterpret_cast<u32x4*>(base + T3_PLANE) = (u32x4){s1[0], s1[1], s1[2], s1[3]};
-        *reinterpret_cast<u32x4*>(base + 2 * T3_PLANE) = (u32x4){s2[0], s2[1], s2[2], s2[3]};
-    };
-    auto store_stage = [&](int buf, const float (&ar)[IPT][8], const float (&br)[IPT][8]) {
-        unsigned short* bA = lds + (size_t)buf * 6 * T3_PLANE;
-        unsigned short* bB = bA + 3 * T3_PLANE;
+                for (int e = 0; e < 8; ++e) if (!BROW) br[j][e] = bp[j][(size_t)e * g.ldb];
 #pragma unroll
-        for (int j = 0; j < IPT; ++j) { put(bA + soa[j], ar[j]); put(bB + so[j], br[j]); }
-    };
-    auto compute = [&](int buf) {
-        const unsigned short* pa = lds + (size_t)buf * 6 * T3_PLANE + (mbase + r) * T3_PB + 8 * h;
-        const unsigned short* pb = lds + (size_t)buf * 6 * T3_PLANE + 3 * T3_PLANE + (nbase + r) * T3_PB + 8 * h;
+            for (int j = 0; j < IPT; ++j) {
+                if (BROW) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(bp[j]), hi = *reinterpret_cast<const f32x4*>(bp[j] + 4);
 #pragma unroll
-        for (int blk = 0; blk < T3_KC / 16; ++blk) {
-            bf16x8 af[3][2], bf[3][NU];
-#pragma unroll
-            for (int p = 0; p < 3; ++p) {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(pa + p * T3_PLANE + i * 32 * T3_PB + 16 * blk);
-#pragma unroll
-                for (int u = 0; u < NU; ++u) bf[p][u] = *reinterpret_cast<const bf16x8*>(pb + p * T3_PLANE + u * 32 * T3_PB + 16 * blk);
-            }
-#pragma unroll
-            for (int i = 0; i < 2; ++i)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) {       // smallest terms first
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][u], acc[i][u], 0, 0, 0);
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][u], acc[i][u], 0, 0, 0);
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][u], acc[i][u], 0, 0, 0);
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][u], acc[i][u], 0, 0, 0);
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][u], acc[i][u], 0, 0, 0);
-                    acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][u], acc[i][u], 0, 0, 0);
+                    for (int e = 0; e < 4; ++e) { br[j][e] = lo[e]; br[j][4 + e] = hi[e]; }
                 }
-        }
-    };
-    load_stage(ar0, br0);
-    store_stage(0, ar0, br0);
-    if (nst > 1) load_stage(ar1, br1);
-    __syncthreads();
-    // iteration st (even: registers 0 are free, 1 hold stage st + 1; odd: the other way round)
-    auto iter = [&](int st, float (&arF)[IPT][8], float (&brF)[IPT][8], const float (&arN)[IPT][8], const float (&brN)[IPT][8]) {
-        if (st + 2 < nst) load_stage(arF, brF);
-        __builtin_amdgcn_sched_barrier(0);
-        compute(NBUF == 2 ? (st & 1) : 0);
-        if (NBUF == 1) __syncthreads();          // every wave has read this stage's fragments
-        if (st + 1 < nst) store_stage(NBUF == 2 ? ((st + 1) & 1) : 0, arN, brN);
+                if (AROW) {
+                    const f32x4 lo = *reinterpret_cast<const f32x4*>(ap[j]), hi = *reinterpret_cast<const f32x4*>(ap[j] + 4);
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) { ar[j][e] = lo[e]; ar[j][4 + e] = hi[e]; }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) ar[j][e] = ap[j][(size_t)e * g.lda];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) { ap[j] += astep; bp[j] += bstep; }
+        };
+        auto put = [&](unsigned short* base, const float (&v)[8]) {
+            uint32_t s0[4], s1[4], s2[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) split3(v[2 * e], v[2 * e + 1], s0[e], s1[e], s2[e]);
+            *reinterpret_cast<u32x4*>(base) = (u32x4){s0[0], s0[1], s0[2], s0[3]};
+            *reinterpret_cast<u32x4*>(base + T3_PLANE) = (u32x4){s1[0], s1[1], s1[2], s1[3]};
+            *reinterpret_cast<u32x4*>(base + 2 * T3_PLANE) = (u32x4){s2[0], s2[1], s2[2], s2[3]};
+        };
+        auto store_stage = [&](int buf, const float (&ar)[IPT][8], const float (&br)[IPT][8]) {
+            unsigned short* bA = lds + (size_t)buf * 6 * T3_PLANE;
+            unsigned short* bB = bA + 3 * T3_PLANE;
+#pragma unroll
+            for (int j = 0; j < IPT; ++j) { put(bA + soa[j], ar[j]); put(bB + so[j], br[j]); }
+        };
+        auto compute = [&](int buf) {
+            const unsigned short* pa = lds + (size_t)buf * 6 * T3_PLANE + (mbase + r) * T3_PB + 8 * h;
+            const unsigned short* pb = lds + (size_t)buf * 6 * T3_PLANE + 3 * T3_PLANE + (nbase + r) * T3_PB + 8 * h;
+#pragma unroll
+            for (int blk = 0; blk < T3_KC / 16; ++blk) {
+                bf16x8 af[3][2], bf[3][NU];
+#pragma unroll
+                for (int p = 0; p < 3; ++p) {
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) af[p][i] = *reinterpret_cast<const bf16x8*>(pa + p * T3_PLANE + i * 32 * T3_PB + 16 * blk);
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) bf[p][u] = *reinterpret_cast<const bf16x8*>(pb + p * T3_PLANE + u * 32 * T3_PB + 16 * blk);
+                }
+#pragma unroll
+                for (int i = 0; i < 2; ++i)
+#pragma unroll
+                    for (int u = 0; u < NU; ++u) {       // smallest terms first
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[2][i], bf[0][u], acc[i][u], 0, 0, 0);
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[2][u], acc[i][u], 0, 0, 0);
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[1][u], acc[i][u], 0, 0, 0);
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1][i], bf[0][u], acc[i][u], 0, 0, 0);
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[1][u], acc[i][u], 0, 0, 0);
+                        acc[i][u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0][i], bf[0][u], acc[i][u], 0, 0, 0);
+                    }
+            }
+        };
+        load_stage(ar0, br0);
+        store_stage(0, ar0, br0);
+        if (nst > 1) load_stage(ar1, br1);
         __syncthreads();
+        // iteration st (even: registers 0 are free, 1 hold stage st + 1; odd: the other way round)
+        auto iter = [&](int st, float (&arF)[IPT][8], float (&brF)[IPT][8], const float (&arN)[IPT][8], const float (&brN)[IPT][8]) {
+            if (st + 2 < nst) load_stage(arF, brF);
+            __builtin_amdgcn_sched_barrier(0);
+            compute(NBUF == 2 ? (st & 1) : 0);
+            if (NBUF == 1) __syncthreads();          // every wave has read this stage's fragments
+            if (st + 1 < nst) store_stage(NBUF == 2 ? ((st + 1) & 1) : 0, arN, brN);
+            __syncthreads();
+        };
+        int st = 0;
+        for (; st + 2 <= nst; st += 2) {
+            iter(st, ar0, br0, ar1, br1);
+            iter(st + 1, ar1, br1, ar0, br0);
+        }
+        if (st < nst) iter(st, ar0, br0, ar1, br1);
     };
-    int st = 0;
-    for (; st + 2 <= nst; st += 2) {
-        iter(st, ar0, br0, ar1, br1);
-        iter(st + 1, ar1, br1, ar0, br0);
+    if (a.nseg == 1) {
+        // K range of this split: a.chunks_per_split counts 128-deep chunks (gemm_f32), a stage here is 32 deep
+        const int kbeg = a.nsplit > 1 ? (int)blockIdx.z * a.chunks_per_split * 128 : 0;
+        const int kend = a.nsplit > 1 ? min(a.seg[0].K, kbeg + a.chunks_per_split * 128) : a.seg[0].K;
+        run_segment(a.seg[0], kbeg, kend);
+    } else {
+#pragma unroll 1
+        for (int sgi = 0; sgi < a.nseg; ++sgi) run_segment(a.seg[sgi], 0, a.seg[sgi].K);
     }
-    if (st < nst) iter(st, ar0, br0, ar1, br1);
     // acc[i][u][q] <-> row m0 + mbase + 32 i + (q & 3) + 8 (q >> 2) + 4 h, column n0 + nbase + 32 u + r
     const bool direct = a.nsplit == 1;
     float* const outp = direct ? a.out : a.out + (size_t)blockIdx.z * a.M * a.N;
@@ -1049,12 +1072,14 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
         for (int u = 0; u < NU; ++u) {
             const int n = n0 + nbase + 32 * u + r;
             if (n >= a.N) continue;
+            const float bias_n = (direct && a.bias) ? a.bias[n] : 0.f;
 #pragma unroll
             for (int q = 0; q < 16; ++q) {
                 const int m = m0 + mbase + 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h;
                 if (m < a.M) {
                     float* o = outp + (size_t)m * ldo + n;
-                    *o = (direct && a.accumulate) ? (*o + acc[i][u][q]) : acc[i][u][q];
+                    const float v = acc[i][u][q] + bias_n;
+                    *o = (direct && a.accumulate) ? (*o + v) : v;
                 }
             }
         }
@@ -1136,6 +1161,17 @@ static bool nt_x3(const GemmArgs& a) {
         if (a.seg[s].K % 128) return false;
     return true;
 }
+// NT shapes with many rows (AoA refiner, beam-search steps, prologue hoists) that go to the split-precision 128 x 128-tile
+// kernel: whole 128-deep chunks, enough tiles to fill at least half of the CUs (one K segment may also be split)
+static bool nt_x3big(const GemmArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ICZ_GEMM_NT_X3BIG"); on = e ? atoi(e) : 1; }
+    if (!on || a.M < 128 || a.N < 128) return false;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % 128) return false;
+    const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
+    return a.nseg == 1 ? tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128 : tiles >= 128;
+}
 static int nt_waves(const GemmArgs& a) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_GEMM_NW"); force = e ? atoi(e) : 0; }
@@ -1147,6 +1183,14 @@ static int nt_waves(const GemmArgs& a) {
 static int nt_tile_n(const GemmArgs& a) { return 16 * nt_waves(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
+    if (layout == GEMM_NT && nt_x3big(a)) {       // 128 x 128 tiles, about two workgroups per CU, at least 4 chunks of 128 per split
+        if (a.nseg > 1) return 1;
+        const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128), tot = a.seg[0].K / 128;
+        int s = 512 / tiles;
+        if (s > tot / 4) s = tot / 4;
+        if (s < 1) s = 1;
+        return cdiv(tot, cdiv(tot, s));
+    }
     if (X3_NBUF == 1 && layout == GEMM_NT && a.M > 32 && nt_x3(a)) target_wgs *= 2;       // two workgroups of the split-precision kernel per CU
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
     int tot = total_chunks(a, stage_k(layout, a));
@@ -1189,6 +1233,12 @@ int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_c
     return best;
 }
 
+// the largest split <= nsplit whose slabs fit `capacity_floats` (no empty splits)
+int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capacity_floats) {
+    nsplit = gemm_normalize_split(layout, a, nsplit);
+    while (nsplit > 1 && gemm_slab_floats(a.M, a.N, nsplit) > capacity_floats) nsplit = gemm_normalize_split(layout, a, nsplit - 1);
+    return nsplit;
+}
 int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit) {
     const int tot = total_chunks(a, stage_k(layout, a));
     if (nsplit < 1) nsplit = 1;
@@ -1233,6 +1283,20 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     bool tail = false;
     for (int s = 0; s < a.nseg; ++s) tail |= (a.seg[s].K % GEMM_BK) != 0;
     if (layout == GEMM_NT) {
+        if (nt_x3big(a) && (a.nseg == 1 || a.nsplit == 1)) {
+            static bool attr = false;
+            if (!attr) {
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 8, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
+                attr = true;
+            }
+            // chunks_per_split was computed in NT stage units (128 here, the predicate guarantees it) -- the kernel's unit too
+            const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), a.nsplit);
+            if ((int)(g128.x * g128.y * g128.z) > 256) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4, true, true>), g128, block, t3_lds(1), stream, a);
+            else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8, true, true>), g128, dim3(512), t3_lds(2), stream, a);
+            ICZ_CHECK_HIP(hipGetLastError());
+            return ICZ_OK;
+        }
         int mt = a.M <= 16 ? 1 : (a.M <= 32 ? 2 : 4);
         const int bn = nt_tile_n(a);
         dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
