@@ -34,6 +34,10 @@ def make_handle(g, sd=None, max_rows=None, max_len=20):
     ("nt", 16, 128, 48), ("nt", 33, 70, 16), ("nt", 320, 4096, 1024), ("nt", 2304, 1024, 2048), ("nt", 130, 3000, 96),
     ("nn", 64, 1024, 4096), ("nn", 5, 96, 53 * 4), ("nn", 100, 64, 10104), ("nn", 20, 2048, 4096),
     ("tn", 4096, 1024, 1280), ("tn", 64, 52, 100), ("tn", 128, 2048, 37), ("tn", 1024, 10104, 64),
+    # the split-precision 128 x 128-tile kernel in its three layouts (csrc/gemm_f32.hip: gemm_tn128_x3_kernel): more than one
+    # round of tiles (one LDS buffer), one round (eight waves), ragged edges, batched-dgrad shapes with split-K
+    ("tn", 4096, 3072, 1280), ("tn", 2100, 2052, 96), ("nn", 1280, 1024, 4096), ("nn", 1280, 1024, 10112), ("nn", 300, 132, 256),
+    ("nt", 640, 10102, 1024), ("nt", 2304, 2048, 2048),
 ])
 @pytest.mark.parametrize("nsplit", [0, 1, 3])
 def test_gemm_against_float64(layout, M, N, K, nsplit):
