@@ -280,9 +280,10 @@ def main():
         "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 throughout (fp32-input MFMA / VALU, float64 CIDEr-D); the weight-gradient GEMMs multiply fp32 operands as "
-                      "three bf16 pieces each (24 mantissa bits, six bf16 MFMAs per product, fp32 accumulation): fp32-level error, "
-                      "inside the same parity bounds (tests/), ICZ_GEMM_TN_X3=0 selects the fp32-MFMA kernel",
+        "arithmetic": "fp32 throughout (fp32-input MFMA / VALU, float64 CIDEr-D); the 128 x 128-tile GEMMs (weight gradients, the "
+                      "dgrad over all time steps, forward GEMMs of 128+ rows) multiply fp32 operands as three bf16 pieces each (24 "
+                      "mantissa bits, six bf16 MFMAs per product, fp32 accumulation): fp32-level error, inside the same parity bounds "
+                      "(tests/); ICZ_GEMM_TN_X3=0 ICZ_GEMM_NN_X3=0 ICZ_GEMM_NT_X3BIG=0 select the fp32-MFMA kernels",
         "config": {"workload": "BUTDDetection SCST step (greedy + sampled rollout + CIDEr-D reward + REINFORCE backward "
                                "+ clamp + Adam), batch %d per GPU, 36x2048 features, H=E=A=1024, V=10102, 20 decode steps" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world},
