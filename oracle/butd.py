@@ -172,18 +172,31 @@ def packed_order(lengths):
     return [(b, t) for t in range(max(lengths)) for b in range(len(lengths)) if lengths[b] > t]
 
 
-def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_masks=None):
-    """DecoderRNN.forward, BUTD_Model.py:97-151 (ss_prob = 0).  Returns packed logits (sum(lengths), V)."""
+def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_masks=None, ss_prob=0.0, ss_gate=None,
+               ss_draw=None, tokens_out=None):
+    """DecoderRNN.forward, BUTD_Model.py:97-151.  Returns packed logits (sum(lengths), V).
+    Scheduled sampling (:120-132, ss_prob > 0): from time step 2 on, row b feeds a draw from softmax(previous logits)
+    instead of its caption token when ss_gate[t][b] < ss_prob; the draw is inverse_cdf_draw with ss_draw[t][b] (no
+    gradient flows through it).  tokens_out, if a list, receives the tokens fed at every step."""
     B = feats.shape[0]
     H = p["TD_atten.weight_hh"].shape[1]
     mean, st = feats.mean(1), zero_state(B, H)
     rows = []
+    logits = None
     for t in range(max(lengths)):
         bt = sum(l > t for l in lengths)
         m = (None if emb_masks is None else torch.as_tensor(emb_masks[t][:bt]),
              None if att_masks is None else torch.as_tensor(att_masks[t][:bt]),
              None if out_masks is None else torch.as_tensor(out_masks[t][:bt]))
-        logits, _, st = step(feats[:bt], mean[:bt], captions[:bt, t], tuple(s[:bt] for s in st), p, m)
+        it = captions[:bt, t]
+        if t >= 2 and ss_prob > 0.0:
+            gate = torch.as_tensor(ss_gate[t][:bt], dtype=torch.float32) < ss_prob
+            if bool(gate.any()):
+                draw = inverse_cdf_draw(torch.softmax(logits.detach()[:bt], dim=1), ss_draw[t][:bt])
+                it = torch.where(gate, draw, it)
+        if tokens_out is not None:
+            tokens_out.append(it.clone())
+        logits, _, st = step(feats[:bt], mean[:bt], it, tuple(s[:bt] for s in st), p, m)
         rows.append(logits)
     return torch.cat(rows, 0)
 

@@ -141,6 +141,35 @@ def injected():
         torch.multinomial = om
 
 
+@contextlib.contextmanager
+def scheduled_sampling_draws(u_gate, u_draw):
+    """The two random draws of the scheduled-sampling branch of DecoderRNN.forward (BUTD_Model.py:120-130), supplied:
+    `torch.zeros(n).uniform_(0, 1)` (once per time step >= 2) returns u_gate[t][:n]; `torch.multinomial(prob_prev, 1)`
+    becomes the inverse-CDF draw with u_draw[t] (same stand-in as Injector.multinomial)."""
+    state = {"t": 1}
+    ou, om = torch.Tensor.uniform_, torch.multinomial
+
+    def uni(self, a=0.0, b=1.0, generator=None):
+        state["t"] += 1
+        self.copy_(torch.from_numpy(u_gate[state["t"]][: self.shape[0]].astype(np.float32)))
+        return self
+
+    def multi(prob, num_samples=1, replacement=False, generator=None):
+        assert num_samples == 1
+        u = torch.from_numpy(u_draw[state["t"]][: prob.shape[0]].astype(np.float64))
+        c = torch.cumsum(prob.double(), dim=1)
+        tgt = (u * c[:, -1]).unsqueeze(1)
+        return torch.searchsorted(c, tgt, right=True).clamp_(max=prob.shape[1] - 1).long()
+
+    torch.Tensor.uniform_ = uni
+    torch.multinomial = multi
+    try:
+        yield state
+    finally:
+        torch.Tensor.uniform_ = ou
+        torch.multinomial = om
+
+
 def make_vocab(V):
     from ClassRepository.CaptionVocabClass import Caption_Vocabulary
     v = Caption_Vocabulary()
@@ -307,6 +336,32 @@ def gen_butd_decoder(tag, B, R, D, H, E, A, V, seed):
         out["xe_grad." + n_] = p.grad.detach().numpy().copy()
     # a second loss value with smoothing 0 (plain XE through the same class)
     out["xe_loss_s0"] = np.float32(LabelSmoothingLoss(0.0)(packed[0].detach(), targets[0]).item())
+
+    # ---- G-ss: the same XE step with scheduled sampling switched on in the decoder (BUTD_Model.py:120-132; Engine.py:143
+    #      sets the attribute on the Captioner, which the decoder never reads -- here it is set where it is read).
+    #      Own random stream, so that every other array of this file stays what it was.
+    ss_rs = np.random.RandomState(seed + 4242)
+    ss_gate = ss_rs.rand(T, B).astype(np.float32)
+    ss_draw = ss_rs.rand(T, B)
+    dec.train()
+    dec.zero_grad()
+    dec.ss_prob = 0.5
+    INJ.set([xe_emb_mask, xe_att_mask, xe_out_mask], None)
+    toks = []
+    hk = dec.embed.register_forward_hook(lambda m, i, o: toks.append(i[0].detach().clone()))
+    with injected(), scheduled_sampling_draws(ss_gate, ss_draw):
+        ss_packed, _ = dec(feats, captions, lengths)
+    hk.remove()
+    dec.ss_prob = 0.0
+    ss_loss = crit(ss_packed[0], targets[0])
+    ss_loss.backward()
+    ss_tok = np.zeros((T, B), dtype=np.int64)
+    for t_, it_ in enumerate(toks):
+        ss_tok[t_, : it_.shape[0]] = it_.numpy()
+    out.update(ss_prob=np.float32(0.5), ss_gate=ss_gate, ss_draw=ss_draw, ss_tokens=ss_tok,
+               ss_packed_logits=ss_packed[0].detach().numpy(), ss_loss=np.float32(ss_loss.item()))
+    for n_, p in dec.named_parameters():
+        out["ss_grad." + n_] = p.grad.detach().numpy().copy()
 
     # ---- G-rl (BUTD_Model.py:191-234 + Utils.py:295-317), injected masks + uniforms
     T = 20

@@ -97,6 +97,28 @@ def test_xe_forward_loss_grads(dec):
         np.testing.assert_allclose(v.grad.numpy(), g["xe_grad." + k], atol=2e-5, rtol=1e-4, err_msg=k)
 
 
+def test_xe_with_scheduled_sampling(dec):
+    """DecoderRNN.forward with ss_prob = 0.5 set on the decoder (BUTD_Model.py:120-132), gate / draw uniforms injected."""
+    g, _, feats = dec
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    B, R, D, H, E, A, V = g["dims"]
+    lengths = g["xe_lengths"].tolist()
+    att = np.unpackbits(g["xe_att_mask"], axis=-1)[..., :A]
+    toks = []
+    logits = ob.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p, g["xe_emb_mask"], att, g["xe_out_mask"],
+                           ss_prob=float(g["ss_prob"]), ss_gate=g["ss_gate"], ss_draw=g["ss_draw"], tokens_out=toks)
+    for t, it in enumerate(toks):
+        assert np.array_equal(it.numpy(), g["ss_tokens"][t, : it.shape[0]]), t
+    assert any(not np.array_equal(it.numpy(), g["xe_captions"][: it.shape[0], t]) for t, it in enumerate(toks))
+    np.testing.assert_allclose(logits.detach().numpy(), g["ss_packed_logits"], atol=1e-4)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["ss_loss"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["ss_grad." + k], atol=2e-5, rtol=1e-4, err_msg=k)
+
+
 def test_sample_rl_and_reinforce_grads(dec):
     g, _, feats = dec
     p = ob.to_params(sd_of(g), requires_grad=True)
