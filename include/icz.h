@@ -135,6 +135,15 @@ int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captio
 int icz_butd_xe_backward(icz_butd_t* h, float smoothing, const icz_butd_params* grads, float* loss_out,
                          float n_tokens_global, void* stream);
 
+/* Scheduled sampling in DecoderRNN.forward (BUTD_Model.py:120-132; the decoder attribute `ss_prob`, which
+ * Engine.py:140-144 means to raise per epoch but sets on the Captioner, where nothing reads it): from time step 2 on,
+ * row b of the following icz_butd_xe_forward calls feeds a draw from softmax(logits of step t-1) instead of its caption
+ * token when gate[t,b] < ss_prob.  gate_uniforms / draw_uniforms: device arrays [T,B] in [0,1) (T = max(lengths), B of
+ * the forward call; parity tests) or NULL for the Philox generator keyed by the call's icz_rng seed.  The draw is the
+ * inverse-CDF draw of the sampler contract (smallest v with cumsum(p)[v] > u sum(p), float64 sums); no gradient
+ * flows through it and the embedding gradient goes to the tokens actually fed.  ss_prob = 0 (default) switches it off. */
+int icz_butd_set_scheduled_sampling(icz_butd_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
+
 /* XE backward driven by an upstream gradient w.r.t. the packed logits [sum(lengths), V] (autograd path:
  * criterion(predictions[0], targets[0]).backward(), Engine.py:182-186). */
 int icz_butd_xe_backward_dlogits(icz_butd_t* h, const float* dpacked, const icz_butd_params* grads, void* stream);

@@ -106,7 +106,12 @@ class BUTDDetection_Captioner(nn.Module):
         self.dims = dict(R=num_regions, D=enc_dim, H=hidden_dim, E=embed_dim, A=atten_dim, V=vocab_size)
         self.max_rows = max_batch * max(1, max_beam)
         self.max_len = max_len
-        self.ss_prob = 0.0              # Engine.py:143 sets it; the reference decoder never reads it
+        # Engine.py:143 sets this attribute per epoch; the reference decoder reads its own copy, which nothing updates
+        # (SURVEY.md 5), so with the reference's schedule settings it stays 0.  Here a non-zero value does what
+        # DecoderRNN.forward does when its `ss_prob` is set (BUTD_Model.py:120-132).
+        self.ss_prob = 0.0
+        self._ss_bound = (0.0, id(None), id(None))
+        self._ss_draws = (None, None)
         self._h = None
         self._bound_ptrs = None
         self._grads = None
@@ -130,12 +135,22 @@ class BUTDDetection_Captioner(nn.Module):
             d = self.dims
             self._h = ButdHandle(d["R"], d["D"], d["H"], d["E"], d["A"], d["V"], self.max_rows, max(self.max_len, 20), dev)
             self._bound_ptrs = None
+            self._ss_bound = (0.0, id(None), id(None))
         if ptrs != self._bound_ptrs:
             self._h.bind({k: p.data for k, p in named.items()})
             self._bound_ptrs = ptrs
         else:
             self._h.refresh()
+        ss = (float(self.ss_prob), id(self._ss_draws[0]), id(self._ss_draws[1]))
+        if ss != self._ss_bound:
+            self._h.set_scheduled_sampling(float(self.ss_prob), *self._ss_draws)
+            self._ss_bound = ss
         return self._h
+
+    def set_scheduled_sampling_draws(self, gate=None, draw=None):
+        """Explicit uniforms [T, B] for the scheduled-sampling gate and draw of the next forward (parity tests);
+        None = the library's Philox streams."""
+        self._ss_draws = (gate, draw)
 
     def _grad_buffers(self):
         if self._grads is None or next(iter(self._grads.values())).device != next(self.parameters()).device:

@@ -78,6 +78,8 @@ struct Butd {
     int64_t* it = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
     uint64_t* d_seed = nullptr;          // Philox seed of the current training-mode call (device resident)
+    float ss_prob = 0.f;                 // scheduled sampling in xe_forward (icz_butd_set_scheduled_sampling)
+    const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // explicit [T, B] uniforms (device) or Philox
     float* d_msum_global = nullptr;      // data-parallel loss normaliser (0 = use the local one)
     float* ws = nullptr;
     size_t ws_floats = 0;

@@ -470,6 +470,88 @@ __device__ __forceinline__ float block_sum_n(float v, float* sm, int nw) {
     __syncthreads();
     return r;
 }
+// Inverse-CDF draw over the probabilities in LDS (the sampler contract of torch.multinomial's stand-in, oracle/butd.py
+// inverse_cdf_draw): smallest v with cumsum(p)[v] > u * sum(p), sums in float64.  Every thread of the SEL_THREADS-wide
+// workgroup calls it; the result (clamped to V - 1) is valid in thread 0 after the call.
+__device__ __forceinline__ int block_inverse_cdf(const float* srow, int V, float u, double* smd, int* smi) {
+    constexpr int NW = SEL_THREADS / 64;
+    const int tid = threadIdx.x;
+    // contiguous slice per thread -> the global "first index above target" is the minimum over threads
+    const int per = (V + SEL_THREADS - 1) / SEL_THREADS;
+    const int v0 = min(V, tid * per), v1 = min(V, v0 + per);
+    double loc = 0.0;
+    for (int v = v0; v < v1; ++v) loc += (double)srow[v];
+    // exclusive prefix over the slice sums: wave-level inclusive scan (shuffles) + the wave totals
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, 64);
+        if ((tid & 63) >= o) inc += up;
+    }
+    if ((tid & 63) == 63) smd[tid >> 6] = inc;
+    __syncthreads();
+    double wave_off = 0.0, total = 0.0;
+    for (int w = 0; w < NW; ++w) {
+        if (w < (tid >> 6)) wave_off += smd[w];
+        total += smd[w];
+    }
+    const double prefix = wave_off + inc - loc;
+    const double target = (double)u * total;
+    int cand = 0x7fffffff;
+    {
+        double run = prefix;
+        for (int v = v0; v < v1; ++v) {
+            run += (double)srow[v];
+            if (run > target) { cand = v; break; }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if ((tid & 63) == 0) smi[tid >> 6] = cand;
+    __syncthreads();
+    int d = 0;
+    if (tid == 0) {          // only thread 0 reads smi[]: the caller may reuse it right away
+        d = smi[0];
+        for (int w = 1; w < NW; ++w) d = min(d, smi[w]);
+        if (d > V - 1) d = V - 1;
+    }
+    return d;
+}
+
+// Scheduled sampling, DecoderRNN.forward (BUTD_Model.py:120-130): from time step 2 on, row b of the XE forward feeds a draw
+// from softmax(logits of step t-1) instead of its caption token when gate < ss_prob.  One workgroup per active row; a row
+// whose gate is not below ss_prob leaves at once (its token stays the caption's).
+struct SsSelArgs {
+    const float* logits_prev;  // [rows, ldl] logits of step t - 1
+    int ldl, V, t;
+    float ss_prob;
+    const float* gate;         // [B] explicit uniforms for this step, or nullptr -> Philox (RNG_SS_GATE)
+    const float* draw;         // [B] explicit uniforms for the inverse-CDF draw, or nullptr -> Philox (RNG_SS_DRAW)
+    const uint64_t* seed_p;
+    int64_t* tok;              // [B] tokens fed at step t (in: caption tokens; out: mixed)
+};
+__global__ __launch_bounds__(SEL_THREADS) void ss_select_kernel(SsSelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float srow[];
+    __shared__ float smf[16];
+    __shared__ double smd[16];
+    __shared__ int smi[16];
+    constexpr int NW = SEL_THREADS / 64;
+    const int row = blockIdx.x, tid = threadIdx.x;
+    const float g = a.gate ? a.gate[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row, RNG_SS_GATE);
+    if (!(g < a.ss_prob)) return;
+    const float* l = a.logits_prev + (size_t)row * a.ldl;
+    float mx = -INFINITY;
+    for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
+    mx = block_max_n(mx, smf, NW);
+    float se = 0.f;
+    for (int v = tid; v < a.V; v += SEL_THREADS) { const float e = expf(srow[v] - mx); srow[v] = e; se += e; }
+    se = block_sum_n(se, smf, NW);
+    for (int v = tid; v < a.V; v += SEL_THREADS) srow[v] = srow[v] / se;                  // torch.softmax
+    __syncthreads();
+    const float u = a.draw ? a.draw[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row, RNG_SS_DRAW);
+    const int d = block_inverse_cdf(srow, a.V, u, smd, smi);
+    if (tid == 0) a.tok[row] = d;
+}
 __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the row, then its probabilities
     __shared__ float smf[16];
@@ -509,44 +591,10 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     const float lse = logf(se);
     for (int v = tid; v < a.V; v += SEL_THREADS) srow[v] = expf((srow[v] - mx) - lse);     // p = exp(log_softmax)
     __syncthreads();
-    // contiguous slice per thread -> the global "first index above target" is the minimum over threads
-    const int per = (a.V + SEL_THREADS - 1) / SEL_THREADS;
-    const int v0 = min(a.V, tid * per), v1 = min(a.V, v0 + per);
-    double loc = 0.0;
-    for (int v = v0; v < v1; ++v) loc += (double)srow[v];
-    // exclusive prefix over the slice sums: wave-level inclusive scan (shuffles) + the wave totals
-    double inc = loc;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-        const double up = __shfl_up(inc, o, 64);
-        if ((tid & 63) >= o) inc += up;
-    }
-    if ((tid & 63) == 63) smd[tid >> 6] = inc;
-    __syncthreads();
-    double wave_off = 0.0, total = 0.0;
-    for (int w = 0; w < NW; ++w) {
-        if (w < (tid >> 6)) wave_off += smd[w];
-        total += smd[w];
-    }
-    const double prefix = wave_off + inc - loc;
     const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
-    const double target = (double)u * total;
-    int cand = 0x7fffffff;
-    {
-        double run = prefix;
-        for (int v = v0; v < v1; ++v) {
-            run += (double)srow[v];
-            if (run > target) { cand = v; break; }
-        }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
-    if ((tid & 63) == 0) smi[tid >> 6] = cand;
-    __syncthreads();
+    const int drawn = block_inverse_cdf(srow, a.V, u, smd, smi);
     if (tid == 0) {
-        int d = smi[0];
-        for (int w = 1; w < NW; ++w) d = min(d, smi[w]);
-        if (d > a.V - 1) d = a.V - 1;
+        const int d = drawn;
         const float lp = (l[d] - mx) - lse;
         bool unf = a.unfinished[row] != 0;
         unf = unf && (d != 2);

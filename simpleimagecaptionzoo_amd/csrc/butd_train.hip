@@ -290,7 +290,18 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     ICZ_CHECK_HIP(hipMemsetAsync(tb.logit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tb.tok);
     cur_captions = captions; cur_L = L;
-    for (int t = 0; t < T; ++t) ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
+    if (ss_prob > 0.f) ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * dims.V)));
+    for (int t = 0; t < T; ++t) {
+        if (t >= 2 && ss_prob > 0.f) {          // BUTD_Model.py:120-130: this step's tokens, mixed with draws from the previous step's logits
+            SsSelArgs sa = {};
+            sa.logits_prev = tb.logit + (size_t)(t - 1) * B * Vp; sa.ldl = (int)Vp; sa.V = dims.V; sa.t = t; sa.ss_prob = ss_prob;
+            sa.gate = ss_gate ? ss_gate + (size_t)t * B : nullptr;
+            sa.draw = ss_draw ? ss_draw + (size_t)t * B : nullptr;
+            sa.seed_p = d_seed; sa.tok = tb.tok + (size_t)t * B;
+            hipLaunchKernelGGL(ss_select_kernel, dim3(rows_t[t]), dim3(SEL_THREADS), sizeof(float) * dims.V, st, sa);
+        }
+        ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
+    }
     if (packed_out) {
         ICZ_TRY(upload_pack_index(st));
         hipLaunchKernelGGL(gather_packed_kernel, dim3(cdiv(dims.V, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, (int)Vp, B,
@@ -634,6 +645,13 @@ int icz_butd_xe_backward_dlogits(icz_butd_t* h, const float* dpacked, const icz_
 int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Butd*>(h)->sample_mask_sum(mask_sum_out, (hipStream_t)stream);
+}
+int icz_butd_set_scheduled_sampling(icz_butd_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms) {
+    ICZ_REQUIRE(h, "icz_butd_set_scheduled_sampling: null handle");
+    ICZ_REQUIRE(ss_prob >= 0.f && ss_prob <= 1.f, "icz_butd_set_scheduled_sampling: ss_prob %g outside [0, 1]", (double)ss_prob);
+    Butd* b = reinterpret_cast<Butd*>(h);
+    b->ss_prob = ss_prob; b->ss_gate = gate_uniforms; b->ss_draw = draw_uniforms;
+    return ICZ_OK;
 }
 int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L,
                         const int32_t* lengths_host, const icz_rng* rng, int32_t train, float* packed_logits_out,

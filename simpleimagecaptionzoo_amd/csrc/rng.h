@@ -6,7 +6,7 @@
 
 namespace icz {
 
-enum RngStream : uint32_t { RNG_EMB = 1, RNG_ATT = 2, RNG_OUT = 3, RNG_UNIFORM = 4 };
+enum RngStream : uint32_t { RNG_EMB = 1, RNG_ATT = 2, RNG_OUT = 3, RNG_UNIFORM = 4, RNG_SS_GATE = 5, RNG_SS_DRAW = 6 };
 
 struct uint4_ { uint32_t x, y, z, w; };
 
@@ -45,8 +45,8 @@ __host__ __device__ inline bool rng_keep(uint64_t seed, uint32_t stream, uint32_
 }
 
 // uniform in [0,1) with 24 random bits (one per (step, row))
-__host__ __device__ inline float rng_uniform(uint64_t seed, uint32_t step, uint64_t row) {
-    uint4_ c = {(uint32_t)row, (uint32_t)(row >> 32), step, (uint32_t)RNG_UNIFORM};
+__host__ __device__ inline float rng_uniform(uint64_t seed, uint32_t step, uint64_t row, uint32_t stream = RNG_UNIFORM) {
+    uint4_ c = {(uint32_t)row, (uint32_t)(row >> 32), step, stream};
     uint4_ r = philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
     return (float)(r.x >> 8) * (1.0f / 16777216.0f);
 }

@@ -158,6 +158,113 @@ def test_xe_forward_backward(golden_dir, name):
     _check_grads(grads, g, "xe_grad.")
 
 
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+def test_xe_with_scheduled_sampling(golden_dir, name):
+    """DecoderRNN.forward with the decoder's ss_prob = 0.5 (BUTD_Model.py:120-132): gate and draw uniforms injected,
+    packed logits / loss / gradients of the reference (the embedding gradient follows the tokens actually fed)."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    g = load(golden_dir, name)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    h, params = make_handle(g)
+    feats = torch.tensor(g["feats"], device="cuda")
+    em, am, om = _masks(g, "xe_", A)
+    rng = make_rng(0, None, em, am, om)
+    caps = torch.tensor(g["xe_captions"], device="cuda")
+    lengths = g["xe_lengths"].tolist()
+    h.set_scheduled_sampling(float(g["ss_prob"]), g["ss_gate"], g["ss_draw"].astype(np.float32))
+    logits = h.xe_forward(feats, caps, lengths, rng, train=True, want_logits=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), g["ss_packed_logits"], atol=2e-4, rtol=1e-4)
+    grads = h.new_grads()
+    loss = h.xe_backward(grads, smoothing=0.1)
+    torch.cuda.synchronize()
+    assert abs(loss.item() - float(g["ss_loss"])) < 1e-4
+    _check_grads(grads, g, "ss_grad.")
+    # switched off again: the plain XE golden
+    h.set_scheduled_sampling(0.0)
+    logits = h.xe_forward(feats, caps, lengths, rng, train=True, want_logits=True)
+    torch.cuda.synchronize()
+    np.testing.assert_allclose(logits.cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+
+
+def test_scheduled_sampling_generator_path_matches_oracle(golden_dir):
+    """Library-generated gate / draw uniforms (Philox streams 5 and 6): regenerate them on the host, run the oracle with
+    them and compare logits, loss and gradients; ss_prob = 1 replaces every token from step 2 on."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from test_gpu_fullsize import _philox4x32_10
+
+    def uniforms(seed, stream, T, B):       # csrc/rng.h rng_uniform: counter (row, 0, step, stream), top 24 bits of word 0
+        rows = np.arange(B)
+        return np.stack([(_philox4x32_10(rows, np.zeros(B), np.full(B, t), np.full(B, stream), seed & 0xFFFFFFFF, seed >> 32)[0]
+                          >> np.uint64(8)).astype(np.float32) / np.float32(16777216.0) for t in range(T)])
+    g = load(golden_dir, "butd_dec_tiny")
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    h, params = make_handle(g)
+    feats = torch.tensor(g["feats"], device="cuda")
+    em, am, om = _masks(g, "xe_", A)
+    seed = 0xC0FFEE
+    rng = make_rng(seed, None, em, am, om)
+    caps = torch.tensor(g["xe_captions"], device="cuda")
+    lengths = g["xe_lengths"].tolist()
+    T = max(lengths)
+    for prob in (0.3, 1.0):
+        h.set_scheduled_sampling(prob)
+        logits = h.xe_forward(feats, caps, lengths, rng, train=True, want_logits=True)
+        grads = h.new_grads()
+        loss = h.xe_backward(grads, smoothing=0.1)
+        torch.cuda.synchronize()
+        gate, draw = uniforms(seed, 5, T, B), uniforms(seed, 6, T, B)
+        p = ob.to_params(sd_of(g), requires_grad=True)
+        att = np.unpackbits(g["xe_att_mask"], axis=-1)[..., :A]
+        toks = []
+        ref = ob.forward_xe(torch.from_numpy(g["feats"]), torch.from_numpy(g["xe_captions"]), lengths, p, g["xe_emb_mask"], att,
+                            g["xe_out_mask"], ss_prob=prob, ss_gate=gate, ss_draw=draw, tokens_out=toks)
+        if prob == 1.0:
+            assert all(not np.array_equal(it.numpy(), g["xe_captions"][: it.shape[0], t]) for t, it in enumerate(toks) if t >= 2)
+        np.testing.assert_allclose(logits.cpu().numpy(), ref.detach().numpy(), atol=2e-4, rtol=1e-4)
+        tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+        rl = ob.label_smoothing_loss(ref, tgt, 0.1)
+        assert abs(loss.item() - rl.item()) < 1e-4
+        rl.backward()
+        for k, v in p.items():
+            np.testing.assert_allclose(grads[k].cpu().numpy(), v.grad.numpy(), atol=2e-4, rtol=2e-3, err_msg=k)
+    h.set_scheduled_sampling(0.0)
+
+
+def test_captioner_ss_prob_attribute_reaches_the_decoder(golden_dir):
+    """Engine.py:143 sets `model.ss_prob`; on this Captioner the attribute drives the XE forward (autograd path of the
+    reference's own training_epoch): packed logits and parameter gradients of the scheduled-sampling golden."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.captioner import BUTDDetection_Captioner
+    g = load(golden_dir, "butd_dec_tiny")
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    cap = BUTDDetection_Captioner(A, E, H, V, device="cuda:0", enc_dim=D, num_regions=R, max_batch=B)
+    cap.load_state_dict({"decoder." + k: torch.tensor(v) for k, v in sd_of(g).items()}, strict=True)
+    cap.to("cuda").train()
+    em, am, om = _masks(g, "xe_", A)
+    rng = make_rng(0, None, em, am, om)
+    vi = {"bu_feats": torch.tensor(g["feats"], device="cuda"), "bu_bboxes": None, "bu_masks": None}
+    caps = torch.tensor(g["xe_captions"], device="cuda")
+    lengths = g["xe_lengths"].tolist()
+    pred = cap(vi, caps, lengths, rng=rng)
+    np.testing.assert_allclose(pred[0].detach().cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+    cap.ss_prob = float(g["ss_prob"])
+    cap.set_scheduled_sampling_draws(g["ss_gate"], g["ss_draw"].astype(np.float32))
+    cap.zero_grad()
+    pred = cap(vi, caps, lengths, rng=rng)
+    np.testing.assert_allclose(pred[0].detach().cpu().numpy(), g["ss_packed_logits"], atol=2e-4, rtol=1e-4)
+    lp = torch.log_softmax(pred[0], dim=-1)
+    tgt = torch.tensor(g["xe_packed_targets"], device="cuda")
+    true = torch.full_like(lp, 0.1 / (V - 1)).scatter_(1, tgt.unsqueeze(1), 0.9)
+    loss = torch.nn.functional.kl_div(lp, true, reduction="none").sum(1).sum() / lp.size(0)
+    loss.backward()
+    assert abs(loss.item() - float(g["ss_loss"])) < 1e-4
+    _check_grads({k: p_.grad for k, p_ in cap.decoder.named_parameters()}, g, "ss_grad.")
+    cap.ss_prob = 0.0
+    pred = cap(vi, caps, lengths, rng=rng)
+    np.testing.assert_allclose(pred[0].detach().cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+
+
 def _beam_regime_sd(g, regime):
     sd = {k: v.copy() for k, v in sd_of(g).items()}
     if regime == "early":
