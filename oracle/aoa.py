@@ -129,15 +129,22 @@ def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True, lens=None)
     return seq, torch.stack(lps, 1)
 
 
-def forward_xe(feats, captions, lengths, p, masks=None, lens=None):
+def forward_xe(feats, captions, lengths, p, masks=None, lens=None, ss_prob=0.0, ss_gate=None, ss_draw=None, tokens_out=None):
+    """AoA_Decoder.forward behind the Captioner, AoA_Model.py:229-293.  ss_prob > 0: scheduled sampling (:258-270) through
+    oracle.butd.scheduled_tokens."""
+    from .butd import scheduled_tokens
     enc = refine(feats, p, masks, lens)
     B, R, Hd = enc.shape
     bu = key_mask(lens, R)
     meanf, st = masked_mean(enc, bu), _zero(B, Hd)
     rows = []
+    logits = None
     for t in range(max(lengths)):
         bt = sum(l > t for l in lengths)
-        logits, _, st = dec_step(captions[:bt, t], tuple(s[:bt] for s in st), enc[:bt], meanf[:bt], p, _step_masks(masks, t, bt),
+        it = scheduled_tokens(captions, t, bt, logits, ss_prob, ss_gate, ss_draw)
+        if tokens_out is not None:
+            tokens_out.append(it.clone())
+        logits, _, st = dec_step(it, tuple(s[:bt] for s in st), enc[:bt], meanf[:bt], p, _step_masks(masks, t, bt),
                                  None if bu is None else bu[:bt])
         rows.append(logits)
     return torch.cat(rows, 0)

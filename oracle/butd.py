@@ -172,6 +172,19 @@ def packed_order(lengths):
     return [(b, t) for t in range(max(lengths)) for b in range(len(lengths)) if lengths[b] > t]
 
 
+def scheduled_tokens(captions, t, bt, prev_logits, ss_prob, ss_gate, ss_draw):
+    """Tokens fed at XE time step t (the block shared by BUTD_Model.py:120-132, AoA_Model.py:258-270, NIC_Model.py:77-89):
+    the caption's, except that from step 2 on a row whose gate uniform is below ss_prob feeds a draw from
+    softmax(previous logits) (inverse_cdf_draw with ss_draw[t]; detached)."""
+    it = captions[:bt, t]
+    if t >= 2 and ss_prob > 0.0:
+        gate = torch.as_tensor(ss_gate[t][:bt], dtype=torch.float32) < ss_prob
+        if bool(gate.any()):
+            draw = inverse_cdf_draw(torch.softmax(prev_logits.detach()[:bt], dim=1), ss_draw[t][:bt])
+            it = torch.where(gate, draw, it)
+    return it
+
+
 def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_masks=None, ss_prob=0.0, ss_gate=None,
                ss_draw=None, tokens_out=None):
     """DecoderRNN.forward, BUTD_Model.py:97-151.  Returns packed logits (sum(lengths), V).
@@ -188,12 +201,7 @@ def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_
         m = (None if emb_masks is None else torch.as_tensor(emb_masks[t][:bt]),
              None if att_masks is None else torch.as_tensor(att_masks[t][:bt]),
              None if out_masks is None else torch.as_tensor(out_masks[t][:bt]))
-        it = captions[:bt, t]
-        if t >= 2 and ss_prob > 0.0:
-            gate = torch.as_tensor(ss_gate[t][:bt], dtype=torch.float32) < ss_prob
-            if bool(gate.any()):
-                draw = inverse_cdf_draw(torch.softmax(logits.detach()[:bt], dim=1), ss_draw[t][:bt])
-                it = torch.where(gate, draw, it)
+        it = scheduled_tokens(captions, t, bt, logits, ss_prob, ss_gate, ss_draw)
         if tokens_out is not None:
             tokens_out.append(it.clone())
         logits, _, st = step(feats[:bt], mean[:bt], it, tuple(s[:bt] for s in st), p, m)

@@ -85,13 +85,19 @@ def beam_search(feats1, p, k, max_steps=50):
     return seqs[int(run.view(-1).argmax())].view(1, -1).float()
 
 
-def forward_xe(feats, captions, lengths, p, out_masks=None):
-    """DecoderRNN.forward, NIC_Model.py:58-98 (ss_prob = 0) -> packed logits (sum(lengths), V)."""
+def forward_xe(feats, captions, lengths, p, out_masks=None, ss_prob=0.0, ss_gate=None, ss_draw=None, tokens_out=None):
+    """DecoderRNN.forward, NIC_Model.py:58-98 -> packed logits (sum(lengths), V).  ss_prob > 0: scheduled sampling
+    (:77-89) through oracle.butd.scheduled_tokens."""
+    from .butd import scheduled_tokens
     h, c = init_state(feats, p)
     rows = []
+    logits = None
     for t in range(max(lengths)):
         bt = sum(l > t for l in lengths)
         m = None if out_masks is None else torch.as_tensor(out_masks[t][:bt])
-        logits, h, c = step(captions[:bt, t], h[:bt], c[:bt], p, m)
+        it = scheduled_tokens(captions, t, bt, logits, ss_prob, ss_gate, ss_draw)
+        if tokens_out is not None:
+            tokens_out.append(it.clone())
+        logits, h, c = step(it, h[:bt], c[:bt], p, m)
         rows.append(logits)
     return torch.cat(rows, 0)

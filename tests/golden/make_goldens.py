@@ -471,6 +471,31 @@ def gen_nic_decoder(tag, B, H, E, V, seed):
                xe_dfeats=f_xe.grad.numpy().copy())
     for n_, p in dec.named_parameters():
         out["xe_grad." + n_] = p.grad.detach().numpy().copy()
+    # XE with scheduled sampling switched on in the decoder (NIC_Model.py:79-89), own random stream
+    ss_rs = np.random.RandomState(seed + 4242)
+    ss_gate = ss_rs.rand(T, B).astype(np.float32)
+    ss_draw = ss_rs.rand(T, B)
+    dec.train()
+    dec.zero_grad()
+    dec.ss_prob = 0.5
+    f_ss = feats.clone().requires_grad_(True)
+    INJ.set([xe_out_mask], None)
+    toks = []
+    hk = dec.embed.register_forward_hook(lambda m, i, o: toks.append(i[0].detach().clone()))
+    with injected(), scheduled_sampling_draws(ss_gate, ss_draw):
+        ss_packed = dec(f_ss, captions, lengths)
+    hk.remove()
+    dec.ss_prob = 0.0
+    ss_loss = LabelSmoothingLoss(smoothing=0.1)(ss_packed[0], targets[0])
+    ss_loss.backward()
+    ss_tok = np.zeros((T, B), dtype=np.int64)
+    for t_, it_ in enumerate(toks):
+        ss_tok[t_, : it_.shape[0]] = it_.numpy()
+    out.update(ss_prob=np.float32(0.5), ss_gate=ss_gate, ss_draw=ss_draw, ss_tokens=ss_tok,
+               ss_packed_logits=ss_packed[0].detach().numpy(), ss_loss=np.float32(ss_loss.item()),
+               ss_dfeats=f_ss.grad.numpy().copy())
+    for n_, p in dec.named_parameters():
+        out["ss_grad." + n_] = p.grad.detach().numpy().copy()
     # sample_rl
     T = 20
     rl_out_mask = (rng.rand(T, B, H) < 0.5).astype(np.uint8)
@@ -624,6 +649,33 @@ def gen_aoa(tag, B, Hd, E, V, seed, counts=None):
                xe_loss=np.float32(loss.item()))
     for n_, p_ in dec.named_parameters():
         out["xe_grad." + n_] = p_.grad.detach().numpy().copy()
+    # ---- XE with scheduled sampling switched on in the decoder (AoA_Model.py:260-270); the dropout masks are the XE run's
+    #      (same seed, same call order), the gate / draw uniforms come from their own stream
+    T_xe = max(lengths)
+    ss_rs = np.random.RandomState(seed + 4242)
+    ss_gate = ss_rs.rand(T_xe, B).astype(np.float32)
+    ss_draw = ss_rs.rand(T_xe, B)
+    m.train()
+    m.zero_grad()
+    dec.ss_prob = 0.5
+    INJ.set_sequential(seed * 7 + 1)
+    toks = []
+    hk = dec.embed.register_forward_hook(lambda mod, i, o: toks.append(i[0].detach().clone()))
+    with injected(), scheduled_sampling_draws(ss_gate, ss_draw):
+        ss_packed = m(vi, captions, lengths)
+    hk.remove()
+    dec.ss_prob = 0.0
+    ss_mk, _ = split_masks(INJ.rec, T_xe)
+    assert all(np.array_equal(ss_mk[k], mk[k]) for k in mk)
+    ss_loss = LabelSmoothingLoss(smoothing=0.1)(ss_packed[0], targets[0])
+    ss_loss.backward()
+    ss_tok = np.zeros((T_xe, B), dtype=np.int64)
+    for t_, it_ in enumerate(toks):
+        ss_tok[t_, : it_.shape[0]] = it_.numpy()
+    out.update(ss_prob=np.float32(0.5), ss_gate=ss_gate, ss_draw=ss_draw, ss_tokens=ss_tok,
+               ss_packed_logits=ss_packed[0].detach().numpy(), ss_loss=np.float32(ss_loss.item()))
+    for n_, p_ in dec.named_parameters():
+        out["ss_grad." + n_] = p_.grad.detach().numpy().copy()
     # ---- sample_rl + REINFORCE
     T = 20
     rl_u = rng.rand(T, B)

@@ -272,6 +272,27 @@ def test_nic_greedy_and_beam(nic):
         assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img)
 
 
+def test_nic_xe_with_scheduled_sampling(nic):
+    """NIC DecoderRNN.forward with the decoder's ss_prob = 0.5 (NIC_Model.py:77-89)."""
+    on_, g, _, feats = nic
+    p = ob.to_params(sd_of(g), requires_grad=True)
+    f = feats.clone().requires_grad_(True)
+    lengths = g["xe_lengths"].tolist()
+    toks = []
+    logits = on_.forward_xe(f, torch.from_numpy(g["xe_captions"]), lengths, p, g["xe_out_mask"], ss_prob=float(g["ss_prob"]),
+                            ss_gate=g["ss_gate"], ss_draw=g["ss_draw"], tokens_out=toks)
+    for t, it in enumerate(toks):
+        assert np.array_equal(it.numpy(), g["ss_tokens"][t, : it.shape[0]]), t
+    np.testing.assert_allclose(logits.detach().numpy(), g["ss_packed_logits"], atol=1e-4)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["ss_loss"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        np.testing.assert_allclose(v.grad.numpy(), g["ss_grad." + k], atol=2e-5, rtol=1e-4, err_msg=k)
+    np.testing.assert_allclose(f.grad.numpy(), g["ss_dfeats"], atol=2e-5, rtol=1e-4)
+
+
 def test_nic_xe_and_rl_grads(nic):
     on_, g, _, feats = nic
     B, H, E, V = g["dims"]
@@ -364,6 +385,26 @@ def test_aoa_refiner_greedy_beam(aoa):
         if counts is not None and k == 3:        # the padded image with its mask decodes the same
             got = oa.beam_search(feats[img:img + 1], q, k, lens=counts[img:img + 1]).numpy()
             assert got.shape == want.shape and np.array_equal(got, want), (regime, k, img, "masked")
+
+
+def test_aoa_xe_with_scheduled_sampling(aoa):
+    """AoA_Decoder.forward with the decoder's ss_prob = 0.5 (AoA_Model.py:258-270), fixed and adaptive regions."""
+    oa, g, feats, counts = aoa
+    p = aoa_params(g, True)
+    lengths = g["xe_lengths"].tolist()
+    toks = []
+    logits = oa.forward_xe(feats, torch.from_numpy(g["xe_captions"]), lengths, p, aoa_masks(g, "xe_mask."), lens=counts,
+                           ss_prob=float(g["ss_prob"]), ss_gate=g["ss_gate"], ss_draw=g["ss_draw"], tokens_out=toks)
+    for t, it in enumerate(toks):
+        assert np.array_equal(it.numpy(), g["ss_tokens"][t, : it.shape[0]]), t
+    np.testing.assert_allclose(logits.detach().numpy(), g["ss_packed_logits"], atol=1e-4)
+    tgt = torch.tensor([g["xe_captions"][b, t + 1] for b, t in ob.packed_order(lengths)])
+    loss = ob.label_smoothing_loss(logits, tgt, 0.1)
+    assert abs(loss.item() - float(g["ss_loss"])) < TOL
+    loss.backward()
+    for k, v in p.items():
+        if k.startswith("decoder."):
+            np.testing.assert_allclose(v.grad.numpy(), g["ss_grad." + k[8:]], atol=2e-5, rtol=1e-4, err_msg=k)
 
 
 def test_aoa_xe_and_rl_decoder_grads(aoa):
