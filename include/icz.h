@@ -188,6 +188,8 @@ int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* capti
                        const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream);
 int icz_nic_xe_backward(icz_nic_t* h, float smoothing, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
                         float n_tokens_global, void* stream);
+/* Scheduled sampling for the following icz_nic_xe_forward calls (NIC_Model.py:77-89): see icz_butd_set_scheduled_sampling. */
+int icz_nic_set_scheduled_sampling(icz_nic_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
 /* DecoderRNN.beam_search_sample, NIC_Model.py:153-212 (batched over images) */
 int icz_nic_beam_search(icz_nic_t* h, const float* features, int32_t n_img, int32_t beam, int32_t max_steps, float* seqs_out,
                         int32_t* lens_out, void* stream);
@@ -255,6 +257,8 @@ int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions
                        const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream);
 int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global,
                         void* stream);
+/* Scheduled sampling for the following icz_aoa_xe_forward calls (AoA_Model.py:258-270): see icz_butd_set_scheduled_sampling. */
+int icz_aoa_set_scheduled_sampling(icz_aoa_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Optimiser step: clip_gradient (Utils.py:241-250, value clamp) + torch.optim.Adam(betas=(0.9,0.999),

@@ -130,6 +130,8 @@ def lib():
         "icz_butd_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_butd_xe_backward": (C.c_int, [vp, f32, C.POINTER(ButdParams), vp, f32, vp]),
         "icz_butd_set_scheduled_sampling": (C.c_int, [vp, f32, vp, vp]),
+        "icz_nic_set_scheduled_sampling": (C.c_int, [vp, f32, vp, vp]),
+        "icz_aoa_set_scheduled_sampling": (C.c_int, [vp, f32, vp, vp]),
         "icz_adam_clamp_step": (C.c_int, [vp, vp, vp, vp, i64, f32, f32, i32, vp]),
         "icz_nic_create": (C.c_int, [C.POINTER(NicDims), C.POINTER(vp)]),
         "icz_nic_destroy": (C.c_int, [vp]),

@@ -11,6 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import _lib
+from .scheduled import ScheduledSamplingState, handle_set_scheduled_sampling
 from ._lib import AOA_DECODER_KEYS, AOA_PARAM_KEYS, AoaDims, AoaParams, AoaRng, check, lib, ptr, stream_ptr
 
 _MASKS = ("proj", "ref_att", "ref_aoa", "ref_sc", "emb", "ctx", "att", "out")
@@ -190,6 +191,10 @@ class AoaHandle:
         check(lib().icz_aoa_sample_backward(self._h, ptr(reward), C.byref(gs), ptr(loss), ptr(msum), float(mask_sum_global), stream_ptr()))
         return loss, msum
 
+    def set_scheduled_sampling(self, ss_prob, gate=None, draw=None):
+        """Scheduled sampling for the following xe_forward calls (AoA_Model.py:258-270 with the decoder's `ss_prob`)."""
+        handle_set_scheduled_sampling(self, "icz_aoa_set_scheduled_sampling", ss_prob, gate, draw)
+
     def xe_forward(self, feats, captions, lengths, rng=None, train=True, want_logits=False):
         feats = self._feats(feats)
         B, L = captions.shape
@@ -233,7 +238,7 @@ class _RefineLayer(nn.Module):
         self.sublayer.norm = _Norm(d)
 
 
-class AoADetection_Captioner(nn.Module):
+class AoADetection_Captioner(nn.Module, ScheduledSamplingState):
     """AoADetection_Captioner (Models/AoA_Model.py:657-753) on libicz: same constructor arguments, state_dict and methods;
     every forward / sampling / search path runs in the HIP library (no torch compute, no CPU fallback)."""
 
@@ -264,6 +269,7 @@ class AoADetection_Captioner(nn.Module):
         self.max_rows, self.max_len = max_batch * max(1, max_beam), max_len
         self._h, self._bound = None, None
         self._seed = 0x5EED
+        self._ss_init()                 # ss_prob (Engine.py:143) and its plumbing: scheduled.py
 
     def _named(self):
         sd = dict(self.named_parameters())
@@ -283,15 +289,18 @@ class AoADetection_Captioner(nn.Module):
         dev = next(iter(named.values())).device
         if dev.type != "cuda":
             raise RuntimeError("AoADetection_Captioner (libicz) needs its parameters on a ROCm device; got %s" % dev)
+        fresh = False
         if self._h is None or self._h.device != dev:
             R, D, Hd, E, V, NH = self.dims
             self._h = AoaHandle(R, D, Hd, E, V, NH, self.max_rows, max(self.max_len, 20), dev)
             self._bound = None
+            fresh = True
         if ptrs != self._bound:
             self._h.bind({k: p.data for k, p in named.items()})
             self._bound = ptrs
         else:
             self._h.refresh()
+        self._ss_push(self._h, fresh)
         return self._h
 
     @staticmethod

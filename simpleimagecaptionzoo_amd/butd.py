@@ -171,11 +171,8 @@ class ButdHandle:
     def set_scheduled_sampling(self, ss_prob, gate=None, draw=None):
         """Scheduled sampling for the following xe_forward calls (BUTD_Model.py:120-132 with the decoder's `ss_prob`):
         gate / draw are optional explicit uniforms [T, B] (parity tests), default Philox."""
-        keep = []
-        for u in (gate, draw):
-            keep.append(None if u is None else torch.as_tensor(u, dtype=torch.float32).to(self.device).contiguous())
-        check(lib().icz_butd_set_scheduled_sampling(self._h, float(ss_prob), ptr(keep[0]), ptr(keep[1])))
-        self._ss_live = keep
+        from .scheduled import handle_set_scheduled_sampling
+        handle_set_scheduled_sampling(self, "icz_butd_set_scheduled_sampling", ss_prob, gate, draw)
 
     def xe_backward(self, grads, smoothing=0.1, n_tokens_global=0.0):
         """LabelSmoothingLoss + backward (Utils.py:268-286) for the last xe_forward(); returns the loss."""

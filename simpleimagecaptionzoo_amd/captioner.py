@@ -14,6 +14,7 @@ import torch.nn as nn
 
 from ._lib import BUTD_PARAM_KEYS
 from .butd import ButdHandle, make_rng
+from .scheduled import ScheduledSamplingState
 
 
 class _Holder(nn.Module):
@@ -93,7 +94,7 @@ class _XEFunction(torch.autograd.Function):
         return (None, None, None, None, None, None) + tuple(grads[k] for k in BUTD_PARAM_KEYS)
 
 
-class BUTDDetection_Captioner(nn.Module):
+class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
     """Models/BUTD_Model.py:443-544 on libicz.  enc_dim / num_regions default to the bottom-up 36 x 2048 layout
     (49 regions = BUTDSpatial's 7x7 grid features, the same decoder, BUTD_Model.py:321-440)."""
 
@@ -106,12 +107,7 @@ class BUTDDetection_Captioner(nn.Module):
         self.dims = dict(R=num_regions, D=enc_dim, H=hidden_dim, E=embed_dim, A=atten_dim, V=vocab_size)
         self.max_rows = max_batch * max(1, max_beam)
         self.max_len = max_len
-        # Engine.py:143 sets this attribute per epoch; the reference decoder reads its own copy, which nothing updates
-        # (SURVEY.md 5), so with the reference's schedule settings it stays 0.  Here a non-zero value does what
-        # DecoderRNN.forward does when its `ss_prob` is set (BUTD_Model.py:120-132).
-        self.ss_prob = 0.0
-        self._ss_bound = (0.0, id(None), id(None))
-        self._ss_draws = (None, None)
+        self._ss_init()                 # ss_prob (Engine.py:143) and its plumbing: scheduled.py
         self._h = None
         self._bound_ptrs = None
         self._grads = None
@@ -129,28 +125,21 @@ class BUTDDetection_Captioner(nn.Module):
         named = self._named()
         ptrs = tuple(p.data_ptr() for p in named.values())
         dev = next(iter(named.values())).device
+        fresh = False
         if dev.type != "cuda":
             raise RuntimeError("BUTDDetection_Captioner (libicz) needs its parameters on a ROCm device; got %s" % dev)
         if self._h is None or self._h.device != dev:
             d = self.dims
             self._h = ButdHandle(d["R"], d["D"], d["H"], d["E"], d["A"], d["V"], self.max_rows, max(self.max_len, 20), dev)
             self._bound_ptrs = None
-            self._ss_bound = (0.0, id(None), id(None))
+            fresh = True
         if ptrs != self._bound_ptrs:
             self._h.bind({k: p.data for k, p in named.items()})
             self._bound_ptrs = ptrs
         else:
             self._h.refresh()
-        ss = (float(self.ss_prob), id(self._ss_draws[0]), id(self._ss_draws[1]))
-        if ss != self._ss_bound:
-            self._h.set_scheduled_sampling(float(self.ss_prob), *self._ss_draws)
-            self._ss_bound = ss
+        self._ss_push(self._h, fresh)
         return self._h
-
-    def set_scheduled_sampling_draws(self, gate=None, draw=None):
-        """Explicit uniforms [T, B] for the scheduled-sampling gate and draw of the next forward (parity tests);
-        None = the library's Philox streams."""
-        self._ss_draws = (gate, draw)
 
     def _grad_buffers(self):
         if self._grads is None or next(iter(self._grads.values())).device != next(self.parameters()).device:

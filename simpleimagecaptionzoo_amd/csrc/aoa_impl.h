@@ -65,6 +65,7 @@ struct Aoa {
     int64_t* it = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
     uint64_t* d_seed = nullptr; float* d_msum = nullptr;
+    float ss_prob = 0.f; const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // scheduled sampling in xe_forward
     BeamBuf bm;
     // training buffers (aoa_train.hip), slot stride = max_rows: th/tm/tctx slot 0 = zeros, slot t+1 = after step t
     bool tready = false;

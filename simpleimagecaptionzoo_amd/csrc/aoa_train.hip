@@ -374,6 +374,9 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
     ICZ_CHECK_HIP(hipMemsetAsync(tlogit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(aoa_captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tok);
     for (int t = 0; t < T; ++t) {
+        if (t >= 2 && ss_prob > 0.f)          // scheduled sampling (AoA_Model.py:258-270): this step's tokens, mixed with draws from the previous logits
+            ICZ_TRY(ss_select_launch(st, rows_t[t], tlogit + (size_t)(t - 1) * B * Vp, (int)Vp, dims.V, t, B, ss_prob, ss_gate, ss_draw, d_seed,
+                                     tok + (size_t)t * B));
         AoaStepIO io = train_io(rows_t[t], t, cur_train);
         io.u_ready = t > 0;             // the next step's rows are a prefix of this step's: its u comes from this step's GLU kernel
         if (t + 1 < T) { const AoaStepIO nx = train_io(rows_t[t + 1], t + 1, cur_train); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
@@ -552,6 +555,13 @@ int icz_aoa_sample_backward(icz_aoa_t* h, const float* reward, const icz_aoa_par
                             float mask_sum_global, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Aoa*>(h)->sample_backward(reward, grads, loss_out, mask_sum_out, mask_sum_global, (hipStream_t)stream);
+}
+int icz_aoa_set_scheduled_sampling(icz_aoa_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms) {
+    ICZ_REQUIRE(h, "null handle");
+    ICZ_REQUIRE(ss_prob >= 0.f && ss_prob <= 1.f, "icz_aoa_set_scheduled_sampling: ss_prob %g outside [0, 1]", (double)ss_prob);
+    Aoa* a = reinterpret_cast<Aoa*>(h);
+    a->ss_prob = ss_prob; a->ss_gate = gate_uniforms; a->ss_draw = draw_uniforms;
+    return ICZ_OK;
 }
 int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,
                        const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream) {

@@ -552,6 +552,23 @@ __global__ __launch_bounds__(SEL_THREADS) void ss_select_kernel(SsSelArgs a) {
     const int d = block_inverse_cdf(srow, a.V, u, smd, smi);
     if (tid == 0) a.tok[row] = d;
 }
+// tokens of XE step t (t >= 2) for the `rows` active rows; gate / draw: explicit [T, B] arrays or nullptr (Philox)
+inline int ss_select_launch(hipStream_t st, int rows, const float* logits_prev, int ldl, int V, int t, int B, float ss_prob,
+                            const float* gate, const float* draw, const uint64_t* seed_p, int64_t* tok_t) {
+    static bool lds_set = false;
+    if (!lds_set) {
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+        lds_set = true;
+    }
+    ICZ_REQUIRE(sizeof(float) * (size_t)V <= 159 * 1024, "scheduled sampling: a row of %d logits does not fit in LDS", V);
+    SsSelArgs sa = {};
+    sa.logits_prev = logits_prev; sa.ldl = ldl; sa.V = V; sa.t = t; sa.ss_prob = ss_prob;
+    sa.gate = gate ? gate + (size_t)t * B : nullptr;
+    sa.draw = draw ? draw + (size_t)t * B : nullptr;
+    sa.seed_p = seed_p; sa.tok = tok_t;
+    hipLaunchKernelGGL(ss_select_kernel, dim3(rows), dim3(SEL_THREADS), sizeof(float) * V, st, sa);
+    return ICZ_OK;
+}
 __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the row, then its probabilities
     __shared__ float smf[16];

@@ -290,16 +290,10 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     ICZ_CHECK_HIP(hipMemsetAsync(tb.logit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tb.tok);
     cur_captions = captions; cur_L = L;
-    if (ss_prob > 0.f) ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(ss_select_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)(sizeof(float) * dims.V)));
     for (int t = 0; t < T; ++t) {
-        if (t >= 2 && ss_prob > 0.f) {          // BUTD_Model.py:120-130: this step's tokens, mixed with draws from the previous step's logits
-            SsSelArgs sa = {};
-            sa.logits_prev = tb.logit + (size_t)(t - 1) * B * Vp; sa.ldl = (int)Vp; sa.V = dims.V; sa.t = t; sa.ss_prob = ss_prob;
-            sa.gate = ss_gate ? ss_gate + (size_t)t * B : nullptr;
-            sa.draw = ss_draw ? ss_draw + (size_t)t * B : nullptr;
-            sa.seed_p = d_seed; sa.tok = tb.tok + (size_t)t * B;
-            hipLaunchKernelGGL(ss_select_kernel, dim3(rows_t[t]), dim3(SEL_THREADS), sizeof(float) * dims.V, st, sa);
-        }
+        if (t >= 2 && ss_prob > 0.f)          // BUTD_Model.py:120-130: this step's tokens, mixed with draws from the previous step's logits
+            ICZ_TRY(ss_select_launch(st, rows_t[t], tb.logit + (size_t)(t - 1) * B * Vp, (int)Vp, dims.V, t, B, ss_prob, ss_gate, ss_draw,
+                                     d_seed, tb.tok + (size_t)t * B));
         ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
     }
     if (packed_out) {

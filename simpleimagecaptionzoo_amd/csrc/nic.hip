@@ -24,6 +24,7 @@ struct Nic {
     int64_t* it = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
     uint64_t* d_seed = nullptr; float* d_msum = nullptr;
+    float ss_prob = 0.f; const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // scheduled sampling in xe_forward
     // training buffers (slot stride = capacity rows): th/tc slot 0 = zeros, slot 1 = after the image step, slot t+2 =
     // after token step t; tg / dG slot 0 = image step, slot t+1 = token step t
     bool tready = false;
@@ -287,6 +288,8 @@ int Nic::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
     ICZ_TRY(image_step(feats, B, th + sH, tc + sH, tg, st));
     for (int t = 0; t < T; ++t) {
         const size_t slot = (size_t)t * B;
+        if (t >= 2 && ss_prob > 0.f)          // NIC_Model.py:77-89
+            ICZ_TRY(ss_select_launch(st, rows_t[t], tlogit + (slot - B) * Vp, (int)Vp, dims.V, t, B, ss_prob, ss_gate, ss_draw, d_seed, tok + slot));
         ICZ_TRY(token_step(rows_t[t], tok + slot, false, th + (slot + B) * H, tc + (slot + B) * H, th + (slot + 2 * B) * H,
                            tc + (slot + 2 * B) * H, temb + slot * E, tg + (slot + B) * 4 * H, thd + slot * H, tlogit + slot * Vp,
                            nic_drop(d_seed, train != 0, rng.out_mask, sH, t), st));
@@ -502,6 +505,13 @@ int icz_nic_sample_backward(icz_nic_t* h, const float* reward, const icz_nic_par
                             float* mask_sum_out, float mask_sum_global, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Nic*>(h)->sample_backward(reward, grads, dfeatures_out, loss_out, mask_sum_out, mask_sum_global, (hipStream_t)stream);
+}
+int icz_nic_set_scheduled_sampling(icz_nic_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms) {
+    ICZ_REQUIRE(h, "null handle");
+    ICZ_REQUIRE(ss_prob >= 0.f && ss_prob <= 1.f, "icz_nic_set_scheduled_sampling: ss_prob %g outside [0, 1]", (double)ss_prob);
+    Nic* n = reinterpret_cast<Nic*>(h);
+    n->ss_prob = ss_prob; n->ss_gate = gate_uniforms; n->ss_draw = draw_uniforms;
+    return ICZ_OK;
 }
 int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* captions, int32_t B, int32_t L, const int32_t* lengths_host,
                        const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream) {

@@ -7,6 +7,7 @@ import torch.nn as nn
 from . import _lib
 from ._lib import NIC_PARAM_FIELDS, NIC_PARAM_KEYS, NicDims, NicParams, check, lib, ptr, stream_ptr
 from .butd import make_rng
+from .scheduled import ScheduledSamplingState, handle_set_scheduled_sampling
 
 
 class NicHandle:
@@ -100,6 +101,10 @@ class NicHandle:
                                             float(mask_sum_global), stream_ptr()))
         return (loss, msum, dfe) if want_dfeats else (loss, msum)
 
+    def set_scheduled_sampling(self, ss_prob, gate=None, draw=None):
+        """Scheduled sampling for the following xe_forward calls (NIC_Model.py:77-89 with the decoder's `ss_prob`)."""
+        handle_set_scheduled_sampling(self, "icz_nic_set_scheduled_sampling", ss_prob, gate, draw)
+
     def xe_forward(self, feats, captions, lengths, rng=None, train=True, want_logits=False):
         feats = self._feats(feats)
         B, L = captions.shape
@@ -131,7 +136,7 @@ class NicHandle:
         return seqs, lens
 
 
-class NICDecoder_Captioner(nn.Module):
+class NICDecoder_Captioner(nn.Module, ScheduledSamplingState):
     """The decoder half of NIC_Captioner (Models/NIC_Model.py:214-332) on libicz.  The CNN encoder + img_embedding
     (NIC_Model.py:8-37) is outside the hot path: pass its output as visual_inputs['img_feats'] (B, embed_dim), or
     supply `encoder` (any nn.Module mapping visual_inputs['img_tensors'] to that embedding)."""
@@ -161,7 +166,7 @@ class NICDecoder_Captioner(nn.Module):
         self.max_rows, self.max_len = max_batch * max(1, max_beam), max_len
         self._h, self._bound = None, None
         self._seed = 0x5EED
-        self.ss_prob = 0.0
+        self._ss_init()                 # ss_prob (Engine.py:143) and its plumbing: scheduled.py
 
     def _named(self):
         sd = dict(self.decoder.named_parameters())
@@ -173,15 +178,18 @@ class NICDecoder_Captioner(nn.Module):
         dev = next(iter(named.values())).device
         if dev.type != "cuda":
             raise RuntimeError("NICDecoder_Captioner (libicz) needs its parameters on a ROCm device; got %s" % dev)
+        fresh = False
         if self._h is None or self._h.device != dev:
             E, H, V = self.dims
             self._h = NicHandle(E, H, V, self.max_rows, max(self.max_len, 20), dev)
             self._bound = None
+            fresh = True
         if ptrs != self._bound:
             self._h.bind({k: p.data for k, p in named.items()})
             self._bound = ptrs
         else:
             self._h.refresh()
+        self._ss_push(self._h, fresh)
         return self._h
 
     def _next_rng(self):

@@ -95,6 +95,24 @@ def test_aoa_xe_logits_loss_and_decoder_grads(g):
     check_grads(grads, g, "xe_grad.")
 
 
+def test_aoa_xe_with_scheduled_sampling(g):
+    """AoA_Decoder.forward with the decoder's ss_prob = 0.5 (AoA_Model.py:258-270), gate / draw uniforms injected; the
+    Captioner attribute drives the same path."""
+    h = make(g)
+    feats = feats_of(g)
+    caps, lengths = torch.tensor(g["xe_captions"], device="cuda"), g["xe_lengths"].tolist()
+    h.set_scheduled_sampling(float(g["ss_prob"]), g["ss_gate"], g["ss_draw"].astype(np.float32))
+    logits = h.xe_forward(feats, caps, lengths, rng_of(g, "xe_mask."), True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["ss_packed_logits"], atol=2e-4, rtol=1e-4)
+    grads = h.new_grads()
+    loss = h.xe_backward(grads, 0.1)
+    assert abs(loss.item() - float(g["ss_loss"])) < 1e-4
+    check_grads(grads, g, "ss_grad.")
+    h.set_scheduled_sampling(0.0)
+    logits = h.xe_forward(feats, caps, lengths, rng_of(g, "xe_mask."), True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+
+
 def test_aoa_sample_rl_and_reinforce_grads(g):
     sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
     sd["decoder.predict.bias"][2] = float(g["rl_end_bias"])

@@ -90,6 +90,28 @@ def test_nic_xe_and_reinforce_gradients(golden_dir, name):
     np.testing.assert_allclose(dfe.cpu().numpy(), g["rl_dfeats"], atol=2e-5, rtol=2e-4)
 
 
+@pytest.mark.parametrize("name", ["nic_dec_tiny", "nic_dec_odd"])
+def test_nic_xe_with_scheduled_sampling(golden_dir, name):
+    """NIC DecoderRNN.forward with the decoder's ss_prob = 0.5 (NIC_Model.py:77-89), gate / draw uniforms injected."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    g = load(golden_dir, name)
+    feats = torch.tensor(g["feats"], device="cuda")
+    h = make(g)
+    rng = make_rng(0, None, None, None, torch.tensor(g["xe_out_mask"], device="cuda"))
+    caps, lengths = torch.tensor(g["xe_captions"], device="cuda"), g["xe_lengths"].tolist()
+    h.set_scheduled_sampling(float(g["ss_prob"]), g["ss_gate"], g["ss_draw"].astype(np.float32))
+    logits = h.xe_forward(feats, caps, lengths, rng, True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["ss_packed_logits"], atol=2e-4, rtol=1e-4)
+    grads = h.new_grads()
+    loss, dfe = h.xe_backward(grads, 0.1, want_dfeats=True)
+    assert abs(loss.item() - float(g["ss_loss"])) < 1e-4
+    check_grads(grads, g, "ss_grad.")
+    np.testing.assert_allclose(dfe.cpu().numpy(), g["ss_dfeats"], atol=2e-5, rtol=2e-4)
+    h.set_scheduled_sampling(0.0)
+    logits = h.xe_forward(feats, caps, lengths, rng, True, True)
+    np.testing.assert_allclose(logits.cpu().numpy(), g["xe_packed_logits"], atol=2e-4, rtol=1e-4)
+
+
 def test_nic_captioner_state_dict_keys(golden_dir):
     from simpleimagecaptionzoo_amd.nic import NICDecoder_Captioner
     g = load(golden_dir, "nic_dec_tiny")
