@@ -1,9 +1,10 @@
 """Scheduled sampling in the XE forward (BUTD_Model.py:120-132, AoA_Model.py:258-270, NIC_Model.py:77-89).
 
-The reference's epoch driver raises `model.ss_prob` per epoch (Engine.py:140-144) but sets it on the Captioner while each
-DecoderRNN reads its own attribute, so the reference's runs never leave ss_prob = 0.  Here the Captioner attribute is
-what the device path reads: 0 (the default, and the reference's live behaviour) keeps teacher forcing; a positive value
-does what DecoderRNN.forward does when its own `ss_prob` is set."""
+The reference's epoch driver raises `model.ss_prob` per epoch (Engine.py:140-144, on by default: Main.py:166-169) but sets
+it on the Captioner while each DecoderRNN reads its own attribute, so the reference's runs never leave teacher forcing.
+The drop-in default is therefore the same: the Captioner accepts the attribute and ignores it.  `scheduled_sampling =
+True` on the Captioner makes the attribute live: the device path then does what DecoderRNN.forward does when its own
+`ss_prob` is set (pinned by goldens generated from the reference decoders with exactly that attribute set)."""
 import torch
 
 from ._lib import check, lib, ptr
@@ -26,11 +27,12 @@ def scheduled_sampling_prob(epoch, ss_opts):
 
 
 class ScheduledSamplingState:
-    """Captioner side: the `ss_prob` attribute Engine.py:143 sets, optional explicit draws (parity tests), and the push of
-    both to the device handle whenever they changed."""
+    """Captioner side: the `ss_prob` attribute Engine.py:143 sets, the `scheduled_sampling` switch that makes it live,
+    optional explicit draws (parity tests), and the push of the effective value to the device handle when it changed."""
 
     def _ss_init(self):
         self.ss_prob = 0.0
+        self.scheduled_sampling = False          # False: `ss_prob` is ignored, as in the reference's own runs
         self._ss_draws = (None, None)
         self._ss_bound = None
 
@@ -41,7 +43,8 @@ class ScheduledSamplingState:
     def _ss_push(self, handle, fresh_handle=False):
         off = (0.0, id(None), id(None))                     # a new handle starts switched off
         bound = off if (fresh_handle or self._ss_bound is None) else self._ss_bound
-        key = (float(self.ss_prob), id(self._ss_draws[0]), id(self._ss_draws[1]))
+        prob = float(self.ss_prob) if self.scheduled_sampling else 0.0
+        key = (prob, id(self._ss_draws[0]), id(self._ss_draws[1]))
         if key != bound:
-            handle.set_scheduled_sampling(float(self.ss_prob), *self._ss_draws)
+            handle.set_scheduled_sampling(prob, *self._ss_draws)
         self._ss_bound = key

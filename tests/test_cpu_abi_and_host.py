@@ -207,7 +207,10 @@ def test_scheduled_sampling_schedule_and_captioner_plumbing():
     h = Handle()
     st._ss_push(h, True)
     assert h.calls == []                      # a new handle is off already
-    st.ss_prob = 0.25                         # what Engine.py:143 does
+    st.ss_prob = 0.25                         # what Engine.py:143 does: ignored by default, as in the reference's runs
+    st._ss_push(h)
+    assert h.calls == []
+    st.scheduled_sampling = True              # opt in: the attribute is live
     st._ss_push(h)
     st._ss_push(h)
     assert h.calls == [(0.25, None, None)]
