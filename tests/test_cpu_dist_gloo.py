@@ -36,7 +36,7 @@ def _rl_grads(ob, p, feats, masks, u, reward, T, lo, hi, denom=None):
     d = mask.sum() if denom is None else denom
     loss = -(lp * reward[lo:hi] * mask).sum() / d
     g = torch.autograd.grad(loss, list(q.values()))
-    return dict(zip(q.keys(), g)), float(mask.sum()), float(loss)
+    return dict(zip(q.keys(), g)), float(mask.sum()), float(loss.detach())
 
 
 def _worker(rank, world, port, out):
