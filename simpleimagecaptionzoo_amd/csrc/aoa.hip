@@ -26,13 +26,19 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_TRY(alloc((void**)&w_pred, sizeof(float) * Vp * Hd));
     ICZ_TRY(alloc((void**)&n_pred, sizeof(float) * d.V));
     ICZ_TRY(alloc((void**)&w_rec, sizeof(float) * 4 * Hd * 2 * Hd));
+    static_assert(NL <= AOA_QKV_MAX_LAYERS, "QkvPackTable too small");
+    for (int l = 0; l < NL; ++l) {
+        ICZ_TRY(alloc((void**)&w_qkv[l], sizeof(float) * 3 * Hd * Hd));
+        ICZ_TRY(alloc((void**)&b_qkv[l], sizeof(float) * 3 * Hd));
+    }
     ICZ_TRY(alloc((void**)&zeros, sizeof(float) * rows * Hd));
     const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
     ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
     for (int b = 0; b < 2; ++b) {
         Bank& s = bank[b];
-        float** ref[] = {&s.xa, &s.xb, &s.ln, &s.q, &s.k, &s.v, &s.o, &s.od, &s.nd, &s.refined, &s.Kd, &s.Vd};
+        float** ref[] = {&s.xa, &s.xb, &s.ln, &s.o, &s.od, &s.nd, &s.refined, &s.Kd, &s.Vd};
         for (float** p : ref) ICZ_TRY(alloc((void**)p, sizeof(float) * RR * Hd));
+        ICZ_TRY(alloc((void**)&s.qkv, sizeof(float) * RR * 3 * Hd));
         ICZ_TRY(alloc((void**)&s.z, sizeof(float) * RR * 2 * Hd));
         ICZ_TRY(alloc((void**)&s.meanf, sizeof(float) * rows * Hd));
         ICZ_TRY(alloc((void**)&s.ws, sizeof(float) * ws_floats));
@@ -71,6 +77,14 @@ int Aoa::refresh(hipStream_t st) {
     hipLaunchKernelGGL(weight_norm_kernel, dim3(cdiv(dims.V, 4)), dim3(256), 0, st, P.predict_v, P.predict_g, w_pred, n_pred, dims.V, dims.Hd);
     const size_t n = (size_t)4 * dims.Hd * 2 * dims.Hd;
     hipLaunchKernelGGL(aoa_pack_rec_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, P.lstm_w_ih, P.lstm_w_hh, w_rec, dims.Hd, dims.E);
+    QkvPackTable qt = {};
+    for (int l = 0; l < NL; ++l) {
+        const icz_aoa_block& b = P.layer[l];
+        qt.w[l][0] = b.q_w; qt.w[l][1] = b.k_w; qt.w[l][2] = b.v_w;
+        qt.b[l][0] = b.q_b; qt.b[l][1] = b.k_b; qt.b[l][2] = b.v_b;
+        qt.wdst[l] = w_qkv[l]; qt.bdst[l] = b_qkv[l];
+    }
+    hipLaunchKernelGGL(aoa_qkv_pack_kernel, dim3(cdiv(dims.Hd * dims.Hd / 4, 256), 3, NL), dim3(256), 0, st, qt, dims.Hd);
     ICZ_CHECK_HIP(hipGetLastError());
     fresh = true;
     return ICZ_OK;
@@ -128,11 +142,9 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
     for (int l = 0; l < NL; ++l) {
         const icz_aoa_block& b = P.layer[l];
         hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, b.ln_g, b.ln_b, ln, rows, Hd, (float*)nullptr);
-        ICZ_TRY(lin(ln, rows, Hd, b.q_w, b.q_b, Hd, q, st));
-        ICZ_TRY(lin(ln, rows, Hd, b.k_w, b.k_b, Hd, k, st));
-        ICZ_TRY(lin(ln, rows, Hd, b.v_w, b.v_b, Hd, v, st));
-        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, q, k, v, o, R, Hd, NH, qc, rr,
-                           dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f));
+        ICZ_TRY(lin(ln, rows, Hd, w_qkv[l], b_qkv[l], 3 * Hd, qkv, st));         // linear_Q | linear_K | linear_V in one GEMM
+        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, qkv, qkv + Hd, qkv + 2 * Hd, o, R, Hd, NH, qc, rr,
+                           dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f), 3 * Hd);
         const float *xo = o, *xn = ln;
         if (train) {
             hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, o, ln, od, nd, (size_t)rows, Hd, rr,

@@ -41,22 +41,23 @@ struct Aoa {
     std::vector<void*> allocs;
     int Vp = 0;
     float *w_pred = nullptr, *n_pred = nullptr, *zeros = nullptr;
+    float* w_qkv[NL] = {}; float* b_qkv[NL] = {};       // per refiner layer [3Hd, Hd] / [3Hd]: linear_Q | linear_K | linear_V (refresh)
     float* w_rec = nullptr;          // [4Hd, 2Hd] = [W_ih[:, E:] | W_hh]: one dgrad GEMM per BPTT step for (du, dh_prev)
     // refiner scratch / per-image tensors (rows = max_rows * R).  Two banks: bank 0 serves the evaluation-mode paths (greedy,
     // beam), bank 1 the training-mode ones (sample, XE, backward), so that the greedy baseline and the sampled rollout of
     // one SCST step can be in flight together; use_bank() points the members below at a bank before a chain is enqueued.
-    struct Bank { float *xa, *xb, *ln, *q, *k, *v, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; int32_t *off, *rowmap; float* featp; };
+    struct Bank { float *xa, *xb, *ln, *qkv, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; int32_t *off, *rowmap; float* featp; };
     Bank bank[2] = {};
     int cur_bank = 0;
     void use_bank(int b) {
         cur_bank = b;
         const Bank& s = bank[b];
-        xa = s.xa; xb = s.xb; ln = s.ln; q = s.q; k = s.k; v = s.v; o = s.o; od = s.od; nd = s.nd; z = s.z;
+        xa = s.xa; xb = s.xb; ln = s.ln; qkv = s.qkv; o = s.o; od = s.od; nd = s.nd; z = s.z;
         refined = s.refined; meanf = s.meanf; Kd = s.Kd; Vd = s.Vd; ws = s.ws; off = s.off; rowmap = s.rowmap;
     }
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    float *xa = nullptr, *xb = nullptr, *ln = nullptr, *q = nullptr, *k = nullptr, *v = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
+    float *xa = nullptr, *xb = nullptr, *ln = nullptr, *qkv = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
           *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;
     // decoder state + scratch
     float *h[2], *m[2], *ctx[2];

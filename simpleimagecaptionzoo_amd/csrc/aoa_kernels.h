@@ -161,8 +161,25 @@ __host__ __device__ __forceinline__ int aoa_pitch(int n) {
 // Both products are register-blocked: a thread owns a 4 x 4 block of S (rows q, q + nq/4, ...; keys r, r + len/4, ...) or a
 // 4 x 4 block of O (4 strided rows x 4 adjacent columns) and walks the reduction dimension four at a time with 16-byte LDS
 // reads -- 8 reads per 64 FMAs, where one element per thread needs 2 reads per FMA and leaves the kernel LDS-bound.
+// The three projections of a refiner layer as one [3 Hd, Hd] weight and one [3 Hd] bias (one GEMM of N = 3 Hd instead of three
+// of N = Hd, which leave half of the CUs idle): copied from the bound parameters at every weight refresh.
+constexpr int AOA_QKV_MAX_LAYERS = 8;
+struct QkvPackTable {
+    const float* w[AOA_QKV_MAX_LAYERS][3];
+    const float* b[AOA_QKV_MAX_LAYERS][3];
+    float* wdst[AOA_QKV_MAX_LAYERS];
+    float* bdst[AOA_QKV_MAX_LAYERS];
+};
+__global__ __launch_bounds__(256) void aoa_qkv_pack_kernel(QkvPackTable t, int Hd) {
+    const int l = blockIdx.z, which = blockIdx.y;
+    const size_t n4 = (size_t)Hd * Hd / 4, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) reinterpret_cast<f32x4*>(t.wdst[l] + (size_t)which * Hd * Hd)[i] = reinterpret_cast<const f32x4*>(t.w[l][which])[i];
+    if (i < (size_t)Hd) t.bdst[l][(size_t)which * Hd + i] = t.b[l][which][i];
+}
+
+// Q, K, V rows are `ldi` floats apart (3 Hd when they are the column blocks of one fused projection), O rows Hd.
 __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
-                                                       float* __restrict__ O, int R, int Hd, int NH, int QC, RegionRows rr, DropP dp) {
+                                                       float* __restrict__ O, int R, int Hd, int NH, int QC, RegionRows rr, DropP dp, int ldi) {
     extern __shared__ __attribute__((aligned(16))) float sm_mha[];     // K,V tiles [R4][ld], Q chunk [QC4][ld], P [QC4][lp]
     const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x;
     const int d = Hd / NH, d4 = d >> 2, ld = aoa_pitch(d), lp = aoa_pitch(R);
@@ -173,13 +190,14 @@ __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__
     float* sv = sk + R4 * ld;
     float* sq = sv + R4 * ld;
     float* sp = sq + QC4 * ld;
-    const size_t base = rr.first(img) * Hd + (size_t)hd * d;
+    const size_t base = rr.first(img) * Hd + (size_t)hd * d;           // output rows
+    const size_t ibase = rr.first(img) * ldi + (size_t)hd * d;         // Q / K / V rows
     for (int i = tid; i < len4 * d4; i += 256) {
         const int r = i / d4, j = (i % d4) * 4;
         f32x4 kk = {0.f, 0.f, 0.f, 0.f}, vv = kk;              // rows [len, len4) are read by the last block of four: zeros
         if (r < len) {
-            kk = *reinterpret_cast<const f32x4*>(K + base + (size_t)r * Hd + j);
-            vv = *reinterpret_cast<const f32x4*>(V + base + (size_t)r * Hd + j);
+            kk = *reinterpret_cast<const f32x4*>(K + ibase + (size_t)r * ldi + j);
+            vv = *reinterpret_cast<const f32x4*>(V + ibase + (size_t)r * ldi + j);
         }
         *reinterpret_cast<f32x4*>(sk + r * ld + j) = kk;
         *reinterpret_cast<f32x4*>(sv + r * ld + j) = vv;
@@ -191,7 +209,7 @@ __global__ __launch_bounds__(256) void mha_self_kernel(const float* __restrict__
         const int nq = min(QC, nrow - q0), nqt = (nq + 3) >> 2;
         for (int i = tid; i < nq * d4; i += 256) {
             const int r = i / d4, j = (i % d4) * 4;
-            *reinterpret_cast<f32x4*>(sq + r * ld + j) = *reinterpret_cast<const f32x4*>(Q + base + (size_t)(q0 + r) * Hd + j);
+            *reinterpret_cast<f32x4*>(sq + r * ld + j) = *reinterpret_cast<const f32x4*>(Q + ibase + (size_t)(q0 + r) * ldi + j);
         }
         __syncthreads();
         for (int i = tid; i < nqt * nrt; i += 256) {
