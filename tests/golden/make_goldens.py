@@ -6,13 +6,15 @@ hot path never touches are stubbed in sys.modules), drives
 inputs and writes input/output vectors as .npz / .json fixtures next to this script.  The fixtures are
 data only (tensors, ids, strings, scores); no reference source travels with them.
 
-The three patches applied *around* (not inside) the reference while it runs:
+The patches applied *around* (not inside) the reference while it runs:
   * torch<=1.4 integer-division semantics for `LongTensor / int` in beam search
     (Models/BUTD_Model.py:277, AoA_Model.py:462, NIC_Model.py:181),
   * `torch.nn.functional.dropout` draws its keep-mask from arrays we supply (so the masks can be
     handed to the HIP path), and
-  * `torch.multinomial(p, 1)` is an inverse-CDF draw from uniforms we supply.
-The last two replace torch's RNG stream (which no other implementation can reproduce) by explicit
+  * `torch.multinomial(p, 1)` is an inverse-CDF draw from uniforms we supply,
+  * for the scheduled-sampling vectors only: `Tensor.uniform_` (the gate draw of DecoderRNN.forward) returns uniforms we
+    supply, and the decoder's own `ss_prob` attribute is set to 0.5 for that run (Engine.py:143 sets the Captioner's).
+These replace torch's RNG stream (which no other implementation can reproduce) by explicit
 inputs; the arithmetic of the reference is untouched.
 
 Usage:  python tests/golden/make_goldens.py
