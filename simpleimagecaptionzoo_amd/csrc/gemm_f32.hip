@@ -1183,11 +1183,14 @@ static int nt_waves(const GemmArgs& a) {
 static int nt_tile_n(const GemmArgs& a) { return 16 * nt_waves(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
-    if (layout == GEMM_NT && nt_x3big(a)) {       // 128 x 128 tiles, about two workgroups per CU, at least 4 chunks of 128 per split
+    if (layout == GEMM_NT && nt_x3big(a)) {
+        // 128 x 128 tiles, two workgroups per CU.  Measured at 2304 rows (tools/perf_gemm_nt_big.py, us for split 1 / 2 / 3 / 4):
+        // N 1024 K 1024: 48 / 55 / 50 / 63;  N 1024 K 2048: 86 / 89 / 77 / 96;  N 2048 K 2048: 165 / 164 / 148 / 153;
+        // N 3072 K 1024: 92 / 115 / 124 / 135  ->  up to 1.75 rounds of workgroups, at least 5 chunks of 128 per split
         if (a.nseg > 1) return 1;
         const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128), tot = a.seg[0].K / 128;
-        int s = 512 / tiles;
-        if (s > tot / 4) s = tot / 4;
+        int s = 896 / tiles;
+        if (s > tot / 5) s = tot / 5;
         if (s < 1) s = 1;
         return cdiv(tot, cdiv(tot, s));
     }
