@@ -175,6 +175,37 @@ def test_xe_then_scst_steps_match_reference_engine(golden_dir, path):
         _check_pinned(g, pre + "sd.", eng.model, slack=8e-4 + 2e-5 * (s + 1))
 
 
+def test_engine_xe_step_with_ss_prob_attribute(golden_dir):
+    """Engine.py:143 sets `model.ss_prob` before training_epoch.  Default: ignored, the step is the reference's (golden
+    loss); with `model.scheduled_sampling = True` the fused step samples its inputs from step 2 on: another, reproducible
+    loss, and teacher forcing again once the attribute is back to 0."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import init_optimizer
+    g, fx = _load(golden_dir)
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    feats = feats_from_seed(int(g["xe0_feats_seed"]), B, R, D)
+    caps = torch.tensor(g["xe0_captions"])
+    lens = [int(x) for x in g["xe0_lengths"]]
+    batch = (tuple(range(B)), None, caps, lens, _supp(feats))
+
+    def one_step(ss_prob, live):
+        eng, _ = _engine(g, fx)
+        em, am, om, _ = masks_from_seed(int(g["xe0_mask_seed"]), max(lens) - 1, B, R, E, A, H)
+        rng = make_rng(77, None, torch.tensor(em, device="cuda"), torch.tensor(am, device="cuda"), torch.tensor(om, device="cuda"))
+        eng.model.ss_prob = ss_prob
+        eng.model.scheduled_sampling = live
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 4e-4}), 4e-4)
+        loss = eng.training_epoch([batch], opt, _Crit(), tqdm_visible=False, rngs=[rng])[0].item()
+        torch.cuda.synchronize()
+        return loss
+
+    want = float(g["xe0_loss"])
+    assert abs(one_step(0.9, False) - want) < 1e-4          # the attribute alone changes nothing, as in the reference
+    a, b = one_step(0.9, True), one_step(0.9, True)
+    assert np.isfinite(a) and a == b and abs(a - want) > 1e-3
+    assert abs(one_step(0.0, True) - want) < 1e-4
+
+
 def test_device_prefetcher_feeds_engine_identically(golden_dir, tmp_path):
     """Packed store + pinned double-buffered H2D (features.py) in front of eval_captions_json_generation: same JSON as the
     reference-style path that stacks per-image numpy arrays."""
