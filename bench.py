@@ -64,7 +64,7 @@ def make_batches(n, B, words, device, rank):
 def secondary(eng, opt, words, device, B):
     """The other rates SURVEY.md 8d lists next to the headline metric, on the same engine and model size (N = 1, a few
     hundred ms each): XE training step (Engine.training_epoch), greedy and beam-5 decode (eval_captions_json_generation's
-    decoders; BASELINE config 3 quotes beam 5 at batch 128)."""
+    decoders; BASELINE config 3 quotes beam 5 at batch 128), and the AoADetection SCST step of config 5."""
     import time as _t
     out = {}
     rs = np.random.RandomState(0)
@@ -114,7 +114,52 @@ def secondary(eng, opt, words, device, B):
             out[name] = {"captions_per_s": nimg / dt, "ms": dt * 1e3, "batch": nimg, "steps": 20}
         out["beam5"]["note"] = "beam 5 = 5 decoder rows per image; random-init weights do not emit <end>, so all 20 steps run"
     h.close()
+    # BASELINE config 3: beam 5 at batch 128 (640 decoder rows)
+    h = ButdHandle(R, D, H, E, A, V, 5 * 128, 20)
+    h.bind(random_butd_params(R, D, H, E, A, V, device, seed=1234))
+    h.enable_graphs(True)
+    with torch.cuda.stream(eng.stream):
+        f128 = torch.relu(torch.randn(128, R, D, device=device))
+        for _ in range(3):
+            h.beam_search(f128, 5, 20)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(10):
+            h.beam_search(f128, 5, 20)
+        torch.cuda.synchronize()
+        dt = (_t.perf_counter() - t0) / 10
+        out["beam5_b128"] = {"captions_per_s": 128 / dt, "ms": dt * 1e3, "batch": 128, "steps": 20}
+    h.close()
+    del h, f128, f64
+    out["aoa_scst_step"] = aoa_scst(words, device, B)
     return out
+
+
+def aoa_scst(words, device, B):
+    """BASELINE config 5 at N = 1: AoADetection (6-layer refiner + AoA decoder) SCST step through AoADetection_Eng, same
+    synthetic inputs, random-init weights (the reference's own initialisation), reward + clamp + Adam included."""
+    import time as _t
+    from simpleimagecaptionzoo_amd.engine import AoADetection_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    vocab = synthetic_vocab(V)
+    df = document_frequency(synthetic_references(2000, words, seed=0))
+    eng = AoADetection_Eng({"model_type": "AoADetection", "embed_dim": E, "hidden_dim": H}, "SYN", vocab, data_dir="/tmp/",
+                           use_bu="fixed", device=device, cider_df=df, max_batch=B)
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    batches = make_batches(2, B, words, device, 0)
+
+    def run(n):
+        eng.SCST_training_epoch([batches[i % 2] for i in range(n)], opt, None, tqdm_visible=False)
+    run(3)
+    torch.cuda.synchronize()
+    t0 = _t.perf_counter()
+    run(10)
+    torch.cuda.synchronize()
+    dt = (_t.perf_counter() - t0) / 10
+    return {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B,
+            "note": "AoADetection_Eng.SCST_training_epoch: refiner x2 (eval + train mode), greedy + sampled rollout, CIDEr-D reward, "
+                    "REINFORCE backward of the decoder, clamp + Adam"}
 
 
 def cpu_baseline(words, rows=8):
