@@ -187,8 +187,13 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A};
         hipLaunchKernelGGL(att_scores_kernel, dim3(rows, ATT_PARTS), dim3(256), sizeof(float) * A, st, a, s.drop_att);
-        hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 512)), dim3(256), 0, st, s.feats, s.img_of_row, (const float*)scores,
-                           s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D);
+        const int G = s.rows_per_img;
+        if (G > 1 && G <= ATT_CTX_MAX_G && rows % G == 0 && !s.alpha_out2)
+            hipLaunchKernelGGL(att_ctx_group_kernel, dim3(rows / G, cdiv(D, 512)), dim3(256), 0, st, s.feats, (const float*)scores,
+                               s.alpha_out ? s.alpha_out : alpha, s.ctx_out ? s.ctx_out : ctx, R, D, G);
+        else
+            hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 512)), dim3(256), 0, st, s.feats, s.img_of_row, (const float*)scores,
+                               s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D);
     }
     const float* ctxp = s.ctx_out ? s.ctx_out : ctx;
     {   // language LSTM: [ctx, h1] W_ih^T + h2 W_hh^T

@@ -44,6 +44,7 @@ int Butd::beam_search(const float* feats, int n_img, int k, int max_steps, float
     for (int step = 1; step <= max_steps; ++step) {
         StepIO s = {};
         s.rows = rows; s.feats = feats; s.img_of_row = bm.img_of_row; s.it = it;
+        s.rows_per_img = k;
         s.h1_in = h1[0]; s.c1_in = c1[0]; s.h2_in = h2[0]; s.c2_in = c2[0];
         s.h1_out = h1[1]; s.c1_out = c1[1]; s.h2_out = h2[1]; s.c2_out = c2[1];
         ICZ_TRY(this->step(s, st));

@@ -13,6 +13,7 @@ struct StepIO {
     int rows;
     const float* feats;              // [n_img, R, D]
     const int32_t* img_of_row;       // beam search: image of each decoder row; null = identity
+    int rows_per_img;                // beam search: > 1 = the rows img * rows_per_img + b belong to image img (img_of_row agrees)
     const int64_t* it;               // [rows] input token ids
     bool emb_ready;                  // the embedding of `it` is already in the emb buffer (skip embed_kernel)
     const float *h1_in, *c1_in, *h2_in, *c2_in;

@@ -324,6 +324,64 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
     if (!half && valid) *reinterpret_cast<f32x4*>(ctx + (size_t)row * D + d) = acc + *reinterpret_cast<const f32x4*>(spart + cg * 4);
 }
 
+// The same for beam search, where the G = beam rows of an image sit next to each other (row = img * G + b) and share its
+// features: one workgroup does the G rows of one image for its 512 columns, so every feature vector is fetched once
+// instead of G times (at 640 rows the per-row kernel moves 189 MB through the caches per step).  Same arithmetic and
+// summation order per row as att_ctx_kernel.  Grid (n_img, D/512).
+constexpr int ATT_CTX_MAX_G = 8;
+__global__ __launch_bounds__(256) void att_ctx_group_kernel(const float* __restrict__ feats, const float* __restrict__ scores,
+                                                            float* __restrict__ alpha_out, float* __restrict__ ctx, int R, int D, int G) {
+    __shared__ float sal[ATT_CTX_MAX_G][64];
+    __shared__ __attribute__((aligned(16))) float spart[ATT_CTX_MAX_G][128 * 4];
+    const int img = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int g = wave; g < G; g += 4) {                 // wave w: softmax of rows w, w + 4
+        const int row = img * G + g;
+        const float scv = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
+        const float mx = wave_max(scv);
+        const float ex = lane < R ? expf(scv - mx) : 0.f;
+        const float sum = wave_sum(ex);
+        const float al = ex / sum;
+        sal[g][lane] = al;
+        if (blockIdx.y == 0 && lane < R) alpha_out[(size_t)row * R + lane] = al;
+    }
+    __syncthreads();
+    const int cg = tid & 127, half = tid >> 7;
+    const int d = blockIdx.y * 512 + cg * 4;
+    const bool valid = d < D;
+    const int Rh = (R + 1) / 2;
+    const int r_lo = half ? Rh : 0, r_hi = half ? R : Rh;
+    const float* f = feats + (size_t)img * R * D + (valid ? d : 0);
+    f32x4 acc[ATT_CTX_MAX_G];
+#pragma unroll
+    for (int g = 0; g < ATT_CTX_MAX_G; ++g) acc[g] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (valid) {
+        constexpr int RB = 9;
+        for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
+            f32x4 x[RB];
+#pragma unroll
+            for (int u = 0; u < RB; ++u) x[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r0 + u, r_hi - 1) * D);
+#pragma unroll
+            for (int g = 0; g < ATT_CTX_MAX_G; ++g)
+                if (g < G) {
+#pragma unroll
+                    for (int u = 0; u < RB; ++u)
+                        if (r0 + u < r_hi) acc[g] += x[u] * sal[g][r0 + u];
+                }
+        }
+    }
+    if (half) {
+#pragma unroll
+        for (int g = 0; g < ATT_CTX_MAX_G; ++g)
+            if (g < G) *reinterpret_cast<f32x4*>(spart[g] + cg * 4) = acc[g];
+    }
+    __syncthreads();
+    if (!half && valid) {
+#pragma unroll
+        for (int g = 0; g < ATT_CTX_MAX_G; ++g)
+            if (g < G) *reinterpret_cast<f32x4*>(ctx + (size_t)(img * G + g) * D + d) = acc[g] + *reinterpret_cast<const f32x4*>(spart[g] + cg * 4);
+    }
+}
+
 __device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_stride, size_t off) {
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (!p) return s;
