@@ -76,8 +76,10 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
  *   stage 2: language_model.weight_{ih,hh};  everything else is complete when the call returns.
  * The host side starts the all-reduce of that group on the same stream (it then runs beside the remaining weight-gradient
  * GEMMs).  NULL removes the hook. */
-/* Data-parallel: the global (all-reduced) mask sum as a DEVICE scalar, so that no host round trip separates the rollout
- * from the backward pass; then call icz_butd_sample_backward with mask_sum_global < 0 ("use the device value"). */
+/* Data-parallel: the global (all-reduced) loss normaliser as a DEVICE scalar, so that no host round trip separates the
+ * forward pass from the backward pass: the mask sum of the rollout (then call icz_butd_sample_backward with
+ * mask_sum_global < 0, "use the device value") or the token count of the XE batch (icz_butd_xe_backward with
+ * n_tokens_global < 0).  icz_nic_set_norm_global / icz_aoa_set_norm_global are the same for the other two decoders. */
 int icz_butd_set_mask_sum_global(icz_butd_t* h, const float* mask_sum_global_dev, void* stream);
 typedef void (*icz_grad_ready_cb)(void* user, int32_t stage);
 int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user);
@@ -128,7 +130,8 @@ int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream);
 /* DecoderRNN.forward + LabelSmoothingLoss + backward (BUTD_Model.py:97-151, Utils.py:268-286,
  * Engine.py:178-186).  captions [B,L] int64, rows sorted by length descending; lengths_host[b] = len-1 as in
  * Engine.py:178 (host array).  packed_logits_out [sum(lengths), V] in pack_padded_sequence order or NULL.
- * n_tokens_global > 0 replaces the local token count as the loss normaliser (data-parallel). */
+ * n_tokens_global > 0 replaces the local token count as the loss normaliser (data-parallel); < 0: the device scalar set by
+ * icz_butd_set_mask_sum_global. */
 int icz_butd_xe_forward(icz_butd_t* h, const float* feats, const int64_t* captions, int32_t B, int32_t L,
                         const int32_t* lengths_host, const icz_rng* rng, int32_t train,
                         float* packed_logits_out, void* stream);
@@ -143,6 +146,12 @@ int icz_butd_xe_backward(icz_butd_t* h, float smoothing, const icz_butd_params* 
  * inverse-CDF draw of the sampler contract (smallest v with cumsum(p)[v] > u sum(p), float64 sums); no gradient
  * flows through it and the embedding gradient goes to the tokens actually fed.  ss_prob = 0 (default) switches it off. */
 int icz_butd_set_scheduled_sampling(icz_butd_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
+
+/* Attention maps of the forward pass the handle holds (the last icz_butd_xe_forward or icz_butd_sample of B rows and T
+ * steps): alphas_out [B, T, R].  A teacher-forced evaluation-mode forward over a decoded sentence yields the alphas the
+ * reference's sample / beam_search_sample return beside the ids (BUTD_Model.py:178-189, :309-317), which
+ * eval_test_image hands to show_additional_rlt (Engine.py:325,339). */
+int icz_butd_saved_alphas(icz_butd_t* h, float* alphas_out, void* stream);
 
 /* XE backward driven by an upstream gradient w.r.t. the packed logits [sum(lengths), V] (autograd path:
  * criterion(predictions[0], targets[0]).backward(), Engine.py:182-186). */
@@ -188,6 +197,7 @@ int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* capti
                        const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream);
 int icz_nic_xe_backward(icz_nic_t* h, float smoothing, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
                         float n_tokens_global, void* stream);
+int icz_nic_set_norm_global(icz_nic_t* h, const float* norm_dev, void* stream);
 /* Scheduled sampling for the following icz_nic_xe_forward calls (NIC_Model.py:77-89): see icz_butd_set_scheduled_sampling. */
 int icz_nic_set_scheduled_sampling(icz_nic_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
 /* DecoderRNN.beam_search_sample, NIC_Model.py:153-212 (batched over images) */
@@ -257,6 +267,9 @@ int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions
                        const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream);
 int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global,
                         void* stream);
+int icz_aoa_set_norm_global(icz_aoa_t* h, const float* norm_dev, void* stream);
+/* As icz_butd_saved_alphas: the decoder block's attention weights averaged over the heads (AoA_Model.py:118), [B, T, regions]. */
+int icz_aoa_saved_alphas(icz_aoa_t* h, float* alphas_out, void* stream);
 /* Scheduled sampling for the following icz_aoa_xe_forward calls (AoA_Model.py:258-270): see icz_butd_set_scheduled_sampling. */
 int icz_aoa_set_scheduled_sampling(icz_aoa_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
 
@@ -295,6 +308,14 @@ int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy
                       const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
                       const int32_t* ent_order, const double* ent_w, const double* ref_norm,
                       const int32_t* ref_len, float* reward_out, double* scores_out, void* stream);
+/* The same against a device-resident STORE of cooked references (every image of the dataset cooked once, instead of the
+ * reference's re-cooking of the batch's references on every call, ciderD.py:41-52): the seven arrays are the store's, laid
+ * out as above with one CSR row per stored image, and img_slot [B] int32 (device) names the store row of image b of the
+ * batch -- the only per-batch upload. */
+int icz_ciderd_reward_indexed(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
+                              const int32_t* img_slot, const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr,
+                              const int32_t* ent_key, const int32_t* ent_order, const double* ent_w, const double* ref_norm,
+                              const int32_t* ref_len, float* reward_out, double* scores_out, void* stream);
 
 /* ------------------------------------------------------------------------------------------------------------
  * Building blocks exported for tests and benchmarks

@@ -142,6 +142,10 @@ def lib():
         "icz_nic_sample_backward": (C.c_int, [vp, vp, C.POINTER(NicParams), vp, vp, vp, f32, vp]),
         "icz_nic_xe_forward": (C.c_int, [vp, vp, vp, i32, i32, C.POINTER(i32), C.POINTER(Rng), i32, vp, vp]),
         "icz_nic_xe_backward": (C.c_int, [vp, f32, C.POINTER(NicParams), vp, vp, f32, vp]),
+        "icz_butd_saved_alphas": (C.c_int, [vp, vp, vp]),
+        "icz_aoa_saved_alphas": (C.c_int, [vp, vp, vp]),
+        "icz_nic_set_norm_global": (C.c_int, [vp, vp, vp]),
+        "icz_aoa_set_norm_global": (C.c_int, [vp, vp, vp]),
         "icz_nic_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),
         "icz_aoa_create": (C.c_int, [C.POINTER(AoaDims), C.POINTER(vp)]),
         "icz_aoa_destroy": (C.c_int, [vp]),
@@ -159,6 +163,7 @@ def lib():
         "icz_ciderd_create": (C.c_int, [vp, vp, i64, C.c_double, vp, C.POINTER(vp)]),
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "icz_ciderd_reward_indexed": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
         "icz_prof_pair_overhead": (C.c_int, [vp, i32, C.POINTER(C.c_double)]),
         "icz_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),

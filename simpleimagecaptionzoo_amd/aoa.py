@@ -180,8 +180,13 @@ class AoaHandle:
         return ids, seq, lp
 
     def sample_mask_sum(self):
+        """Local sum of the REINFORCE mask (Utils.py:307-309) as a 1-element DEVICE tensor (no host round trip)."""
         seq = self._live[2]
-        return float((seq[:, :-1] > 0).sum().item() + seq.shape[0])
+        return ((seq[:, :-1] > 0).sum() + seq.shape[0]).float().view(1)
+
+    def set_mask_sum_global(self, t):
+        """DP: the all-reduced loss normaliser as a 1-element device tensor; then pass -1 as the global normaliser."""
+        check(lib().icz_aoa_set_norm_global(self._h, ptr(t), stream_ptr()))
 
     def sample_backward(self, reward, grads, mask_sum_global=0.0):
         reward = reward.to(device=self.device, dtype=torch.float32).contiguous()
@@ -190,6 +195,12 @@ class AoaHandle:
         gs = self._grad_struct(grads)
         check(lib().icz_aoa_sample_backward(self._h, ptr(reward), C.byref(gs), ptr(loss), ptr(msum), float(mask_sum_global), stream_ptr()))
         return loss, msum
+
+    def saved_alphas(self, B, T, regions):
+        """Head-averaged decoder attention [B, T, regions] of the forward pass the handle holds (last xe_forward / sample)."""
+        out = torch.empty(B, T, regions, device=self.device)
+        check(lib().icz_aoa_saved_alphas(self._h, ptr(out), stream_ptr()))
+        return out
 
     def set_scheduled_sampling(self, ss_prob, gate=None, draw=None):
         """Scheduled sampling for the following xe_forward calls (AoA_Model.py:258-270 with the decoder's `ss_prob`)."""
@@ -280,8 +291,9 @@ class AoADetection_Captioner(nn.Module, ScheduledSamplingState):
         return {k: sd[k] for k in AOA_DECODER_KEYS}
 
     def _next_rng(self):
+        from .dist import seed_for_rank
         self._seed += 1
-        return make_aoa_rng(self._seed)
+        return make_aoa_rng(seed_for_rank(self._seed))   # data-parallel replicas draw independent streams
 
     def _handle(self):
         named = self._named()
@@ -339,3 +351,33 @@ class AoADetection_Captioner(nn.Module, ScheduledSamplingState):
         lens = lens.tolist()
         out = [seqs[i:i + 1, :lens[i]] for i in range(len(lens))]
         return out[0] if len(out) == 1 else out
+
+    def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):
+        """AoA_Model.py:755-786 -> (caption words, [alphas (1, steps, regions)]): the decoder block's attention weights
+        averaged over the heads (:118), taken from an evaluation-mode teacher-forced pass over the decoded sentence (the
+        decoder state is a function of the token prefix, so these are the maps the reference records while decoding)."""
+        feats = self._feats(visual_inputs)
+        raw = feats[0] if isinstance(feats, RegionBatch) else feats
+        assert raw.size(0) == 1
+        h = self._handle()
+        if eval_beam_size != -1:
+            seqs, lens = h.beam_search(feats, eval_beam_size, 50)
+            ids = seqs[:, :int(lens[0])].long()
+            replay = ids                                     # <sta> w1 .. wn [<end>]
+        else:
+            ids = h.greedy(feats, max_len)
+            replay = torch.cat([torch.ones(1, 1, dtype=torch.int64, device=ids.device), ids], 1)
+        steps = replay.shape[1] - 1
+        if steps > 0:
+            h.xe_forward(feats, replay, [steps], None, train=False)
+            alphas = h.saved_alphas(1, steps, raw.shape[1])
+        else:
+            alphas = torch.zeros(1, 0, raw.shape[1], device=raw.device)
+        caption = []
+        for word_id in ids[0].cpu().numpy():
+            word = caption_vocab.ix2word[int(word_id)]
+            if word == "<end>":
+                break
+            elif word != "<sta>":
+                caption.append(word)
+        return caption, [alphas]

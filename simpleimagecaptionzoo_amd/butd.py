@@ -138,7 +138,8 @@ class ButdHandle:
         return out
 
     def set_mask_sum_global(self, t):
-        """DP: hand the all-reduced mask sum over as a 1-element device tensor; then sample_backward(..., mask_sum_global=-1)."""
+        """DP: hand the all-reduced loss normaliser (mask sum of the rollout / token count of the XE batch) over as a 1-element
+        device tensor; then sample_backward(..., mask_sum_global=-1) / xe_backward(..., n_tokens_global=-1)."""
         check(lib().icz_butd_set_mask_sum_global(self._h, ptr(t), stream_ptr()))
 
     def sample_backward(self, reward, grads, mask_sum_global=0.0):
@@ -187,6 +188,12 @@ class ButdHandle:
         dlogp = dlogp.to(device=self.device, dtype=torch.float32).contiguous()
         gs = self._grad_struct(grads)
         check(lib().icz_butd_sample_backward_dlogp(self._h, ptr(dlogp), C.byref(gs), stream_ptr()))
+
+    def saved_alphas(self, B, T):
+        """Attention maps [B, T, R] of the forward pass the handle holds (the last xe_forward / sample of B rows, T steps)."""
+        out = torch.empty(B, T, self.R, device=self.device)
+        check(lib().icz_butd_saved_alphas(self._h, ptr(out), stream_ptr()))
+        return out
 
     def xe_backward_dlogits(self, dpacked, grads):
         """BPTT of the last xe_forward() for an upstream gradient w.r.t. the packed logits (sum(lengths), V)."""

@@ -147,8 +147,9 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
         return self._grads
 
     def _next_rng(self):
+        from .dist import seed_for_rank
         self._seed += 1
-        return make_rng(self._seed)
+        return make_rng(seed_for_rank(self._seed))       # data-parallel replicas draw independent streams
 
     def set_seed(self, seed):
         self._seed = int(seed)
@@ -193,13 +194,26 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
         return out[0] if len(out) == 1 else out
 
     def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):
-        """BUTD_Model.py:519-544 (attention maps are not returned by the fused path: alphas = None)."""
+        """BUTD_Model.py:519-544 -> (caption words, [alphas (1, steps, R)]).  Greedy: the attention maps come out of the decode
+        itself; beam search: the decoder state of a beam is a function of its token prefix, so the maps of the winning beam
+        are those of an evaluation-mode teacher-forced pass over the returned sentence (what the reference carries along
+        beam by beam, :282,:309-317)."""
         feats = visual_inputs["bu_feats"]
         assert feats.size(0) == 1
+        h = self._handle()
         if eval_beam_size != -1:
-            ids = self.beam_search_sampler(visual_inputs, eval_beam_size)
+            seqs, lens = h.beam_search(feats, eval_beam_size, 50)
+            n = int(lens[0])
+            ids = seqs[:, :n]
+            steps = n - 1                                   # one map per generated token (the leading <sta> has none, :316)
+            if steps > 0:
+                h.xe_forward(feats, ids.long(), [steps], None, train=False)
+                alphas = h.saved_alphas(1, steps)
+            else:
+                alphas = torch.zeros(1, 0, self.dims["R"], device=feats.device)
         else:
-            ids = self.sampler(visual_inputs, max_len)
+            ids, alphas = h.greedy(feats, max_len, want_alphas=True)
+            ids, alphas = ids.clone(), alphas.clone()
         caption = []
         for word_id in ids[0].cpu().numpy():
             word = caption_vocab.ix2word[int(word_id)]
@@ -207,4 +221,4 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
                 break
             elif word != "<sta>":
                 caption.append(word)
-        return caption, [None]
+        return caption, [alphas]

@@ -4,7 +4,8 @@ What depends on strings is prepared once on the host and kept resident on the de
   * the document-frequency table (the pickle of PreProcess/CIDEr_idf_preproccess.py:78-82) becomes an
     open-addressing hash of id n-grams -> idf = log(ref_len) - log(max(1, df))   (ciderD_scorer.py:141-145);
   * every image's references are "cooked" once (n-gram tf-idf vectors, norms, bigram length; ciderD_scorer.py:
-    128-153) and cached -- the reference re-unpickles the table and re-cooks the references for every batch.
+    128-153) and appended to a device-resident store; a batch names its images by store row -- the reference
+    re-unpickles the table and re-cooks the references for every batch.
 Reference words outside the vocabulary are distinct strings in the reference; they get private ids >= V here, so
 they still count in the reference norms and can never match a hypothesis n-gram (hypotheses only contain
 vocabulary ids).  Scoring itself runs in libicz (csrc/ciderd.hip) in float64.
@@ -99,8 +100,8 @@ class CiderDReward:
                                       C.byref(self._h)))
         self.persistent = False
         self._out = {}
-        self._cooked = {}                    # image id -> cooked reference arrays (host)
-        self._batch_cache = {}
+        self._cooked = {}                    # image id -> cooked reference arrays (host), until they are in the store
+        self._store_init()
 
     def close(self):
         if self._h:
@@ -154,34 +155,106 @@ class CiderDReward:
         return (np.asarray(ent_ptr, np.int32), np.asarray(keys, np.int32).reshape(-1, 4), np.asarray(order, np.int32),
                 np.asarray(ws, np.float64), np.asarray(norms, np.float64).reshape(-1, 4), np.asarray(lens, np.int32))
 
-    def _batch(self, img_ids, gts):
-        key = tuple(img_ids)
-        hit = self._batch_cache.get(key)
-        if hit is not None:
-            return hit
-        img_ref_ptr, ref_ent_ptr = [0], [0]
-        K, O, W, N, L = [], [], [], [], []
-        for i in img_ids:
-            c = self._cooked.get(i)
-            if c is None:
-                c = self.cook_image(gts[i])
-                self._cooked[i] = c
-            ep, k, o, w, nrm, ln = c
-            base = ref_ent_ptr[-1]
-            ref_ent_ptr.extend((base + ep[1:]).tolist())
-            img_ref_ptr.append(img_ref_ptr[-1] + len(ln))
-            K.append(k); O.append(o); W.append(w); N.append(nrm); L.append(ln)
+    # ---- device-resident reference store -----------------------------------------------------
+    # Every image's cooked references are uploaded ONCE, appended to seven growing device arrays (CSR over stored images ->
+    # references -> n-gram entries); a batch is then just an int32 list of store rows.  Steady state (every epoch after the
+    # first, or after preload()): no cooking, no CSR assembly, one 4 B-per-image upload from pinned memory.  The reference
+    # re-cooks the batch's references on every call (ciderD.py:41-52).
+    def _store_init(self):
         dev = self.device
-        out = (torch.tensor(img_ref_ptr, dtype=torch.int32, device=dev),
-               torch.tensor(ref_ent_ptr, dtype=torch.int32, device=dev),
-               torch.from_numpy(np.concatenate(K).astype(np.int32)).to(dev),
-               torch.from_numpy(np.concatenate(O).astype(np.int32)).to(dev),
-               torch.from_numpy(np.concatenate(W)).to(dev),
-               torch.from_numpy(np.concatenate(N)).to(dev),
-               torch.from_numpy(np.concatenate(L).astype(np.int32)).to(dev))
-        if len(self._batch_cache) < 4096:
-            self._batch_cache[key] = out
-        return out
+        self._n_img = self._n_ref = self._n_ent = 0
+        self._slot = {}                      # image id -> store row
+        z = lambda n, dt, *rest: torch.zeros((n,) + rest, dtype=dt, device=dev)
+        self._st = {"irp": z(1025, torch.int32), "rep": z(8193, torch.int32), "key": z(1 << 17, torch.int32, 4),
+                    "ord": z(1 << 17, torch.int32), "w": z(1 << 17, torch.float64), "norm": z(8192, torch.float64, 4),
+                    "len": z(8192, torch.int32)}
+        self._idx_ring, self._idx_ev, self._idx_i, self._idx_dev = [], [], 0, {}
+
+    def _grow(self, name, need):
+        t = self._st[name]
+        if t.shape[0] >= need:
+            return
+        cap = t.shape[0]
+        while cap < need:
+            cap *= 2
+        new = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
+        new[:t.shape[0]] = t
+        self._st[name] = new
+
+    def prepare(self, img_ids, gts):
+        """Cook the references of images not seen before (host only, thread-safe: a loader's worker thread calls this for
+        batch i+1 while batch i is on the device, features.DevicePrefetcher(on_batch=...))."""
+        for i in img_ids:
+            if i not in self._slot and i not in self._cooked:
+                self._cooked[i] = self.cook_image(gts[i])
+
+    def preload(self, gts):
+        """Cook and upload the references of a whole dataset split ({image id: [reference strings]}) ahead of training."""
+        ids = list(gts.keys())
+        for lo in range(0, len(ids), 1024):
+            self._append(ids[lo:lo + 1024], gts)
+
+    def _append(self, img_ids, gts):
+        new = [i for i in dict.fromkeys(img_ids) if i not in self._slot]
+        if not new:
+            return
+        self.prepare(new, gts)
+        irp, rep, K, O, W, N, L = [], [], [], [], [], [], []
+        nref, nent = self._n_ref, self._n_ent
+        for i in new:
+            ep, k, o, w, nrm, ln = self._cooked.pop(i)
+            rep.extend((nent + ep[1:]).tolist())
+            nent += int(ep[-1])
+            nref += len(ln)
+            irp.append(nref)
+            K.append(k); O.append(o); W.append(w); N.append(nrm); L.append(ln)
+        n_new = len(new)
+        self._grow("irp", self._n_img + n_new + 1)
+        self._grow("rep", nref + 1)
+        for name in ("norm", "len"):
+            self._grow(name, nref)
+        for name in ("key", "ord", "w"):
+            self._grow(name, nent)
+        st = self._st
+        up = lambda arr, dt: torch.from_numpy(np.ascontiguousarray(arr)).to(dt).pin_memory()
+        st["irp"][self._n_img + 1:self._n_img + 1 + n_new].copy_(up(np.asarray(irp), torch.int32), non_blocking=True)
+        st["rep"][self._n_ref + 1:nref + 1].copy_(up(np.asarray(rep), torch.int32), non_blocking=True)
+        st["key"][self._n_ent:nent].copy_(up(np.concatenate(K).reshape(-1, 4), torch.int32), non_blocking=True)
+        st["ord"][self._n_ent:nent].copy_(up(np.concatenate(O), torch.int32), non_blocking=True)
+        st["w"][self._n_ent:nent].copy_(up(np.concatenate(W), torch.float64), non_blocking=True)
+        st["norm"][self._n_ref:nref].copy_(up(np.concatenate(N).reshape(-1, 4), torch.float64), non_blocking=True)
+        st["len"][self._n_ref:nref].copy_(up(np.concatenate(L), torch.int32), non_blocking=True)
+        torch.cuda.current_stream(self.device).synchronize()       # cold path only: the pinned temporaries go out of scope
+        for j, i in enumerate(new):
+            self._slot[i] = self._n_img + j
+        self._n_img += n_new
+        self._n_ref, self._n_ent = nref, nent
+
+    def _slots(self, img_ids, gts):
+        """Store rows of the batch as a device int32 tensor (uploading first whatever the store does not hold yet)."""
+        slot = self._slot
+        try:
+            rows = [slot[i] for i in img_ids]
+        except KeyError:
+            self._append(img_ids, gts)
+            rows = [slot[i] for i in img_ids]
+        B = len(rows)
+        if not self._idx_ring or self._idx_ring[0].numel() < B:
+            self._idx_ring = [torch.zeros(max(B, 256), dtype=torch.int32).pin_memory() for _ in range(8)]
+            self._idx_ev = [None] * 8
+        k = self._idx_i = (self._idx_i + 1) % 8
+        if self._idx_ev[k] is not None:
+            self._idx_ev[k].synchronize()                           # the copy issued 8 batches ago has left this buffer
+        host = self._idx_ring[k]
+        host.numpy()[:B] = rows
+        dev = self._idx_dev.get(B)
+        if dev is None:
+            dev = self._idx_dev[B] = torch.zeros(B, dtype=torch.int32, device=self.device)
+        dev.copy_(host[:B], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._idx_ev[k] = ev
+        return dev
 
     # ---- scoring ---------------------------------------------------------------------------------
     def reward(self, gen, greedy, ground_truth, img_ids, return_scores=False):
@@ -190,7 +263,8 @@ class CiderDReward:
         B, T = gen.shape
         gen = gen.to(device=self.device, dtype=torch.int64).contiguous()
         greedy = greedy.to(device=self.device, dtype=torch.int64).contiguous()
-        irp, rep, K, O, W, N, L = self._batch(list(img_ids), ground_truth)
+        idx = self._slots(list(img_ids), ground_truth)
+        st = self._st
         if self.persistent:       # stable addresses for hipGraph replay downstream (overwritten by the next call)
             key = (B, T)
             if key not in self._out:
@@ -200,6 +274,7 @@ class CiderDReward:
         else:
             reward = torch.empty(B, T, dtype=torch.float32, device=self.device)
             scores = torch.empty(2 * B, dtype=torch.float64, device=self.device)
-        check(lib().icz_ciderd_reward(self._h, ptr(gen), ptr(greedy), B, T, ptr(irp), ptr(rep), ptr(K), ptr(O), ptr(W),
-                                      ptr(N), ptr(L), ptr(reward), ptr(scores), stream_ptr()))
+        check(lib().icz_ciderd_reward_indexed(self._h, ptr(gen), ptr(greedy), B, T, ptr(idx), ptr(st["irp"]), ptr(st["rep"]),
+                                              ptr(st["key"]), ptr(st["ord"]), ptr(st["w"]), ptr(st["norm"]), ptr(st["len"]),
+                                              ptr(reward), ptr(scores), stream_ptr()))
         return (reward, scores) if return_scores else reward

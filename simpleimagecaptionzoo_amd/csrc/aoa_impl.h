@@ -69,7 +69,8 @@ struct Aoa {
     float ss_prob = 0.f; const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // scheduled sampling in xe_forward
     BeamBuf bm;
     // training buffers (aoa_train.hip), slot stride = max_rows: th/tm/tctx slot 0 = zeros, slot t+1 = after step t
-    bool tready = false;
+    int tcap_B = 0, tcap_T = 0;          // capacity of the training buffers (grown on demand by ensure_train)
+    std::vector<void*> tallocs; bool alloc_train = false;
     int64_t* tok = nullptr;
     float *th = nullptr, *tm = nullptr, *tctx = nullptr, *temb = nullptr, *tu = nullptr, *tg = nullptr, *tstats = nullptr, *tqn = nullptr,
           *tQp = nullptr, *tP = nullptr, *tPd = nullptr, *tdS = nullptr, *tdX = nullptr, *txatt = nullptr, *tz = nullptr, *tcd = nullptr, *tlogit = nullptr;
@@ -108,12 +109,13 @@ struct Aoa {
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
+        for (void* p : tallocs) (void)hipFree(p);
         for (void* p : allocs) (void)hipFree(p);
     }
     int alloc(void** p, size_t bytes) {
         ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
         ICZ_CHECK_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
-        allocs.push_back(*p);
+        (alloc_train ? tallocs : allocs).push_back(*p);
         return ICZ_OK;
     }
     int init(const icz_aoa_dims& d);
@@ -138,7 +140,7 @@ struct Aoa {
         return d;
     }
     // training paths (aoa_train.hip)
-    int ensure_train();
+    int ensure_train(int B, int T);
     AoaStepIO train_io(int rows, int t, bool train);
     int sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st);

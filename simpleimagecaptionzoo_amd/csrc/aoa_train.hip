@@ -208,10 +208,23 @@ __global__ void aoa_gather_packed_kernel(const float* __restrict__ logit, int V,
 
 }  // namespace
 
-int Aoa::ensure_train() {
-    if (tready) return ICZ_OK;
+// Training buffers sized by what the batches ask for (the reference never truncates captions, Datasets.py:47-51: the step
+// count of an XE batch is only known when it arrives); growing re-allocates them all.
+int Aoa::ensure_train(int Bq, int Tq) {
+    if (Bq <= tcap_B && Tq <= tcap_T) return ICZ_OK;
     ICZ_REQUIRE(dims.Hd <= 4096, "aoa: training paths keep a LayerNorm row in registers (hidden size %d > 4096)", dims.Hd);
-    const size_t B = dims.max_rows, T = dims.max_len, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
+    ICZ_REQUIRE(Tq <= XE_MAX_T, "aoa: %d steps exceed the limit of %d", Tq, XE_MAX_T);
+    if (tcap_B > Bq) Bq = tcap_B;
+    if (tcap_T > Tq) Tq = tcap_T;
+    if (dims.max_len > Tq) Tq = dims.max_len;
+    if (!tallocs.empty()) {
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+        for (void* p : tallocs) (void)hipFree(p);
+        tallocs.clear();
+        tcap_B = tcap_T = 0; mode = 0;
+    }
+    struct Scope { bool& f; Scope(bool& x) : f(x) { f = true; } ~Scope() { f = false; } } scope(alloc_train);
+    const size_t B = Bq, T = Tq, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
     {
         const size_t dh = Hd / NH, lds_bwd = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128 + 4);
         if (lds_bwd > 48 * 1024)
@@ -251,7 +264,7 @@ int Aoa::ensure_train() {
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
-    tready = true;
+    tcap_B = Bq; tcap_T = Tq;
     return ICZ_OK;
 }
 
@@ -274,9 +287,9 @@ AoaStepIO Aoa::train_io(int rows, int t, bool train) {
 }
 
 int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
-    ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0 && T <= dims.max_len, "aoa sample: bad arguments");
+    ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0, "aoa sample: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
-    ICZ_TRY(ensure_train());
+    ICZ_TRY(ensure_train(B, T));
     use_bank(1);
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
@@ -334,7 +347,8 @@ int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* lo
     ICZ_REQUIRE(mode == 1, "aoa: no rollout stored (call icz_aoa_sample first)");
     ICZ_REQUIRE(reward && G, "aoa sample_backward: null argument");
     const int B = cur_B, T = cur_T;
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
+    if (msum_global >= 0.f)      // < 0: keep the device value handed over by icz_aoa_set_norm_global
+        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
     hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum, coef, loss_out, msum_out);
     hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, draw, lse, coef, B, T);
     mode = 0;
@@ -352,8 +366,7 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
         ICZ_REQUIRE(b == 0 || lengths[b] <= lengths[b - 1], "aoa xe_forward: lengths must be sorted in decreasing order");
         if (lengths[b] > T) T = lengths[b];
     }
-    ICZ_REQUIRE(T <= dims.max_len, "aoa xe_forward: %d steps exceed max_len %d", T, dims.max_len);
-    ICZ_TRY(ensure_train());
+    ICZ_TRY(ensure_train(B, T));
     use_bank(1);
     if (r) rng = *r; else rng = {};
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
@@ -400,15 +413,16 @@ int Aoa::xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, 
     ICZ_REQUIRE(G, "aoa xe_backward: null grads");
     const int B = cur_B, T = cur_T;
     const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
+    const float* n_dev = n_tokens_global < 0.f ? d_msum : nullptr;      // < 0: the device scalar handed over by *_set_*_global
     ICZ_CHECK_HIP(hipMemsetAsync(loss_rows, 0, sizeof(float) * T * B, st));
     {
         ICZ_REQUIRE(T <= XE_MAX_T, "xe_backward: %d steps exceed %d", T, XE_MAX_T);
         XeRows xr = {};
         for (int t = 0; t < T; ++t) xr.n[t] = rows_t[t];
-        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tlogit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n,
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tlogit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n, n_dev,
                            loss_rows);
     }
-    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, loss_out);
+    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     mode = 0;
     return bptt(*G, st);
 }
@@ -567,6 +581,20 @@ int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions
                        const icz_aoa_rng* rng, int32_t train, float* packed_logits_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Aoa*>(h)->xe_forward(feats, captions, B, L, lengths_host, rng, train, packed_logits_out, (hipStream_t)stream);
+}
+int icz_aoa_saved_alphas(icz_aoa_t* h, float* alphas_out, void* stream) {
+    ICZ_REQUIRE(h && alphas_out, "icz_aoa_saved_alphas: null argument");
+    Aoa* a = reinterpret_cast<Aoa*>(h);
+    ICZ_REQUIRE(a->mode != 0 && a->tP, "icz_aoa_saved_alphas: no forward pass stored");
+    const int n = a->cur_B * a->cur_T * a->cur_R;
+    hipLaunchKernelGGL(saved_alphas_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a->tP, a->cur_T, a->cur_B, a->dims.NH, a->cur_R, alphas_out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+int icz_aoa_set_norm_global(icz_aoa_t* h, const float* norm_dev, void* stream) {
+    ICZ_REQUIRE(h && norm_dev, "icz_aoa_set_norm_global: null argument");
+    ICZ_CHECK_HIP(hipMemcpyAsync(reinterpret_cast<Aoa*>(h)->d_msum, norm_dev, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ICZ_OK;
 }
 int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global, void* stream) {
     ICZ_REQUIRE(h, "null handle");

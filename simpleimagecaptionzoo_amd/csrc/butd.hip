@@ -18,8 +18,13 @@ void set_error(const char* fmt, ...) {
 // ------------------------------------------------------------------------------------------------
 int Butd::alloc(void** p, size_t bytes) {
     ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
-    allocs.push_back(*p);
+    (alloc_train ? tallocs : allocs).push_back(*p);
     return ICZ_OK;
+}
+
+void Butd::clear_graphs() {
+    for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
+    graphs.clear();
 }
 
 int Butd::init(const icz_butd_dims& d) {
@@ -75,9 +80,10 @@ Butd::~Butd() {
     if (ev_join2) (void)hipEventDestroy(ev_join2);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
-    for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
+    clear_graphs();
     if (cap_st) (void)hipStreamDestroy(cap_st);
     if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
+    for (void* p : tallocs) (void)hipFree(p);
     for (void* p : allocs) (void)hipFree(p);
 }
 
@@ -296,6 +302,12 @@ int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* p) {
         ICZ_REQUIRE(((uintptr_t)q[i] & 15) == 0 || i == 16 || i == 17, "icz_butd_bind_params: parameter %zu not 16-byte aligned", i);
     }
     Butd* b = reinterpret_cast<Butd*>(h);
+    // the captured graphs carry the old parameter pointers in their kernel arguments (embed_weight, the LSTM weights and
+    // biases ...): a rebind to other tensors must not replay them
+    if (b->bound && memcmp(&b->P, p, sizeof(*p)) != 0) {
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+        b->clear_graphs();
+    }
     b->P = *p;
     b->bound = true;
     b->fresh = false;

@@ -67,6 +67,8 @@ struct Butd {
     icz_butd_params P;
     bool bound = false, fresh = false;
     std::vector<void*> allocs;
+    std::vector<void*> tallocs;          // training buffers (TrainBuf): re-allocated when a batch needs more rows / steps
+    bool alloc_train = false;            // alloc() target: tallocs instead of allocs
 
     // weight-normed weights (w = g v / ||v||) and the row norms ||v||
     float *w_enc = nullptr, *w_dec = nullptr, *w_aff = nullptr, *w_pred = nullptr;
@@ -105,6 +107,7 @@ struct Butd {
     hipStream_t cap_st = nullptr;
     uint64_t tick = 0;
     template <class F> int run_cached(const std::vector<uintptr_t>& key, hipStream_t st, F&& fn);
+    void clear_graphs();                 // captured kernel arguments hold parameter / buffer addresses: drop them when those change
     int greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
     int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
     int greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);

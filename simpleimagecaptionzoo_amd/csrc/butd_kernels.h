@@ -457,6 +457,17 @@ __global__ __launch_bounds__(256) void zero_bufs_kernel(ZeroList z, size_t n) {
     for (int k = 0; k < z.count; ++k) *reinterpret_cast<f32x4*>(z.p[k] + i) = zero;
 }
 
+// attention maps of a stored forward pass, [T, B, NH, R] -> [B, T, R] averaged over the NH heads (BUTD: NH = 1)
+__global__ void saved_alphas_kernel(const float* __restrict__ src, int T, int B, int NH, int R, float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * T * R) return;
+    const int r = i % R, t = (i / R) % T, b = i / (R * T);
+    const float* p = src + ((size_t)(t * B + b) * NH) * R + r;
+    float s = 0.f;
+    for (int h = 0; h < NH; ++h) s += p[(size_t)h * R];
+    out[i] = s / (float)NH;
+}
+
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -759,10 +770,12 @@ constexpr int XE_MAX_T = 128;
 struct XeRows { int n[XE_MAX_T]; };
 __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict__ logits, int V, int ldl,
                                                               const int64_t* __restrict__ captions, int L, int B, XeRows rows,
-                                                              float smoothing, float inv_n, float* __restrict__ loss_rows) {
+                                                              float smoothing, float inv_n_host, const float* __restrict__ n_dev,
+                                                              float* __restrict__ loss_rows) {
     __shared__ float smf[4];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     if (b >= rows.n[t]) return;
+    const float inv_n = n_dev ? 1.0f / n_dev[0] : inv_n_host;      // data-parallel: the all-reduced token count, a device scalar
     const int row = t * B + b;
     float* l = logits + (size_t)row * ldl;
     float mx = -INFINITY;
@@ -791,8 +804,10 @@ __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict_
 }
 
 // sum of n floats in fixed order by one workgroup, scaled
-__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale, float* __restrict__ out) {
+__global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale_host, const float* __restrict__ n_dev,
+                                                        float* __restrict__ out) {
     __shared__ float smf[4];
+    const float scale = n_dev ? 1.0f / n_dev[0] : scale_host;
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += x[i];
     s = block_sum_256(s, smf);

@@ -18,10 +18,23 @@ __global__ void sample_init_kernel(uint8_t* unf, int* nunf, int64_t* tok, int B,
 int Butd::ensure_train(int B, int T) {
     if (tb.B >= B && tb.T >= T) return ICZ_OK;
     ICZ_REQUIRE(B <= dims.max_rows, "butd: batch %d exceeds capacity %d", B, dims.max_rows);
-    ICZ_REQUIRE(T <= dims.max_len, "butd: %d steps exceed max_len %d", T, dims.max_len);
-    // allocate once for the handle's full capacity
-    B = dims.max_rows;
-    T = dims.max_len;
+    ICZ_REQUIRE(T <= XE_MAX_T, "butd: %d steps exceed the limit of %d", T, XE_MAX_T);
+    // Sized by what the batches ask for, not by the handle's row capacity (which also covers images x beam rows): the
+    // reference never truncates captions (Datasets.py:47-51), so the step count of an XE batch is only known when it
+    // arrives.  Growing re-allocates everything: the rollout / XE activations kept for a pending backward are lost (callers
+    // run forward and backward of one batch back to back) and every captured graph holds stale addresses.
+    if (tb.B > B) B = tb.B;
+    if (tb.T > T) T = tb.T;
+    if (dims.max_len > T) T = dims.max_len;
+    if (!tallocs.empty()) {
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+        clear_graphs();
+        for (void* p : tallocs) (void)hipFree(p);
+        tallocs.clear();
+        tb = TrainBuf();
+        mode = 0;
+    }
+    struct Scope { bool& f; Scope(bool& x) : f(x) { f = true; } ~Scope() { f = false; } } scope(alloc_train);
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
     const size_t Vp = round4(dims.V);
     const size_t TB = (size_t)T * B;
@@ -70,6 +83,8 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dWdec, sizeof(float) * A * H));
     ICZ_TRY(zalloc((void**)&tb.dWaff, sizeof(float) * A));
     ICZ_TRY(zalloc((void**)&tb.scalars, sizeof(float) * 16));
+    ICZ_TRY(zalloc((void**)&tb.scalars_i, sizeof(int) * 2 * T));
+    tb.scalars_i_cap = 2 * T;
     (void)V;
     tb.B = B;
     tb.T = T;
@@ -311,10 +326,7 @@ int Butd::upload_pack_index(hipStream_t st) {
     std::vector<int> hostv(2 * T);
     int acc = 0;
     for (int t = 0; t < T; ++t) { hostv[t] = acc; hostv[T + t] = rows_t[t]; acc += rows_t[t]; }
-    if (!tb.scalars_i) {
-        ICZ_TRY(alloc((void**)&tb.scalars_i, sizeof(int) * 2 * dims.max_len));
-        tb.scalars_i_cap = 2 * dims.max_len;
-    }
+    ICZ_REQUIRE(tb.scalars_i && 2 * T <= tb.scalars_i_cap, "butd: pack index capacity");
     ICZ_CHECK_HIP(hipMemcpyAsync(tb.scalars_i, hostv.data(), sizeof(int) * 2 * T, hipMemcpyHostToDevice, st));
     ICZ_CHECK_HIP(hipStreamSynchronize(st));   // the host vector goes out of scope
     return ICZ_OK;
@@ -368,15 +380,16 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
     const int B = cur_B, T = cur_T;
     const int Vp = round4(dims.V);
     const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
+    const float* n_dev = n_tokens_global < 0.f ? d_msum_global : nullptr;      // < 0: the device scalar handed over by *_set_*_global
     ICZ_CHECK_HIP(hipMemsetAsync(tb.loss_rows, 0, sizeof(float) * T * B, st));
     {
         ICZ_REQUIRE(T <= XE_MAX_T, "xe_backward: %d steps exceed %d", T, XE_MAX_T);
         XeRows xr = {};
         for (int t = 0; t < T; ++t) xr.n[t] = rows_t[t];
-        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tb.logit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n,
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tb.logit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n, n_dev,
                            tb.loss_rows);
     }
-    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, loss_out);
+    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
     return bptt(*G, st);
@@ -639,6 +652,15 @@ int icz_butd_xe_backward_dlogits(icz_butd_t* h, const float* dpacked, const icz_
 int icz_butd_sample_mask_sum(icz_butd_t* h, float* mask_sum_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Butd*>(h)->sample_mask_sum(mask_sum_out, (hipStream_t)stream);
+}
+int icz_butd_saved_alphas(icz_butd_t* h, float* alphas_out, void* stream) {
+    ICZ_REQUIRE(h && alphas_out, "icz_butd_saved_alphas: null argument");
+    Butd* b = reinterpret_cast<Butd*>(h);
+    ICZ_REQUIRE(b->mode != 0 && b->tb.alpha, "icz_butd_saved_alphas: no forward pass stored");
+    const int n = b->cur_B * b->cur_T * b->dims.R;
+    hipLaunchKernelGGL(saved_alphas_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, b->tb.alpha, b->cur_T, b->cur_B, 1, b->dims.R, alphas_out);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
 }
 int icz_butd_set_scheduled_sampling(icz_butd_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms) {
     ICZ_REQUIRE(h, "icz_butd_set_scheduled_sampling: null handle");

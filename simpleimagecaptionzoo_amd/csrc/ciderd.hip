@@ -35,6 +35,7 @@ __host__ __device__ inline uint32_t ngram_hash(int a, int b, int c, int d) {
 struct CiderArgs {
     const int32_t* keys; const double* idf; const double* penalty; int64_t cap; double default_idf;
     const int64_t* gen; const int64_t* greedy; int B, T;
+    const int32_t* img_slot;     // [B] slot of image b in the reference store, or null = b (the arrays below are the batch's own)
     const int32_t* img_ref_ptr; const int32_t* ref_ent_ptr; const int32_t* ent_key; const int32_t* ent_order;
     const double* ent_w; const double* ref_norm; const int32_t* ref_len;
     double* scores;      // [2B]
@@ -123,7 +124,8 @@ __global__ __launch_bounds__(64 * CD_NW) void ciderd_kernel(CiderArgs a) {
     }
     __syncthreads();
     // ---- references of this image, CD_NW at a time: wave w takes reference rc + w
-    const int r0 = a.img_ref_ptr[b], r1 = a.img_ref_ptr[b + 1];
+    const int slot = a.img_slot ? a.img_slot[b] : b;
+    const int r0 = a.img_ref_ptr[slot], r1 = a.img_ref_ptr[slot + 1];
     double score[4] = {0.0, 0.0, 0.0, 0.0};
     for (int rc = r0; rc < r1; rc += CD_NW) {
         const int r = rc + wave;
@@ -210,22 +212,39 @@ int icz_ciderd_destroy(icz_ciderd_t* h) {
     return ICZ_OK;
 }
 
-int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
-                      const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
-                      const int32_t* ent_order, const double* ent_w, const double* ref_norm, const int32_t* ref_len,
-                      float* reward_out, double* scores_out, void* stream) {
+static int ciderd_reward_impl(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T, const int32_t* img_slot,
+                              const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
+                              const int32_t* ent_order, const double* ent_w, const double* ref_norm, const int32_t* ref_len,
+                              float* reward_out, double* scores_out, void* stream) {
     ICZ_REQUIRE(h && gen && greedy && img_ref_ptr && ref_ent_ptr && ent_key && ent_order && ent_w && ref_norm && ref_len,
                 "icz_ciderd_reward: null argument");
     ICZ_REQUIRE(scores_out, "icz_ciderd_reward: scores_out (2B float64 scratch) is required");
     ICZ_REQUIRE(B > 0 && T > 0 && T <= CD_MAXT, "icz_ciderd_reward: T=%d out of range 1..%d", T, CD_MAXT);
     CiderD* c = reinterpret_cast<CiderD*>(h);
-    CiderArgs a = {c->keys, c->idf, c->penalty, c->cap, c->default_idf, gen, greedy, B, T,
+    CiderArgs a = {c->keys, c->idf, c->penalty, c->cap, c->default_idf, gen, greedy, B, T, img_slot,
                    img_ref_ptr, ref_ent_ptr, ent_key, ent_order, ent_w, ref_norm, ref_len, scores_out};
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(ciderd_kernel, dim3(2 * B), dim3(64 * CD_NW), 0, st, a);
     if (reward_out) hipLaunchKernelGGL(ciderd_reward_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, st, scores_out, B, T, reward_out);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
+}
+
+int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
+                      const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
+                      const int32_t* ent_order, const double* ent_w, const double* ref_norm, const int32_t* ref_len,
+                      float* reward_out, double* scores_out, void* stream) {
+    return ciderd_reward_impl(h, gen, greedy, B, T, nullptr, img_ref_ptr, ref_ent_ptr, ent_key, ent_order, ent_w, ref_norm, ref_len,
+                              reward_out, scores_out, stream);
+}
+
+int icz_ciderd_reward_indexed(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,
+                              const int32_t* img_slot, const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr,
+                              const int32_t* ent_key, const int32_t* ent_order, const double* ent_w, const double* ref_norm,
+                              const int32_t* ref_len, float* reward_out, double* scores_out, void* stream) {
+    ICZ_REQUIRE(img_slot, "icz_ciderd_reward_indexed: null img_slot");
+    return ciderd_reward_impl(h, gen, greedy, B, T, img_slot, img_ref_ptr, ref_ent_ptr, ent_key, ent_order, ent_w, ref_norm, ref_len,
+                              reward_out, scores_out, stream);
 }
 
 }  // extern "C"

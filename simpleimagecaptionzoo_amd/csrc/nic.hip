@@ -27,7 +27,8 @@ struct Nic {
     float ss_prob = 0.f; const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // scheduled sampling in xe_forward
     // training buffers (slot stride = capacity rows): th/tc slot 0 = zeros, slot 1 = after the image step, slot t+2 =
     // after token step t; tg / dG slot 0 = image step, slot t+1 = token step t
-    bool tready = false;
+    int tcap_B = 0, tcap_T = 0;          // capacity of the training buffers (grown on demand by ensure_train)
+    std::vector<void*> tallocs; bool alloc_train = false;
     int64_t* tok = nullptr;
     float *th = nullptr, *tc = nullptr, *temb = nullptr, *tg = nullptr, *thd = nullptr, *tlogit = nullptr;
     float *dG = nullptr, *dHd = nullptr, *dEmb = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *dWp = nullptr;
@@ -44,12 +45,13 @@ struct Nic {
 
     ~Nic() {
         if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);
+        for (void* p : tallocs) (void)hipFree(p);
         for (void* p : allocs) (void)hipFree(p);
     }
     int alloc(void** p, size_t bytes) {
         ICZ_CHECK_HIP(hipMalloc(p, bytes ? bytes : 16));
         ICZ_CHECK_HIP(hipMemset(*p, 0, bytes ? bytes : 16));
-        allocs.push_back(*p);
+        (alloc_train ? tallocs : allocs).push_back(*p);
         return ICZ_OK;
     }
     int init(const icz_nic_dims& d);
@@ -58,7 +60,7 @@ struct Nic {
     int token_step(int rows, const int64_t* tokens, bool emb_ready, const float* h_in, const float* c_in, float* h_out, float* c_out,
                    float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st);
     int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
-    int ensure_train();
+    int ensure_train(int B, int T);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_backward(const float* reward, const icz_nic_params* G, float* dfeats, float* loss_out, float* msum_out, float msum_global, hipStream_t st);
     int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_rng* r, int train,
@@ -161,9 +163,22 @@ int Nic::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
     return ICZ_OK;
 }
 
-int Nic::ensure_train() {
-    if (tready) return ICZ_OK;
-    const size_t B = dims.max_rows, T = dims.max_len, H = dims.H, E = dims.E;
+// Training buffers sized by what the batches ask for (the reference never truncates captions, Datasets.py:47-51: the step
+// count of an XE batch is only known when it arrives); growing re-allocates them all.
+int Nic::ensure_train(int Bq, int Tq) {
+    if (Bq <= tcap_B && Tq <= tcap_T) return ICZ_OK;
+    ICZ_REQUIRE(Tq <= XE_MAX_T, "nic: %d steps exceed the limit of %d", Tq, XE_MAX_T);
+    if (tcap_B > Bq) Bq = tcap_B;
+    if (tcap_T > Tq) Tq = tcap_T;
+    if (dims.max_len > Tq) Tq = dims.max_len;
+    if (!tallocs.empty()) {
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+        for (void* p : tallocs) (void)hipFree(p);
+        tallocs.clear();
+        tcap_B = tcap_T = 0; mode = 0;
+    }
+    struct Scope { bool& f; Scope(bool& x) : f(x) { f = true; } ~Scope() { f = false; } } scope(alloc_train);
+    const size_t B = Bq, T = Tq, H = dims.H, E = dims.E;
     const size_t TB = T * B;
     ICZ_TRY(alloc((void**)&tok, sizeof(int64_t) * (TB + B)));
     ICZ_TRY(alloc((void**)&th, sizeof(float) * (TB + 2 * B) * H));
@@ -187,7 +202,7 @@ int Nic::ensure_train() {
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
-    tready = true;
+    tcap_B = Bq; tcap_T = Tq;
     return ICZ_OK;
 }
 
@@ -200,9 +215,9 @@ static DropCfg nic_drop(const uint64_t* seed_p, bool train, const uint8_t* base,
 }
 
 int Nic::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
-    ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0 && T <= dims.max_len, "nic sample: bad arguments");
+    ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0, "nic sample: bad arguments");
     ICZ_REQUIRE(fresh, "nic: call icz_nic_refresh_weights after binding/updating parameters");
-    ICZ_TRY(ensure_train());
+    ICZ_TRY(ensure_train(B, T));
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats; cur_seq = seq_out; cur_logp = logp_out;
@@ -236,7 +251,8 @@ int Nic::sample_backward(const float* reward, const icz_nic_params* G, float* df
     ICZ_REQUIRE(mode == 1, "nic: no rollout stored (call icz_nic_sample first)");
     ICZ_REQUIRE(reward && G, "nic sample_backward: null argument");
     const int B = cur_B, T = cur_T;
-    hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
+    if (msum_global >= 0.f)      // < 0: keep the device value handed over by icz_nic_set_norm_global
+        hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
     hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum, coef, loss_out, msum_out);
     hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, draw, lse, coef, B, T);
     mode = 0;
@@ -267,8 +283,7 @@ int Nic::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
         ICZ_REQUIRE(b == 0 || lengths[b] <= lengths[b - 1], "nic xe_forward: lengths must be sorted in decreasing order");
         if (lengths[b] > T) T = lengths[b];
     }
-    ICZ_REQUIRE(T <= dims.max_len, "nic xe_forward: %d steps exceed max_len %d", T, dims.max_len);
-    ICZ_TRY(ensure_train());
+    ICZ_TRY(ensure_train(B, T));
     if (r) rng = *r; else rng = {};
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 2; cur_B = B; cur_T = T; cur_L = L; cur_train = train != 0; cur_feats = feats; cur_captions = captions;
@@ -312,15 +327,16 @@ int Nic::xe_backward(float smoothing, const icz_nic_params* G, float* dfeats, fl
     ICZ_REQUIRE(G, "nic xe_backward: null grads");
     const int B = cur_B, T = cur_T;
     const float n = n_tokens_global > 0.f ? n_tokens_global : (float)n_tokens;
+    const float* n_dev = n_tokens_global < 0.f ? d_msum : nullptr;      // < 0: the device scalar handed over by *_set_*_global
     ICZ_CHECK_HIP(hipMemsetAsync(loss_rows, 0, sizeof(float) * T * B, st));
     {
         ICZ_REQUIRE(T <= XE_MAX_T, "xe_backward: %d steps exceed %d", T, XE_MAX_T);
         XeRows xr = {};
         for (int t = 0; t < T; ++t) xr.n[t] = rows_t[t];
-        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tlogit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n,
+        hipLaunchKernelGGL(xe_loss_dlogits_kernel, dim3(B, T), dim3(256), 0, st, tlogit, dims.V, Vp, cur_captions, cur_L, B, xr, smoothing, 1.0f / n, n_dev,
                            loss_rows);
     }
-    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, loss_out);
+    if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     mode = 0;
     return bptt(*G, dfeats, st);
 }
@@ -517,6 +533,11 @@ int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* capti
                        const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Nic*>(h)->xe_forward(features, captions, B, L, lengths_host, rng, train, packed_logits_out, (hipStream_t)stream);
+}
+int icz_nic_set_norm_global(icz_nic_t* h, const float* norm_dev, void* stream) {
+    ICZ_REQUIRE(h && norm_dev, "icz_nic_set_norm_global: null argument");
+    ICZ_CHECK_HIP(hipMemcpyAsync(reinterpret_cast<Nic*>(h)->d_msum, norm_dev, sizeof(float), hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return ICZ_OK;
 }
 int icz_nic_xe_backward(icz_nic_t* h, float smoothing, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
                         float n_tokens_global, void* stream) {

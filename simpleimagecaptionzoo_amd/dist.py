@@ -64,20 +64,42 @@ def all_reduce_scalar(x):
     return float(t.item())
 
 
+def seed_for_rank(seed):
+    """Philox seed of this rank: replicas must not draw the same dropout masks / sampling uniforms for their local row b
+    (the streams are keyed by (seed, stream, step, element) and every shard numbers its rows from 0)."""
+    return (int(seed) + (rank() << 40)) & 0xFFFFFFFFFFFFFFFF
+
+
 def all_gather_rows(t):
-    """Concatenate per-rank (B_r, ...) tensors along dim 0 in rank order (B_r may differ between ranks)."""
+    """Concatenate per-rank (B_r, ...) tensors along dim 0 in rank order (B_r may differ between ranks): one all-gather of
+    the row counts (read back once), one of the rows padded to the largest count."""
     if not is_distributed():
         return t
     n = torch.tensor([t.shape[0]], dtype=torch.int64, device=t.device)
-    sizes = [torch.zeros_like(n) for _ in range(td.get_world_size())]
-    td.all_gather(sizes, n)
-    sizes = [int(s.item()) for s in sizes]
+    alln = torch.zeros(td.get_world_size(), dtype=torch.int64, device=t.device)
+    td.all_gather_into_tensor(alln, n)
+    sizes = alln.tolist()
     mx = max(sizes)
     pad = torch.zeros((mx,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
     pad[:t.shape[0]] = t
     outs = [torch.zeros_like(pad) for _ in sizes]
     td.all_gather(outs, pad)
     return torch.cat([o[:s] for o, s in zip(outs, sizes)], 0)
+
+
+def gather_caption_rows(keys, image_ids, rows, device, width=52):
+    """G3: all-gather the decoded captions of every rank and return (image ids, token rows) of ALL ranks ordered by `keys`
+    (the image's position in the loader).  rows: per image a 1-D array of token ids (greedy: 20; beam search: <sta> + at most
+    50 tokens + <end>), padded here with -1 to `width`."""
+    import numpy as np
+    pack = np.full((len(rows), 2 + width), -1, dtype=np.int64)
+    for j, r in enumerate(rows):
+        pack[j, 0], pack[j, 1] = keys[j], image_ids[j]
+        pack[j, 2:2 + len(r)] = np.asarray(r, dtype=np.int64)
+    dev = torch.device(device) if td.get_backend() == "nccl" else torch.device("cpu")
+    allp = all_gather_rows(torch.from_numpy(pack).to(dev)).cpu().numpy()
+    allp = allp[np.argsort(allp[:, 0], kind="stable")]
+    return [int(x) for x in allp[:, 1]], [row[2:][row[2:] >= 0] for row in allp]
 
 
 def shard_range(n, r=None, w=None):

@@ -135,6 +135,50 @@ class Engine(object):
     def model_construction(self, max_batch):
         raise NotImplementedError
 
+    # ---- checkpoints: the reference's files (Engine.py:43-70, 81-88) + the optimizer state next to them
+    def _cp_paths(self, scst, root=None):
+        import os
+        flag = "scst_" if scst else ""
+        cp_dir = os.path.join(root or "./CheckPoints/%s/" % self.tag, "cp")
+        return cp_dir, os.path.join(cp_dir, "Captioner_%scp.pth" % flag), os.path.join(cp_dir, "%sstate_histories.json" % flag), \
+            os.path.join(cp_dir, "Optimizer_%scp.pth" % flag)
+
+    def save_checkpoint(self, cider_scores, save_scst_model=False, optimizer=None, root=None):
+        """Engine.py:81-88: model state_dict + score history, same file names; with `optimizer` also its state
+        (`Optimizer_[scst_]cp.pth`, torch.optim layout) -- the reference re-creates Adam every epoch (Engine.py:133-136) and
+        loses the moments at every restart."""
+        import os
+        cp_dir, model_path, his_path, opt_path = self._cp_paths(save_scst_model, root)
+        os.makedirs(cp_dir, exist_ok=True)
+        torch.save(self.model.state_dict(), model_path)
+        json.dump({"cider_his": cider_scores}, open(his_path, "w"))
+        if optimizer is not None:
+            torch.save(optimizer.state_dict(), opt_path)
+
+    def load_from_checkpoint(self, load_scst_model=False, load_best=False, optimizer=None, root=None):
+        """Engine.py:43-70 (same files, same return value) + the optimizer state when `optimizer` is given and the file exists."""
+        import os
+        cp_dir, model_path, his_path, opt_path = self._cp_paths(load_scst_model, root)
+        cider_his, start_epoch = [], 1
+        best_not_found = False
+        if load_best:
+            best = os.path.join(os.path.dirname(cp_dir), "best", os.path.basename(model_path))
+            if os.path.exists(best):
+                self.model.load_state_dict(torch.load(best, map_location=self.device))
+            else:
+                best_not_found = True
+        if not load_best or best_not_found:
+            if os.path.exists(his_path):
+                cider_his = json.load(open(his_path, "r"))["cider_his"]
+            if os.path.exists(model_path):
+                self.model.load_state_dict(torch.load(model_path, map_location=self.device))
+            else:
+                print("recent checkpoint not found.")
+            if optimizer is not None and os.path.exists(opt_path):
+                optimizer.load_state_dict(torch.load(opt_path, map_location=self.device))
+            start_epoch = len(cider_his) + 1
+        return cider_his, start_epoch
+
 
 class BUTDDetection_Eng(Engine):
     """ModelEngines/BUTD_Engine.py:21-47 + the three hot Engine methods on libicz."""
@@ -310,8 +354,17 @@ class BUTDDetection_Eng(Engine):
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
             h.xe_forward(self._features(visual_inputs), captions, lengths, rng, train=True)
             grads = self._grads()
-            n_tok = float(sum(lengths))
-            n_glob = icz_dist.all_reduce_scalar(n_tok) if icz_dist.is_distributed() else 0.0
+            n_glob = 0.0
+            if icz_dist.is_distributed():
+                # G2: every rank scales by 1 / (global token count).  The count is all-reduced on the device
+                # and handed to the library as a device scalar: no host round trip between forward and backward
+                n_dev = torch.full((1,), float(sum(lengths)), dtype=torch.float32, device=self.device)
+                if hasattr(h, "set_mask_sum_global"):
+                    icz_dist.all_reduce_sum_(n_dev)
+                    h.set_mask_sum_global(n_dev)
+                    n_glob = -1.0
+                else:
+                    n_glob = icz_dist.all_reduce_scalar(n_dev)
             ov = self._reduce_grads_begin(h)
             loss = h.xe_backward(grads, smoothing, n_glob)
             self._reduce_grads_end(ov)
@@ -355,7 +408,7 @@ class BUTDDetection_Eng(Engine):
             loss, _ = h.sample_backward(rewards, grads, msum_glob)
             self._reduce_grads_end(ov)
             self._apply(optimizer, 0.25)
-            losses.append(loss)
+            losses.append(loss.clone())      # with graphs the handle returns one persistent buffer, overwritten by the next step
             if tqdm_visible:
                 monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))
         return losses
@@ -366,30 +419,45 @@ class BUTDDetection_Eng(Engine):
             return self._eval_captions_json_generation(dataloader, eval_beam_size, tqdm_visible)
 
     def _eval_captions_json_generation(self, dataloader, eval_beam_size=-1, tqdm_visible=True):
-        """Engine.py:274-300.  Beam search accepts any batch size here (the reference's loader uses 1)."""
+        """Engine.py:274-300.  Beam search accepts any batch size here (the reference's loader uses 1).
+        Data-parallel (torch.distributed initialised): every rank walks the same loader and decodes the
+        batches i with i % world == rank; the (image id, token ids) rows are all-gathered and every rank returns the
+        complete list in loader order -- what the corpus-level scorer after it (COCO_Eval_Utils.py:15-35) needs in one
+        place; rank 0 is the one that should write / score it."""
         self.model.eval()
-        result = []
         print("Generating captions json for evaluation. Beam Search: %s" % (eval_beam_size != -1))
         monitor = _monitor(dataloader, "Generating Process", tqdm_visible)
-        ix2word = self.caption_vocab.ix2word
+        dp = icz_dist.is_distributed()
+        rank, world = icz_dist.rank(), icz_dist.world_size()
+        ids_out, rows_out, keys_out, n_seen = [], [], [], 0
         for batch_i, (image_ids, img_tensors, supp_info_datas) in enumerate(monitor):
-            visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
-            h = self._hot_handle()
-            if eval_beam_size != -1:
-                seqs, lens = h.beam_search(self._features(visual_inputs), eval_beam_size, 50)
-                seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
-                rows = [seqs[i, :lens[i]] for i in range(len(lens))]
-            else:
-                rows = list(h.greedy(self._features(visual_inputs), 20).cpu().numpy())
-            for image_idx, sampled_ids in enumerate(rows):
-                sampled_caption = []
-                for word_id in sampled_ids:
-                    word = ix2word[int(word_id)]
-                    if word == "<end>":
-                        break
-                    elif word != "<sta>":
-                        sampled_caption.append(word)
-                result.append({"image_id": int(image_ids[image_idx]), "caption": " ".join(sampled_caption)})
+            nb = len(image_ids)
+            if not dp or batch_i % world == rank:
+                visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
+                h = self._hot_handle()
+                if eval_beam_size != -1:
+                    seqs, lens = h.beam_search(self._features(visual_inputs), eval_beam_size, 50)
+                    seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+                    rows = [seqs[i, :lens[i]] for i in range(len(lens))]
+                else:
+                    rows = list(h.greedy(self._features(visual_inputs), 20).cpu().numpy())
+                ids_out += [int(i) for i in image_ids]
+                rows_out += rows
+                keys_out += list(range(n_seen, n_seen + nb))
+            n_seen += nb
+        if dp:
+            ids_out, rows_out = icz_dist.gather_caption_rows(keys_out, ids_out, rows_out, self.device)
+        result = []
+        ix2word = self.caption_vocab.ix2word
+        for image_id, sampled_ids in zip(ids_out, rows_out):
+            sampled_caption = []
+            for word_id in sampled_ids:
+                word = ix2word[int(word_id)]
+                if word == "<end>":
+                    break
+                elif word != "<sta>":
+                    sampled_caption.append(word)
+            result.append({"image_id": image_id, "caption": " ".join(sampled_caption)})
         return result
 
 

@@ -128,10 +128,17 @@ class DevicePrefetcher:
     """Iterate `loader` (batch tuples of Datasets.py:153-175: img_ids first, supp_info_datas last) one batch ahead of the
     consumer.  Features come from `store` (by image id) or, without a store, from the tuples' own supp_info_datas."""
 
-    def __init__(self, loader, device="cuda:0", store=None, depth=2):
-        self.loader, self.store = loader, store
+    def __init__(self, loader, device="cuda:0", store=None, depth=3, on_batch=None, gather_threads=4):
+        """on_batch(batch): optional host-side work for a batch, run on the worker thread before the batch is handed over
+        (e.g. CiderDReward.prepare: cooking the references of images the scorer has not seen yet).  gather_threads: the copy
+        of a batch's per-image features into pinned memory is split over this many threads (numpy copies release the GIL)."""
+        self.loader, self.store, self.on_batch = loader, store, on_batch
         self.device = torch.device(device)
         self.depth = max(2, int(depth))
+        self._pool = None
+        if gather_threads > 1:
+            from concurrent.futures import ThreadPoolExecutor
+            self._pool, self._nthr = ThreadPoolExecutor(max_workers=gather_threads), gather_threads
         self.copy_stream = torch.cuda.Stream(device=self.device)
         self._pinned, self._dev, self._ready, self._free = [None] * self.depth, [None] * self.depth, [None] * self.depth, [None] * self.depth
 
@@ -156,9 +163,16 @@ class DevicePrefetcher:
             self.store.gather_into(img_ids, host)
             boxes = [self.store[i]["bu_bbox"] for i in img_ids]
         else:
-            for j, s in enumerate(supp):
-                host[j, :counts[j]] = s["bu_feat"]
-                host[j, counts[j]:] = 0
+            def fill(lo, hi):
+                for j in range(lo, hi):
+                    host[j, :counts[j]] = supp[j]["bu_feat"]
+                    host[j, counts[j]:] = 0
+            if self._pool is not None and B >= 2 * self._nthr:
+                per = (B + self._nthr - 1) // self._nthr
+                for f in [self._pool.submit(fill, lo, min(B, lo + per)) for lo in range(0, B, per)]:
+                    f.result()
+            else:
+                fill(0, B)
             boxes = [s["bu_bbox"] for s in supp]
         with torch.cuda.stream(self.copy_stream):
             dev.copy_(pinned, non_blocking=True)
@@ -192,6 +206,8 @@ class DevicePrefetcher:
                     if stop.is_set():
                         return
                     released[slot].clear()
+                    if self.on_batch is not None:
+                        self.on_batch(batch)
                     todo.put((slot, self._stage(slot, batch), None))
                     slot = (slot + 1) % self.depth
                 todo.put((None, None, None))

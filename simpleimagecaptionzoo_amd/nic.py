@@ -41,8 +41,13 @@ class NicHandle:
         return greedy, seq, lp
 
     def sample_mask_sum(self):
+        """Local sum of the REINFORCE mask (Utils.py:307-309) as a 1-element DEVICE tensor (no host round trip)."""
         seq = self._live[2]
-        return float((seq[:, :-1] > 0).sum().item() + seq.shape[0])
+        return ((seq[:, :-1] > 0).sum() + seq.shape[0]).float().view(1)
+
+    def set_mask_sum_global(self, t):
+        """DP: the all-reduced loss normaliser as a 1-element device tensor; then pass -1 as the global normaliser."""
+        check(lib().icz_nic_set_norm_global(self._h, ptr(t), stream_ptr()))
 
     def bind(self, tensors):
         st = NicParams()
@@ -193,8 +198,9 @@ class NICDecoder_Captioner(nn.Module, ScheduledSamplingState):
         return self._h
 
     def _next_rng(self):
+        from .dist import seed_for_rank
         self._seed += 1
-        return make_rng(self._seed)
+        return make_rng(seed_for_rank(self._seed))       # data-parallel replicas draw independent streams
 
     def _features(self, visual_inputs):
         if "img_feats" in visual_inputs:
@@ -212,8 +218,7 @@ class NICDecoder_Captioner(nn.Module, ScheduledSamplingState):
 
     def sampler_rl(self, visual_inputs, max_len=20, rng=None):
         """NIC_Model.py:275-287 (fused path: no autograd graph; use the handle's sample_backward)."""
-        self._seed += 1
-        return self._handle().sample(self._features(visual_inputs).detach(), max_len, rng or make_rng(self._seed))
+        return self._handle().sample(self._features(visual_inputs).detach(), max_len, rng or self._next_rng())
 
     def beam_search_sampler(self, visual_inputs, beam_size=5):
         """NIC_Model.py:289-301."""
@@ -229,3 +234,20 @@ class NICDecoder_Captioner(nn.Module, ScheduledSamplingState):
         logits = self._handle().xe_forward(self._features(visual_inputs).detach(), captions, list(lengths),
                                            (rng or make_rng(self._seed)) if train else None, train=train, want_logits=True)
         return (logits, None)
+
+    def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):
+        """NIC_Model.py:306-331 -> (caption words, []): NIC has no attention maps."""
+        feats = self._features(visual_inputs).detach()
+        assert feats.size(0) == 1
+        if eval_beam_size != -1:
+            ids = self.beam_search_sampler(visual_inputs, eval_beam_size)
+        else:
+            ids = self.sampler(visual_inputs, max_len)
+        caption = []
+        for word_id in ids[0].cpu().numpy():
+            word = caption_vocab.ix2word[int(word_id)]
+            if word == "<end>":
+                break
+            elif word != "<sta>":
+                caption.append(word)
+        return caption, []

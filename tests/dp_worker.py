@@ -39,6 +39,15 @@ def main():
         td.all_reduce(t)
         return float(t.item())
 
+    # G3: evaluation sharded over the ranks batch by batch, rows all-gathered: every rank must return the JSON
+    # the reference Engine produced in one process, in loader order (batches of 3 / 1 images: unequal shares)
+    ef = feats_from_seed(int(g["eval_feats_seed"]), B, R, D)
+    eids = tuple(int(i) for i in g["eval_img_ids"])
+    loader3 = [(eids[i:i + 3], None, tge._supp(ef[i:i + 3])) for i in range(0, B, 3)]
+    loader1 = [(eids[i:i + 1], None, tge._supp(ef[i:i + 1])) for i in range(B)]
+    assert eng.eval_captions_json_generation(loader3, eval_beam_size=-1, tqdm_visible=False) == fx["eval_greedy_json"]
+    assert eng.eval_captions_json_generation(loader1, eval_beam_size=3, tqdm_visible=False) == fx["eval_beam3_json"]
+
     opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 4e-4}), 4e-4)
     for s in range(2):
         pre = "xe%d_" % s

@@ -238,8 +238,9 @@ def df_to_json(df):
 
 
 # ------------------------------------------------------------------------------------------------
-def gen_butd_decoder(tag, B, R, D, H, E, A, V, seed):
-    """G-step, G-greedy, G-beam, G-xe, G-rl on Models/BUTD_Model.py DecoderRNN."""
+def gen_butd_decoder(tag, B, R, D, H, E, A, V, seed, cap_len=(6, 13)):
+    """G-step, G-greedy, G-beam, G-xe, G-rl on Models/BUTD_Model.py DecoderRNN.  cap_len: range of the XE caption lengths
+    (incl. <sta> / <end>); the reference never truncates captions (Datasets.py:47-51)."""
     from Models.BUTD_Model import DecoderRNN
     from Utils import LabelSmoothingLoss, RewardCriterion
     from torch.nn.utils.rnn import pack_padded_sequence
@@ -308,7 +309,7 @@ def gen_butd_decoder(tag, B, R, D, H, E, A, V, seed):
     out["beam_end_bias"] = np.array([np.nan, 4.0, -1e4, np.nan], dtype=np.float32)
 
     # ---- G-xe (BUTD_Model.py:97-151 + Utils.py:268-286 + Engine.py:178-187), train mode, injected masks
-    lengths_full = sorted(rng.randint(6, 13, size=B).tolist(), reverse=True)  # incl. <sta> and <end>
+    lengths_full = sorted(rng.randint(cap_len[0], cap_len[1], size=B).tolist(), reverse=True)  # incl. <sta> and <end>
     L = max(lengths_full)
     caps = np.zeros((B, L), dtype=np.int64)
     for b, l in enumerate(lengths_full):
@@ -1018,10 +1019,15 @@ def gen_engine(tag, seed, B=6, V=53, H=16, E=16, A=16):
 if __name__ == "__main__":
     bootstrap()
     torch.set_num_threads(4)
-    which = sys.argv[1:] or ["butd", "nic", "aoa", "cider", "corpus", "engine"]
+    which = sys.argv[1:] or ["butd", "butd2", "nic", "aoa", "cider", "corpus", "engine"]
     if "butd" in which:
         gen_butd_decoder("butd_dec_tiny", B=5, R=36, D=64, H=32, E=32, A=32, V=53, seed=11)
         gen_butd_decoder("butd_dec_odd", B=3, R=36, D=96, H=48, E=16, A=64, V=70, seed=12)
+    if "butd2" in which:
+        # BUTDSpatial_Captioner's decoder (BUTD_Model.py:321-440 builds the same DecoderRNN over the 7 x 7 = 49 grid cells of
+        # EncoderCNN, BASELINE config 2) and a batch of long captions (more XE time steps than any decode runs)
+        gen_butd_decoder("butd_dec_spatial", B=4, R=49, D=64, H=32, E=32, A=32, V=53, seed=13)
+        gen_butd_decoder("butd_dec_long", B=3, R=36, D=32, H=16, E=16, A=16, V=53, seed=14, cap_len=(28, 43))
     if "nic" in which:
         gen_nic_decoder("nic_dec_tiny", B=5, H=32, E=32, V=53, seed=31)
         gen_nic_decoder("nic_dec_odd", B=3, H=48, E=16, V=70, seed=32)

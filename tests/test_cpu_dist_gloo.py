@@ -57,6 +57,13 @@ def _worker(rank, world, port, out):
     D.all_reduce_sum_(flat)                       # G1
     loss = D.all_reduce_scalar(loss_part)
     ids = D.all_gather_rows(torch.arange(lo, hi).view(-1, 1))   # G3 with unequal shard sizes
+    # G3 as the Engine's evaluation uses it: rank r decoded the batches i with i % world == r (3 images per batch, ragged
+    # token rows); every rank gets all captions back in loader order
+    mine = [i for i in range(10) if (i // 3) % world == rank]
+    cap_ids, cap_rows = D.gather_caption_rows(mine, [1000 + i for i in mine], [np.arange(4, 4 + 1 + i % 5) for i in mine], "cpu")
+    assert cap_ids == [1000 + i for i in range(10)]
+    assert all(r.tolist() == list(range(4, 4 + 1 + i % 5)) for i, r in enumerate(cap_rows))
+    assert D.seed_for_rank(7) != 7 or rank == 0
     if rank == 0:
         torch.save({"flat": flat, "loss": loss, "msum": msum, "ids": ids}, out)
     torch.distributed.barrier()

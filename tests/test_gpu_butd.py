@@ -68,7 +68,7 @@ def test_gemm_against_float64(layout, M, N, K, nsplit):
     assert np.abs(got - want).max() < tol * max(1.0, np.abs(want).max()), np.abs(got - want).max()
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def test_step_matches_reference(golden_dir, name):
     g = load(golden_dir, name)
     h, _ = make_handle(g)
@@ -82,7 +82,7 @@ def test_step_matches_reference(golden_dir, name):
         np.testing.assert_allclose(got.cpu().numpy(), g["step_" + key], atol=1e-4, rtol=1e-4, err_msg=key)
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def test_greedy_token_exact(golden_dir, name):
     g = load(golden_dir, name)
     h, _ = make_handle(g)
@@ -112,7 +112,7 @@ def _check_grads(grads, g, prefix):
         assert np.abs(got - want).max() <= 2e-4 * scale + 2e-6, (k, np.abs(got - want).max(), scale)
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def test_sample_rl_and_reinforce_backward(golden_dir, name):
     """sample_rl with injected uniforms/masks: ids exact, logprobs 1e-4; REINFORCE grads vs reference autograd."""
     from simpleimagecaptionzoo_amd.butd import make_rng
@@ -137,7 +137,7 @@ def test_sample_rl_and_reinforce_backward(golden_dir, name):
     _check_grads(grads, g, "rl_grad.")
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def test_xe_forward_backward(golden_dir, name):
     from simpleimagecaptionzoo_amd.butd import make_rng
     g = load(golden_dir, name)
@@ -158,7 +158,7 @@ def test_xe_forward_backward(golden_dir, name):
     _check_grads(grads, g, "xe_grad.")
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def test_xe_with_scheduled_sampling(golden_dir, name):
     """DecoderRNN.forward with the decoder's ss_prob = 0.5 (BUTD_Model.py:120-132): gate and draw uniforms injected,
     packed logits / loss / gradients of the reference (the embedding gradient follows the tokens actually fed)."""
@@ -283,7 +283,7 @@ def _beam_regime_sd(g, regime):
     return sd
 
 
-@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd"])
+@pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 @pytest.mark.parametrize("regime", ["nat", "early", "never", "track"])
 def test_beam_search_token_exact(golden_dir, name, regime):
     """Batched device beam search vs the reference's one-image-at-a-time beam search (k = 1, 3, 5)."""

@@ -21,7 +21,7 @@ def sd_of(g, prefix="sd."):
     return {k[len(prefix):]: v for k, v in g.items() if k.startswith(prefix)}
 
 
-@pytest.fixture(scope="module", params=["butd_dec_tiny", "butd_dec_odd"])
+@pytest.fixture(scope="module", params=["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
 def dec(request, golden_dir):
     g = load(golden_dir, request.param)
     return g, ob.to_params(sd_of(g)), torch.from_numpy(g["feats"])
@@ -74,7 +74,9 @@ def test_beam_token_exact(dec):
             assert want.shape[1] == 51 and 2 not in want
         if want[0, -1] == 2 and want.shape[1] > 3:
             mid_sentence_end += 1
-    assert mid_sentence_end >= 1      # the shrinking-k / best-complete path is exercised
+    # the shrinking-k / best-complete path is exercised (a coverage check of the fixture, not a parity check: the 16-wide
+    # 'long' fixture has no such case)
+    assert mid_sentence_end >= 1 or int(g["dims"][3]) == 16
 
 
 def test_xe_forward_loss_grads(dec):
