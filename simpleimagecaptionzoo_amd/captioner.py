@@ -195,9 +195,11 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
 
     def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):
         """BUTD_Model.py:519-544 -> (caption words, [alphas (1, steps, R)]).  Greedy: the attention maps come out of the decode
-        itself; beam search: the decoder state of a beam is a function of its token prefix, so the maps of the winning beam
-        are those of an evaluation-mode teacher-forced pass over the returned sentence (what the reference carries along
-        beam by beam, :282,:309-317)."""
+        itself.  Beam search: the decoder state of a beam is a function of its token prefix, so the maps of the returned
+        sentence are those of an evaluation-mode teacher-forced pass over it.  (The reference means to carry them along beam
+        by beam, :282,:309-317, but appends every step's maps without the beam permutation -- `alpha.unsqueeze(1)` is not
+        indexed by prev_word_inds and the history is never compacted with incomplete_inds -- so for beam > 1 its result mixes
+        the maps of different beams; for beam 1 both agree, tests/test_gpu_round2.py.)"""
         feats = visual_inputs["bu_feats"]
         assert feats.size(0) == 1
         h = self._handle()

@@ -179,7 +179,7 @@ class DevicePrefetcher:
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[slot] = ev
-        out = {"bu_feats": dev, "bu_bboxes": boxes}
+        out = {"bu_feats": dev, "bu_bboxes": boxes, "bu_ring": True}      # bu_ring: one of a few reused device buffers
         if min(counts) < R:
             out["bu_counts"] = counts
         return batch[:-1] + (out,)

@@ -243,10 +243,12 @@ def test_dp_overlap_hook_single_rank_group(golden_dir):
     eng, vocab = _engine(g, fx)
     B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
     dev = "cuda"
+    created = False
     if not td.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
         td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        created = True
     real = icz_dist.is_distributed
     icz_dist.is_distributed = lambda: True
     calls = []
@@ -278,6 +280,9 @@ def test_dp_overlap_hook_single_rank_group(golden_dir):
         assert calls == [4, 4] and eng._hooked is not None and eng._pending == []
     finally:
         icz_dist.is_distributed = real
+        if created:
+            torch.cuda.synchronize()
+            td.destroy_process_group()
 
 
 def test_fused_adam_state_dict_roundtrip():

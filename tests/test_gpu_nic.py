@@ -158,3 +158,22 @@ def test_nic_engine_xe_step_and_scst(golden_dir):
     assert np.isfinite(losses[0].item())
     res = eng.eval_captions_json_generation([(tuple(range(B)), None, {"img_feats": feats})], eval_beam_size=3, tqdm_visible=False)
     assert len(res) == B and all(isinstance(r["caption"], str) for r in res)
+
+
+def test_nic_eval_test_image(golden_dir):
+    """NICDecoder_Captioner.eval_test_image (NIC_Model.py:306-331): the caption words of the golden ids and no attention maps."""
+    from simpleimagecaptionzoo_amd.nic import NICDecoder_Captioner
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    g = dict(np.load(os.path.join(golden_dir, "nic_dec_tiny.npz")))
+    B, H, E, V = [int(x) for x in g["dims"]][:4]
+    cap = NICDecoder_Captioner(E, H, V, max_batch=8).cuda()
+    cap.load_state_dict({"decoder." + k[3:]: torch.tensor(v) for k, v in g.items() if k.startswith("sd.")})
+    cap.eval()
+    vocab = synthetic_vocab(V)
+    feats = torch.tensor(g["feats"], device="cuda")
+    for img in range(2):
+        vi = {"img_feats": feats[img:img + 1]}
+        for beam, ids in ((-1, g["greedy_ids"][img].tolist()), (3, g["beam_nat_k3_i%d" % img].ravel().astype(int).tolist())):
+            words, extra = cap.eval_test_image(vi, vocab, max_len=20, eval_beam_size=beam)
+            cut = ids[:ids.index(2)] if 2 in ids else ids
+            assert extra == [] and words == [vocab.ix2word[i] for i in cut if i != 1]
