@@ -291,7 +291,6 @@ def test_aoa_eval_test_image_words_and_attention_maps(g):
     """AoADetection_Captioner.eval_test_image (AoA_Model.py:755-786; Engine.py:325,339): the caption of the golden greedy / beam
     ids and the head-averaged decoder attention of every step (:118) -- the oracle's, step by step over the same tokens."""
     from oracle import aoa as oa
-    from oracle.butd import to_params
     from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner
     from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
     B, R, D, Hd, E, V, NH = dims(g)
@@ -300,7 +299,8 @@ def test_aoa_eval_test_image_words_and_attention_maps(g):
     cap.load_state_dict({k: torch.tensor(v) for k, v in sd.items()})
     cap.eval()
     vocab = synthetic_vocab(V)
-    p = to_params(sd)
+    p = {k: torch.tensor(np.asarray(v), dtype=torch.float32) for k, v in sd.items()}
+    oa_nh, oa.NH = oa.NH, NH
     feats = feats_of(g)
     for img in range(2):
         vi = {"bu_feats": feats[img:img + 1], "bu_bboxes": None, "bu_masks": None}
@@ -317,3 +317,4 @@ def test_aoa_eval_test_image_words_and_attention_maps(g):
                 want.append(al)
             assert tuple(alphas.shape) == (1, len(fed), R)
             np.testing.assert_allclose(alphas.cpu().numpy()[0], torch.cat(want, 0).numpy(), atol=1e-4)
+    oa.NH = oa_nh
