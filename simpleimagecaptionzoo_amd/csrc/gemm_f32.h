@@ -42,6 +42,11 @@ struct GemmSeg {
     int K;
     // optional row gather for A (NT only): row m of A is A + gather[m]*lda, with ReLU applied on load
     const int64_t* gather;
+    // optional (NT, skinny split-precision kernel): the three bf16 pieces of A, written by A's producer (split3_planes.h):
+    // piece p of element (m, k) at Apl[p * Apl_stride + m * lda + perm(k)], perm = the kernel's k order inside 32-blocks.
+    // All segments of a launch must carry them for the kernel to use them (else it splits A itself).
+    const unsigned short* Apl;
+    long long Apl_stride;
 };
 
 struct GemmArgs {
@@ -67,5 +72,14 @@ size_t gemm_slab_floats(int M, int N, int nsplit);
 int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit);
 // the largest split <= nsplit whose slabs fit the given capacity
 int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capacity_floats);
+
+// gemm_skinny_x3.hip: NT at 33..128 rows with split-precision operands (the decoder-step GEMMs); ICZ_GEMM_SKINNY_X3=0 keeps
+// the fp32-MFMA kernel.  Stage depth 64 (a.chunks_per_split counts 64-deep chunks), column tile 64 or 128.
+bool gemm_skinny_x3_enabled();
+bool gemm_skinny_x3_fits(const GemmArgs& a);
+int gemm_skinny_x3_tile_n(const GemmArgs& a);
+int gemm_skinny_x3(const GemmArgs& a, hipStream_t stream);
+struct Planes;
+int split3_planes(const float* x, int rows, int K, int ld, Planes pl, hipStream_t st);
 
 }  // namespace icz

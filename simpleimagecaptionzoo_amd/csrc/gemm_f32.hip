@@ -1111,6 +1111,7 @@ size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)
 
 // NT pipeline-stage depth: 128 when every segment's K is a multiple of 128 and the tile is full height (MT = 4)
 static int nt_stage_k(const GemmArgs& a) {
+    if (gemm_skinny_x3_fits(a)) return 64;
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_GEMM_BK"); force = e ? atoi(e) : 0; }
     if (a.M <= 32) return 64;
@@ -1166,7 +1167,7 @@ static bool nt_x3(const GemmArgs& a) {
 static bool nt_x3big(const GemmArgs& a) {
     static int on = -1;
     if (on < 0) { const char* e = getenv("ICZ_GEMM_NT_X3BIG"); on = e ? atoi(e) : 1; }
-    if (!on || a.M < 128 || a.N < 128) return false;
+    if (!on || a.M < 128 || a.N < 128 || gemm_skinny_x3_fits(a)) return false;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return false;
     const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
@@ -1180,7 +1181,7 @@ static int nt_waves(const GemmArgs& a) {
     return 8;
 }
 // NT column-tile width: 16 columns per wave; 8-wave workgroups (two waves per SIMD sharing one staged A chunk) -> 128
-static int nt_tile_n(const GemmArgs& a) { return 16 * nt_waves(a); }
+static int nt_tile_n(const GemmArgs& a) { return gemm_skinny_x3_fits(a) ? gemm_skinny_x3_tile_n(a) : 16 * nt_waves(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     if (layout == GEMM_NT && nt_x3big(a)) {
@@ -1196,6 +1197,7 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     }
     if (X3_NBUF == 1 && layout == GEMM_NT && a.M > 32 && nt_x3(a)) target_wgs *= 2;       // two workgroups of the split-precision kernel per CU
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
+    if (layout == GEMM_NT && gemm_skinny_x3_fits(a)) tiles = cdiv(a.N, nt_tile_n(a));        // one row tile of up to 128 rows
     int tot = total_chunks(a, stage_k(layout, a));
     int s = target_wgs / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -1304,8 +1306,9 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         const int bn = nt_tile_n(a);
         dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
         hipEvent_t e0 = nullptr, e1 = nullptr;
+        const bool skinny = gemm_skinny_x3_fits(a);
         // inside a stream capture the two records become event nodes of the graph: every replay refreshes them
-        if (g_prof.on && mt == 4 && (g_prof.seen++ % g_prof.every) == 0) {
+        if (g_prof.on && (mt == 4 || skinny) && (g_prof.seen++ % g_prof.every) == 0) {
             if (g_prof.used + 2 <= g_prof.ev.size()) {
                 e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
                 g_prof.used += 2;
@@ -1315,6 +1318,11 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         }
 #define ICZ_NT(MT_, NTW_, BK_) do { if (tail) hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, true, BK_>), grid, block, 0, stream, a); \
                                     else hipLaunchKernelGGL((gemm_nt_kernel<MT_, NTW_, false, BK_>), grid, block, 0, stream, a); } while (0)
+        if (skinny) {
+            const int st = gemm_skinny_x3(a, stream);
+            if (e1) (void)hipEventRecord(e1, stream);
+            return st;
+        }
         if (mt == 4 && nt_x3(a)) {
             static bool attr_done = false;
             if (!attr_done) {
