@@ -348,10 +348,11 @@ def main():
         "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 throughout (float64 CIDEr-D); GEMMs multiply fp32 operands as three bf16 pieces each (24 mantissa "
-                      "bits, six bf16 MFMAs per product, fp32 accumulation): fp32-level error, pinned against float64 in "
-                      "tests/test_gpu_butd.py and inside every parity bound of tests/; `fp32_mfma_gemms` is the same bench with "
-                      "every GEMM on the fp32-input MFMA instead",
+        "arithmetic": "fp32 throughout (float64 CIDEr-D): the 64-row decoder-step GEMMs on the fp32-input MFMA; the 128 x 128-tile GEMMs "
+                      "(weight gradients, the dgrad over all time steps, forward GEMMs of 128+ rows) multiply fp32 operands as three "
+                      "bf16 pieces each (24 mantissa bits, six bf16 MFMAs per product, fp32 accumulation): fp32-level error, held to "
+                      "3e-6 of the largest output against float64 in tests/test_gpu_butd.py and inside every parity bound of tests/; "
+                      "`fp32_mfma_gemms` is the same bench with every GEMM on the fp32-input MFMA",
         "config": {"workload": "BUTDDetection SCST step (greedy + sampled rollout + CIDEr-D reward + REINFORCE backward "
                                "+ clamp + Adam), batch %d per GPU, 36x2048 features, H=E=A=1024, V=10102, 20 decode steps" % B,
                    "global_batch": world * B, "parallelism": "dp%d" % world},
@@ -379,9 +380,11 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
     kern = max(pair - max(empty_pair - 1.7, 0.0), 1e-3) if pair > 0 else 0.0
     gbs = bytes_pl / (kern * 1e-6) / 1e9 if kern > 0 else 0.0
     tf = flops_pl / (kern * 1e-6) / 1e12 if kern > 0 else 0.0
-    # split-precision kernel: 6 bf16 MFMAs per fp32 product; dense bf16 peak 2.5 PFLOP/s -> 417 TFLOP/s of fp32-equivalent products
-    x3_peak = 2500.0 / 6.0
-    t_hbm, t_mfma = bytes_pl / (HBM_PEAK_GBS * 1e9), flops_pl / (x3_peak * 1e12)
+    # The decoder-step GEMMs run on the fp32-input MFMA (157.3 TFLOP/s: the vector rate) unless ICZ_GEMM_SKINNY_X3=1 selects the
+    # split-precision kernel (6 bf16 MFMAs per fp32 product: 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent products)
+    x3 = os.environ.get("ICZ_GEMM_SKINNY_X3", "0") not in ("", "0")
+    mfma_peak = 2500.0 / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS
+    t_hbm, t_mfma = bytes_pl / (HBM_PEAK_GBS * 1e9), flops_pl / (mfma_peak * 1e12)
     traffic, src = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
@@ -390,14 +393,18 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
         src = "profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters cannot be read in-process)"
     except Exception:
         pass
-    roof = {"kernel": "decoder-step forward GEMMs at 64..128 rows (LSTM gates, dec_att, predict): gemm_skinny_x3_kernel / gemm_nt_kernel<4>"}
+    roof = {"kernel": "decoder-step forward GEMMs at 64 rows (LSTM gates, dec_att, predict, prologue hoists): " +
+                      ("gemm_skinny_x3_kernel (split precision)" if x3 else "gemm_nt_kernel<4,1,false,128,4,true> (fp32-input MFMA)")}
     if t_mfma >= t_hbm:
-        roof.update({"bound": "mfma", "achieved": tf, "peak": x3_peak, "unit": "TFLOP/s", "frac": tf / x3_peak})
+        roof.update({"bound": "mfma", "achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak})
     else:
         roof.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS})
     roof.update({"traffic": traffic, "traffic_source": src, "avg_launch_us": kern, "event_pair_us": pair, "empty_kernel_pair_us": empty_pair,
                  "launches": launches, "bytes_per_launch": bytes_pl, "flops_per_launch": flops_pl,
-                 "roofline_us_per_launch": {"hbm": t_hbm * 1e6, "mfma_bf16x3": t_mfma * 1e6, "mfma_f32": flops_pl / (MFMA_F32_PEAK_TFLOPS * 1e12) * 1e6},
+                 "roofline_us_per_launch": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
+                 "l1_path_note": "measured in round 2 (csrc/gemm_skinny_x3.hip, MEASURED): at 64 rows these GEMMs are bound by the bytes a "
+                                 "compute unit pulls through its vector-memory path, weights AND the activation tile every workgroup "
+                                 "re-reads from L2 (~14 B/cycle/CU for both together), plus ~30 % of fixed prologue / epilogue per launch",
                  "measured": "HIP event pair around every launch (eager single-stream re-run of bench steps right after the timed region) "
                              "minus the pair around an empty kernel + 1.7 us",
                  "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS})

@@ -1181,7 +1181,17 @@ static int nt_waves(const GemmArgs& a) {
     return 8;
 }
 // NT column-tile width: 16 columns per wave; 8-wave workgroups (two waves per SIMD sharing one staged A chunk) -> 128
-static int nt_tile_n(const GemmArgs& a) { return gemm_skinny_x3_fits(a) ? gemm_skinny_x3_tile_n(a) : 16 * nt_waves(a); }
+// ICZ_GEMM_NTW=2 (development): two 16-column tiles per wave on the 64-row decoder-step shapes -> 128 columns per workgroup,
+// half the activation bytes per weight byte through the L1 path (see gemm_skinny_x3.hip, MEASURED)
+static int nt_ntw(const GemmArgs& a) {
+    static int ntw = -1;
+    if (ntw < 0) { const char* e = getenv("ICZ_GEMM_NTW"); ntw = e ? atoi(e) : 1; }
+    if (ntw != 2 || a.M <= 32 || a.M > 64 || a.N < 2048 || a.N > 8192) return 1;
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % 128) return 1;
+    return 2;
+}
+static int nt_tile_n(const GemmArgs& a) { return gemm_skinny_x3_fits(a) ? gemm_skinny_x3_tile_n(a) : 16 * nt_waves(a) * nt_ntw(a); }
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     if (layout == GEMM_NT && nt_x3big(a)) {
@@ -1333,6 +1343,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         }
         else if (mt == 1) ICZ_NT(1, 1, 64);
         else if (mt == 2) ICZ_NT(2, 1, 64);
+        else if (nt_ntw(a) == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, false, 128, 4, false>), grid, block, 0, stream, a);
         else if (nt_stage_k(a) == 128 && nt_waves(a) == 8) {
             hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 8>), grid, dim3(512), 0, stream, a);
         }

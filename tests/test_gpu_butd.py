@@ -71,8 +71,9 @@ def test_gemm_against_float64(layout, M, N, K, nsplit):
     # Against the exact (float64) product of the same fp32 operands: 3e-6 of the largest output for EVERY kernel -- fp32 MFMA
     # (k-ordered fp32 fma chains) and split precision (three bf16 pieces per operand, six bf16 MFMAs per product, fp32
     # accumulation: the dropped piece products are below 3 * 2^-24 |x w|) alike.  bf16 operands would miss it 1000-fold.
+    # (fp32 accumulation itself grows like sqrt(K): the bound is scaled accordingly beyond K = 4096, the decoder's longest)
     err = np.abs(got - want).max() / max(1.0, np.abs(want).max())
-    assert err < 3e-6, err
+    assert err < 3e-6 * max(1.0, np.sqrt(K / 4096.0)), err
 
 
 @pytest.mark.parametrize("name", ["butd_dec_tiny", "butd_dec_odd", "butd_dec_spatial", "butd_dec_long"])
