@@ -308,6 +308,15 @@ int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy
                       const int32_t* img_ref_ptr, const int32_t* ref_ent_ptr, const int32_t* ent_key,
                       const int32_t* ent_order, const double* ent_w, const double* ref_norm,
                       const int32_t* ref_len, float* reward_out, double* scores_out, void* stream);
+/* Host-side cooking of references (ciderD_scorer.py:17-32, 128-153) from token ids into the flat arrays above -- pure host code,
+ * HOST pointers throughout.  df_keys_host / df_idf_host: the table of icz_ciderd_create in host memory (it must then also hold
+ * the n-grams that contain out-of-vocabulary words, under the private ids the caller gives those words).  tokens: the token
+ * ids of n_refs references back to back, reference r = tokens[ref_tok_ptr[r] .. ref_tok_ptr[r+1]).  Outputs sized by the
+ * caller (max_ent entries; at most 4 * tokens in all): ref_ent_ptr_out [n_refs+1] counts from 0. */
+int icz_ciderd_cook_host(const int32_t* df_keys_host, const double* df_idf_host, int64_t cap, double default_idf,
+                         const int32_t* tokens, const int32_t* ref_tok_ptr, int32_t n_refs, int64_t max_ent,
+                         int32_t* ent_key_out, int32_t* ent_order_out, double* ent_w_out, int32_t* ref_ent_ptr_out,
+                         double* ref_norm_out, int32_t* ref_len_out, int64_t* n_ent_out);
 /* The same against a device-resident STORE of cooked references (every image of the dataset cooked once, instead of the
  * reference's re-cooking of the batch's references on every call, ciderD.py:41-52): the seven arrays are the store's, laid
  * out as above with one CSR row per stored image, and img_slot [B] int32 (device) names the store row of image b of the

@@ -163,6 +163,7 @@ def lib():
         "icz_ciderd_create": (C.c_int, [vp, vp, i64, C.c_double, vp, C.POINTER(vp)]),
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
+        "icz_ciderd_cook_host": (C.c_int, [vp, vp, i64, C.c_double, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
         "icz_ciderd_reward_indexed": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
         "icz_prof_pair_overhead": (C.c_int, [vp, i32, C.POINTER(C.c_double)]),

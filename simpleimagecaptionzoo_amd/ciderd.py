@@ -41,29 +41,27 @@ def _ngrams(ids, n=4):
     return counts
 
 
-class CiderDReward:
-    """Device-resident CIDEr-D scorer for SCST.
+class ReferenceCooker:
+    """Host side of the scorer: the document-frequency table over id n-grams and the cooking of references (n-gram tf-idf
+    vectors, norms, bigram length; ciderD_scorer.py:17-32, 128-153).  No device memory: usable without a GPU.
 
-    document_frequency: {tuple of words: count}; ref_len: number of training images (both straight from the
-    reference's '<dataset>-train.p' pickle); word2ix: the caption vocabulary."""
+    document_frequency: {tuple of words: count}; ref_len: number of training images (both straight from the reference's
+    '<dataset>-train.p' pickle); word2ix: the caption vocabulary."""
 
-    def __init__(self, document_frequency, ref_len, word2ix, device="cuda:0", sigma=6.0):
-        self.device = torch.device(device)
+    def __init__(self, document_frequency, ref_len, word2ix):
+        import threading
         self.word2ix = dict(word2ix)
         self.V = len(self.word2ix)
         self._ext = {}                       # out-of-vocabulary reference words -> private ids >= V
+        self._ext_lock = threading.Lock()
         self.log_ref_len = float(np.log(float(ref_len)))
         self._df = document_frequency
         self._log_cache = {}
-        # ---- df table restricted to n-grams made of vocabulary words (only those can be looked up by hypotheses)
+        # ---- df table over id n-grams.  Words outside the caption vocabulary get private ids >= V right here, so that the
+        #      n-grams containing them keep their document frequency for the reference weights (hypotheses never look them up)
         keys, vals = [], []
-        w2i = self.word2ix
         for gram, cnt in document_frequency.items():
-            try:
-                ids = [w2i[w] for w in gram]
-            except KeyError:
-                continue
-            keys.append(ids + [-1] * (4 - len(ids)))
+            keys.append([self._word_id(w) for w in gram] + [-1] * (4 - len(gram)))
             vals.append(self._idf(cnt))
         n = len(keys)
         cap = 2
@@ -91,30 +89,8 @@ class CiderDReward:
                 placed[win] = True
                 todo = todo[~placed[todo]]
                 probe[todo] += 1
-        self._keys = torch.from_numpy(tkeys).to(self.device)
-        self._idf_t = torch.from_numpy(tidf).to(self.device)
-        pen = np.array([np.e ** (-(float(d) ** 2) / (2 * sigma ** 2)) for d in range(64)], dtype=np.float64)
-        self._pen = torch.from_numpy(pen).to(self.device)
-        self._h = C.c_void_p()
-        check(lib().icz_ciderd_create(ptr(self._keys), ptr(self._idf_t), cap, self.log_ref_len, ptr(self._pen),
-                                      C.byref(self._h)))
-        self.persistent = False
-        self._out = {}
-        self._cooked = {}                    # image id -> cooked reference arrays (host), until they are in the store
-        self._store_init()
+        self.keys_host, self.idf_host, self.cap = tkeys, tidf, cap
 
-    def close(self):
-        if self._h:
-            lib().icz_ciderd_destroy(self._h)
-            self._h = C.c_void_p()
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
-
-    # ---- host-side cooking ---------------------------------------------------------------------
     def _idf(self, cnt):
         v = self._log_cache.get(cnt)
         if v is None:
@@ -127,12 +103,16 @@ class CiderDReward:
         if i is None:
             i = self._ext.get(w)
             if i is None:
-                i = self.V + len(self._ext)
-                self._ext[w] = i
+                with self._ext_lock:         # a loader's worker thread cooks too (CiderDReward.prepare)
+                    i = self._ext.get(w)
+                    if i is None:
+                        i = self.V + len(self._ext)
+                        self._ext[w] = i
         return i
 
     def cook_image(self, refs):
-        """refs: list of reference strings of one image -> (ent_ptr, keys, order, w, norm, length)."""
+        """refs: list of reference strings of one image -> (ent_ptr, keys, order, w, norm, length).  The Python statement of
+        what icz_ciderd_cook_host does (cook_images below); kept as its checker (tests/test_cpu_abi_and_host.py)."""
         ent_ptr, keys, order, ws, norms, lens = [0], [], [], [], [], []
         for ref in refs:
             words = ref.split()
@@ -154,6 +134,72 @@ class CiderDReward:
             ent_ptr.append(len(keys))
         return (np.asarray(ent_ptr, np.int32), np.asarray(keys, np.int32).reshape(-1, 4), np.asarray(order, np.int32),
                 np.asarray(ws, np.float64), np.asarray(norms, np.float64).reshape(-1, 4), np.asarray(lens, np.int32))
+
+    def cook_images(self, refs_per_image):
+        """[[reference strings of image 0], ...] -> one (ent_ptr, keys, order, w, norm, length) tuple per image, through the
+        library's host cooker (one call for all of them, outside the GIL)."""
+        tok, tptr, nref = [], [0], []
+        get, wid = self.word2ix.get, self._word_id
+        for refs in refs_per_image:
+            nref.append(len(refs))
+            for ref in refs:
+                ids = [get(w) for w in ref.split()]
+                if None in ids:              # out-of-vocabulary words: private ids
+                    ids = [wid(w) for w in ref.split()]
+                tok += ids
+                tptr.append(len(tok))
+        n_refs = len(tptr) - 1
+        tok = np.asarray(tok, dtype=np.int32)
+        tptr = np.asarray(tptr, dtype=np.int32)
+        max_ent = 4 * max(1, tok.size)
+        K, O = np.empty((max_ent, 4), np.int32), np.empty(max_ent, np.int32)
+        W, EP = np.empty(max_ent, np.float64), np.empty(n_refs + 1, np.int32)
+        N, L = np.empty((max(1, n_refs), 4), np.float64), np.empty(max(1, n_refs), np.int32)
+        ne = C.c_int64()
+        P = lambda a: a.ctypes.data_as(C.c_void_p)
+        check(lib().icz_ciderd_cook_host(P(self.keys_host), P(self.idf_host), self.cap, self.log_ref_len, P(tok), P(tptr), n_refs, max_ent,
+                                         P(K), P(O), P(W), P(EP), P(N), P(L), C.byref(ne)))
+        out, r0 = [], 0
+        for nr in nref:
+            e0, e1 = int(EP[r0]), int(EP[r0 + nr])
+            out.append(((EP[r0:r0 + nr + 1] - e0).astype(np.int32), K[e0:e1].copy(), O[e0:e1].copy(), W[e0:e1].copy(), N[r0:r0 + nr].copy(),
+                        L[r0:r0 + nr].copy()))
+            r0 += nr
+        return out
+
+
+class CiderDReward:
+    """Device-resident CIDEr-D scorer for SCST (arguments as ReferenceCooker's)."""
+
+    def __init__(self, document_frequency, ref_len, word2ix, device="cuda:0", sigma=6.0):
+        self.device = torch.device(device)
+        self.cooker = ReferenceCooker(document_frequency, ref_len, word2ix)
+        self.V = self.cooker.V
+        self._keys = torch.from_numpy(self.cooker.keys_host).to(self.device)
+        self._idf_t = torch.from_numpy(self.cooker.idf_host).to(self.device)
+        pen = np.array([np.e ** (-(float(d) ** 2) / (2 * sigma ** 2)) for d in range(64)], dtype=np.float64)
+        self._pen = torch.from_numpy(pen).to(self.device)
+        self._h = C.c_void_p()
+        check(lib().icz_ciderd_create(ptr(self._keys), ptr(self._idf_t), self.cooker.cap, self.cooker.log_ref_len, ptr(self._pen),
+                                      C.byref(self._h)))
+        self.persistent = False
+        self._out = {}
+        self._cooked = {}                    # image id -> cooked reference arrays (host), until they are in the store
+        self._store_init()
+
+    def close(self):
+        if self._h:
+            lib().icz_ciderd_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def cook_image(self, refs):
+        return self.cooker.cook_image(refs)
 
     # ---- device-resident reference store -----------------------------------------------------
     # Every image's cooked references are uploaded ONCE, appended to seven growing device arrays (CSR over stored images ->
@@ -183,10 +229,11 @@ class CiderDReward:
 
     def prepare(self, img_ids, gts):
         """Cook the references of images not seen before (host only, thread-safe: a loader's worker thread calls this for
-        batch i+1 while batch i is on the device, features.DevicePrefetcher(on_batch=...))."""
-        for i in img_ids:
-            if i not in self._slot and i not in self._cooked:
-                self._cooked[i] = self.cook_image(gts[i])
+        batch i+1 while batch i is on the device, features.DevicePrefetcher(on_batch=...); the cooker runs outside the GIL)."""
+        new = [i for i in dict.fromkeys(img_ids) if i not in self._slot and i not in self._cooked]
+        if new:
+            for i, c in zip(new, self.cooker.cook_images([gts[i] for i in new])):
+                self._cooked[i] = c
 
     def preload(self, gts):
         """Cook and upload the references of a whole dataset split ({image id: [reference strings]}) ahead of training."""
@@ -216,15 +263,14 @@ class CiderDReward:
         for name in ("key", "ord", "w"):
             self._grow(name, nent)
         st = self._st
-        up = lambda arr, dt: torch.from_numpy(np.ascontiguousarray(arr)).to(dt).pin_memory()
-        st["irp"][self._n_img + 1:self._n_img + 1 + n_new].copy_(up(np.asarray(irp), torch.int32), non_blocking=True)
-        st["rep"][self._n_ref + 1:nref + 1].copy_(up(np.asarray(rep), torch.int32), non_blocking=True)
-        st["key"][self._n_ent:nent].copy_(up(np.concatenate(K).reshape(-1, 4), torch.int32), non_blocking=True)
-        st["ord"][self._n_ent:nent].copy_(up(np.concatenate(O), torch.int32), non_blocking=True)
-        st["w"][self._n_ent:nent].copy_(up(np.concatenate(W), torch.float64), non_blocking=True)
-        st["norm"][self._n_ref:nref].copy_(up(np.concatenate(N).reshape(-1, 4), torch.float64), non_blocking=True)
-        st["len"][self._n_ref:nref].copy_(up(np.concatenate(L), torch.int32), non_blocking=True)
-        torch.cuda.current_stream(self.device).synchronize()       # cold path only: the pinned temporaries go out of scope
+        up = lambda arr, dt: torch.from_numpy(np.ascontiguousarray(arr)).to(dt)      # small pageable copies: cold path only
+        st["irp"][self._n_img + 1:self._n_img + 1 + n_new].copy_(up(np.asarray(irp), torch.int32))
+        st["rep"][self._n_ref + 1:nref + 1].copy_(up(np.asarray(rep), torch.int32))
+        st["key"][self._n_ent:nent].copy_(up(np.concatenate(K).reshape(-1, 4), torch.int32))
+        st["ord"][self._n_ent:nent].copy_(up(np.concatenate(O), torch.int32))
+        st["w"][self._n_ent:nent].copy_(up(np.concatenate(W), torch.float64))
+        st["norm"][self._n_ref:nref].copy_(up(np.concatenate(N).reshape(-1, 4), torch.float64))
+        st["len"][self._n_ref:nref].copy_(up(np.concatenate(L), torch.int32))
         for j, i in enumerate(new):
             self._slot[i] = self._n_img + j
         self._n_img += n_new

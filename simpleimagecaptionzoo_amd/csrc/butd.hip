@@ -193,8 +193,13 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         ns = g.nsplit;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A};
-        hipLaunchKernelGGL(att_scores_kernel, dim3(rows, ATT_PARTS), dim3(256), sizeof(float) * A, st, a, s.drop_att);
         const int G = s.rows_per_img;
+        // compare the accumulation order: the per-row kernel sums a region row in the lane order of three regions at a time, the
+        // grouped one region by region -- identical per (row, region): a wave's lanes cover the same columns in the same order
+        if (G > 1 && G <= ATT_CTX_MAX_G && rows % G == 0 && s.drop_att.mode == 0 && sizeof(float) * A * G <= 60 * 1024)
+            hipLaunchKernelGGL(att_scores_group_kernel, dim3(rows / G, ATT_PARTS), dim3(256), sizeof(float) * A * G, st, a, G);
+        else
+            hipLaunchKernelGGL(att_scores_kernel, dim3(rows, ATT_PARTS), dim3(256), sizeof(float) * A, st, a, s.drop_att);
         if (G > 1 && G <= ATT_CTX_MAX_G && rows % G == 0 && !s.alpha_out2)
             hipLaunchKernelGGL(att_ctx_group_kernel, dim3(rows / G, cdiv(D, 512)), dim3(256), 0, st, s.feats, (const float*)scores,
                                s.alpha_out ? s.alpha_out : alpha, s.ctx_out ? s.ctx_out : ctx, R, D, G);

@@ -275,6 +275,64 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
     }
 }
 
+constexpr int ATT_CTX_MAX_G = 8;
+// The same for beam search, where the G = beam rows of an image sit next to each other (row = img * G + g) and share its
+// projected features: one workgroup per (image, part) builds the G dec_ctx rows in LDS and walks its regions once, every
+// region row of enc_ctx (A floats) is fetched once instead of G times (at 640 rows the per-row kernel re-reads 47 MB per
+// step through the caches).  Evaluation mode only (beam search has no dropout); same arithmetic and summation order per
+// row as att_scores_kernel.  Grid (n_img, parts).
+__global__ __launch_bounds__(256) void att_scores_group_kernel(AttScoreArgs a, int G) {
+    extern __shared__ __attribute__((aligned(16))) float sdec[];   // [G][A]
+    const int img = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const size_t MN = (size_t)a.rows * a.A;
+    for (int g = 0; g < G; ++g) {
+        const int row = img * G + g;
+        for (int c = tid * 4; c < a.A; c += 1024) {
+            const size_t off = (size_t)row * a.A + c;
+            f32x4 s = *reinterpret_cast<const f32x4*>(a.dec_slab + off);
+            for (int z = 1; z < a.nsplit; ++z) s += *reinterpret_cast<const f32x4*>(a.dec_slab + (size_t)z * MN + off);
+            s += *reinterpret_cast<const f32x4*>(a.b_dec + c);
+            *reinterpret_cast<f32x4*>(sdec + (size_t)g * a.A + c) = s;
+            if (a.dec_ctx_out && part == 0) *reinterpret_cast<f32x4*>(a.dec_ctx_out + off) = s;
+        }
+    }
+    __syncthreads();
+    const float baff = a.b_aff[0];
+    for (int i0 = wave; part + nparts * i0 < a.R; i0 += 4) {
+        const int r = part + nparts * i0;
+        const float* e = a.enc_ctx + ((size_t)img * a.R + r) * a.A;
+        float acc[ATT_CTX_MAX_G];
+#pragma unroll
+        for (int g = 0; g < ATT_CTX_MAX_G; ++g) acc[g] = 0.f;
+        for (int c0 = lane * 4; c0 < a.A; c0 += 1024) {
+            f32x4 x[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(e + min(c0 + 256 * u, a.A - 4));
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int c = c0 + 256 * u;
+                if (c < a.A) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
+#pragma unroll
+                    for (int g = 0; g < ATT_CTX_MAX_G; ++g)
+                        if (g < G) {
+                            const f32x4 d = *reinterpret_cast<const f32x4*>(sdec + (size_t)g * a.A + c);
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) acc[g] += fmaxf(x[u][j] + d[j], 0.f) * w[j];
+                        }
+                }
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < ATT_CTX_MAX_G; ++g)
+            if (g < G) {
+                const float v = wave_sum(acc[g]);
+                if (lane == 0) a.scores[(size_t)(img * G + g) * a.R + r] = v + baff;
+            }
+    }
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // softmax over regions + attention-weighted feature sum (:60-61):
 //   alpha = softmax_r(score[row,:]);  ctx[row, d] = sum_r alpha[r] * feats[img, r, d]
@@ -328,7 +386,6 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
 // features: one workgroup does the G rows of one image for its 512 columns, so every feature vector is fetched once
 // instead of G times (at 640 rows the per-row kernel moves 189 MB through the caches per step).  Same arithmetic and
 // summation order per row as att_ctx_kernel.  Grid (n_img, D/512).
-constexpr int ATT_CTX_MAX_G = 8;
 __global__ __launch_bounds__(256) void att_ctx_group_kernel(const float* __restrict__ feats, const float* __restrict__ scores,
                                                             float* __restrict__ alpha_out, float* __restrict__ ctx, int R, int D, int G) {
     __shared__ float sal[ATT_CTX_MAX_G][64];

@@ -6,6 +6,10 @@
 // matches the hypothesis against one of the image's cooked references at a time.  Every floating-point accumulation is
 // performed by one lane in the reference's dict-insertion order (per reference by the wave's lane 0, across references
 // by thread 0 in reference order), which makes the scores bit-identical to the reference's float64 results.
+#include <math.h>
+
+#include <vector>
+
 #include "icz_common.h"
 
 namespace icz {
@@ -227,6 +231,70 @@ static int ciderd_reward_impl(icz_ciderd_t* h, const int64_t* gen, const int64_t
     hipLaunchKernelGGL(ciderd_kernel, dim3(2 * B), dim3(64 * CD_NW), 0, st, a);
     if (reward_out) hipLaunchKernelGGL(ciderd_reward_kernel, dim3(cdiv(B * T, 256)), dim3(256), 0, st, scores_out, B, T, reward_out);
     ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// Host side of the reference store: "cooking" references (ciderD_scorer.py:17-32 precook + :128-153 counts2vec) from token
+// ids -- the reference does this in Python dict loops for every batch; here once per image, ~100x faster than the Python
+// restatement in ciderd.py (which stays as the checker of this function, tests/test_cpu_abi_and_host.py).  Pure host code:
+// no device memory is touched.  Entries of a reference come out in the scorer's dict-insertion order (order k ascending,
+// first occurrence ascending), weights / norms in the scorer's float64 arithmetic (pow(w, 2) summed in that order, sqrt).
+int icz_ciderd_cook_host(const int32_t* df_keys_host, const double* df_idf_host, int64_t cap, double default_idf,
+                         const int32_t* tokens, const int32_t* ref_tok_ptr, int32_t n_refs, int64_t max_ent,
+                         int32_t* ent_key_out, int32_t* ent_order_out, double* ent_w_out, int32_t* ref_ent_ptr_out,
+                         double* ref_norm_out, int32_t* ref_len_out, int64_t* n_ent_out) {
+    ICZ_REQUIRE(df_keys_host && df_idf_host && tokens && ref_tok_ptr && ent_key_out && ent_order_out && ent_w_out && ref_ent_ptr_out &&
+                ref_norm_out && ref_len_out && n_ent_out, "icz_ciderd_cook_host: null argument");
+    ICZ_REQUIRE(cap >= 2 && (cap & (cap - 1)) == 0 && n_refs >= 0, "icz_ciderd_cook_host: bad table size / reference count");
+    int64_t ne = 0;
+    ref_ent_ptr_out[0] = 0;
+    std::vector<int32_t> cnt;
+    for (int32_t r = 0; r < n_refs; ++r) {
+        const int32_t* t = tokens + ref_tok_ptr[r];
+        const int L = ref_tok_ptr[r + 1] - ref_tok_ptr[r];
+        const int64_t e0 = ne;
+        cnt.clear();
+        for (int k = 1; k <= 4; ++k) {
+            const int64_t k0 = ne;                       // entries of order k start here
+            for (int i = 0; i + k <= L; ++i) {
+                int32_t key[4] = {-1, -1, -1, -1};
+                for (int j = 0; j < k; ++j) key[j] = t[i + j];
+                int64_t hit = -1;
+                for (int64_t e = k0; e < ne; ++e) {
+                    const int32_t* kk = ent_key_out + e * 4;
+                    if (kk[0] == key[0] && kk[1] == key[1] && kk[2] == key[2] && kk[3] == key[3]) { hit = e; break; }
+                }
+                if (hit >= 0) { ++cnt[(size_t)(hit - e0)]; continue; }
+                ICZ_REQUIRE(ne < max_ent, "icz_ciderd_cook_host: more than %lld n-gram entries", (long long)max_ent);
+                int32_t* o = ent_key_out + ne * 4;
+                o[0] = key[0]; o[1] = key[1]; o[2] = key[2]; o[3] = key[3];
+                ent_order_out[ne] = k;
+                cnt.push_back(1);
+                ++ne;
+            }
+        }
+        double norm[4] = {0.0, 0.0, 0.0, 0.0};
+        int32_t len2 = 0;
+        for (int64_t e = e0; e < ne; ++e) {
+            const int32_t* kk = ent_key_out + e * 4;
+            double idfv = default_idf;
+            const uint32_t hsh = ngram_hash(kk[0], kk[1], kk[2], kk[3]);
+            for (int64_t probe = 0; probe < cap; ++probe) {
+                const int64_t s = (int64_t)((hsh + (uint32_t)probe) & (uint32_t)(cap - 1));
+                const int32_t* tk = df_keys_host + s * 4;
+                if (tk[0] == -1) break;
+                if (tk[0] == kk[0] && tk[1] == kk[1] && tk[2] == kk[2] && tk[3] == kk[3]) { idfv = df_idf_host[s]; break; }
+            }
+            const double w = (double)cnt[(size_t)(e - e0)] * idfv;     // float(term_freq) * (ref_len - df)   (ciderD_scorer.py:145)
+            ent_w_out[e] = w;
+            norm[ent_order_out[e] - 1] += pow(w, 2.0);                   // norm[n] += pow(vec[n][ngram], 2)   (:147)
+            if (ent_order_out[e] == 2) len2 += cnt[(size_t)(e - e0)];
+        }
+        for (int n = 0; n < 4; ++n) ref_norm_out[(size_t)r * 4 + n] = sqrt(norm[n]);
+        ref_len_out[r] = len2;
+        ref_ent_ptr_out[r + 1] = (int32_t)ne;
+    }
+    *n_ent_out = ne;
     return ICZ_OK;
 }
 

@@ -79,6 +79,10 @@ bool gemm_skinny_x3_enabled();
 bool gemm_skinny_x3_fits(const GemmArgs& a);
 int gemm_skinny_x3_tile_n(const GemmArgs& a);
 int gemm_skinny_x3(const GemmArgs& a, hipStream_t stream);
+// the LSTM-gate form (activations resident in LDS; see gemm_skinny_x3.hip): fixed decomposition, nsplit = K chunks / 4
+bool gemm_resident_x3_fits(const GemmArgs& a);
+int gemm_resident_x3_nsplit(const GemmArgs& a);
+int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
 struct Planes;
 int split3_planes(const float* x, int rows, int K, int ld, Planes pl, hipStream_t st);
 

@@ -442,11 +442,271 @@ __global__ __launch_bounds__(64 * NW) void gemm_skinny_x3_kernel(GemmArgs a) {
     stamp(31);
 }
 
-// ------------------------------------------------------------------------------------------------
 static int sk_env(const char* name, int dflt) {
     const char* e = getenv(name);
     return e ? atoi(e) : dflt;
 }
+
+// ------------------------------------------------------------------------------------------------
+// Second structure, for the two LSTM-gate GEMMs of a decoder step (N = 4 H output columns, K = 3 H / 4 H): the activations
+// of the workgroup's WHOLE k range (NSR stages of 64) are split ONCE and stay in LDS as three bf16 planes, and the workgroup
+// then streams TPW column tiles of 128 one after the other through them.  What this buys, by the MEASURED model of the
+// header (a compute unit moves ~14 bytes per cycle through its vector-memory path, activations included):
+//   * activation bytes per weight byte 0.25 instead of 0.5 (one 64 x 256 fp32 read per 2 x 128 x 256 weights), and the
+//     activation split done once per workgroup instead of once per stage;
+//   * no barrier after the first one: the planes are read-only, the four waves run free through the TPW * NSR pipeline steps
+//     (weight ring as above, loads spread over the MFMA groups), each wave's accumulators leaving through its own LDS strip as
+//     full 16-byte row segments when a tile is done.
+// Everything is compile-time (steps, ring slots, tile boundaries): no branch with a vector-memory operation in it.
+// Launch: grid (N / (128 TPW), 1, chunks / NSR); every workgroup has exactly NSR chunks (the launcher checks).
+constexpr int RS_PB = 64 * 4 + 16;         // bf16 per LDS row for NSR = 4: 544 B -> conflict-free 16-byte fragment reads
+template <int MT, int NSR, int TPW, int D>
+constexpr size_t rs_lds_bytes() { return (size_t)3 * (16 * MT) * RS_PB * 2 + (size_t)4 * (16 * MT) * 32 * 4; }
+
+template <int MT, int NSR, int TPW, int D, bool STAMPS = false>
+__global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
+    static_assert(NSR == 4, "row stride RS_PB is laid out for four stages");
+    unsigned long long* const stamps = STAMPS ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) +
+                                                    32 * ((size_t)blockIdx.z * gridDim.x + blockIdx.x) : nullptr;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (STAMPS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0 && i < 32) stamps[i] = t;
+        }
+    };
+    stamp(0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    unsigned short* const planes = reinterpret_cast<unsigned short*>(sk_smem);
+    constexpr int ROWS = 16 * MT, NCT = 2, NT = TPW * NSR;
+    constexpr size_t PLANE = (size_t)ROWS * RS_PB;
+    constexpr int XI = ROWS * 8 / 256;                         // staging items (row, 8-k group) per thread and stage
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int n0 = blockIdx.x * (128 * TPW), z = blockIdx.z;
+    const int c_begin = z * NSR;
+    float* const strip = reinterpret_cast<float*>(sk_smem + 3 * PLANE * 2) + (size_t)wave * ROWS * 32;      // this wave's epilogue staging
+
+    struct Cur { int seg, k0; };
+    auto seek = [&](int stage) __attribute__((always_inline)) {
+        Cur c = {0, 0};
+        int q = stage;
+#pragma unroll
+        for (int sg = 0; sg < GEMM_MAX_SEG - 1; ++sg) {
+            if (c.seg == sg && sg < a.nseg - 1) {
+                const int nst = a.seg[sg].K / SK_BK;
+                if (q >= nst) { q -= nst; c.seg = sg + 1; }
+            }
+        }
+        c.k0 = q * SK_BK;
+        return c;
+    };
+
+    // ---- phase B: NT pipeline steps, step i = (tile i / NSR, stage i % NSR)
+    f32x4 acc[MT][NCT];
+    f32x4 w[D][2][NCT][2];
+    sk_u32x4 bq[2][NCT][3];
+    const float* wp[NCT];
+    auto point_w = [&](auto stepc) __attribute__((always_inline)) {       // weight pointers of pipeline step i
+        constexpr int i = decltype(stepc)::value, tile = i / NSR, st = i % NSR;
+        const Cur c = seek(c_begin + st);
+        const GemmSeg& g = a.seg[c.seg];
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            const int col = n0 + 128 * tile + (wave * NCT + cc) * 16 + li;
+            wp[cc] = g.B + (size_t)(col < a.N ? col : a.N - 1) * g.ldb + c.k0 + 4 * lq;
+        }
+    };
+    constexpr int LW = 2 * NCT * 2, WP = 4 * NCT, G = 2 * MT;
+    auto load_w1 = [&](auto slot, auto idx) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value, i = decltype(idx)::value, b = i / (2 * NCT), c = (i / 2) % NCT, h = i & 1;
+        w[S][b][c][h] = *reinterpret_cast<const f32x4*>(wp[c] + 32 * b + 16 * h);
+    };
+    auto w_piece = [&](auto slot, auto blk, auto piece, auto which) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value, B_ = decltype(blk)::value, P = decltype(piece)::value, Wh = decltype(which)::value;
+        constexpr int c = P >> 2, i = P & 3;
+        uint32_t p0, p1, p2;
+        sk_split3(w[S][B_][c][i >> 1][2 * (i & 1)], w[S][B_][c][i >> 1][2 * (i & 1) + 1], p0, p1, p2);
+        bq[Wh][c][0][i] = p0; bq[Wh][c][1][i] = p1; bq[Wh][c][2][i] = p2;
+    };
+    // ---- phase A: the activations of the whole k range -> three bf16 planes in LDS (k order permuted inside 32-blocks)
+    {
+        f32x4 xr[NSR][XI][2];
+        sk_static_for<0, NSR>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            const Cur c = seek(c_begin + st);
+            const GemmSeg& g = a.seg[c.seg];
+            sk_static_for<0, XI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int item = tid + 256 * j, row = item >> 3, kg = item & 7;
+                const float* xp = g.A + (size_t)(row < a.M ? row : a.M - 1) * g.lda + c.k0 + 8 * kg;
+                xr[st][j][0] = *reinterpret_cast<const f32x4*>(xp);
+                xr[st][j][1] = *reinterpret_cast<const f32x4*>(xp + 4);
+            });
+        });
+        // the weights of the first D - 1 pipeline steps go out now: their HBM latency passes behind the split below
+        sk_static_for<0, D - 1>([&](auto ic) {
+            point_w(ic);
+            sk_static_for<0, LW>([&](auto lc) { load_w1(ic, lc); });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+        sk_static_for<0, NSR>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            sk_static_for<0, XI>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int item = tid + 256 * j, row = item >> 3, kg = item & 7;
+                const int kk0 = 8 * (kg & 3), half = kk0 >> 4, q0 = (kk0 & 15) >> 2;
+                unsigned short* o0 = planes + (size_t)row * RS_PB + 64 * st + 32 * (kg >> 2) + 8 * q0 + 4 * half;
+                sk_static_for<0, 2>([&](auto hc) {
+                    constexpr int hlf = decltype(hc)::value;
+                    uint32_t a0, a1, a2, b0, b1, b2;
+                    sk_split3(xr[st][j][hlf][0], xr[st][j][hlf][1], a0, a1, a2);
+                    sk_split3(xr[st][j][hlf][2], xr[st][j][hlf][3], b0, b1, b2);
+                    unsigned short* o = o0 + 8 * hlf;
+                    *reinterpret_cast<sk_u32x2*>(o) = (sk_u32x2){a0, b0};
+                    *reinterpret_cast<sk_u32x2*>(o + PLANE) = (sk_u32x2){a1, b1};
+                    *reinterpret_cast<sk_u32x2*>(o + 2 * PLANE) = (sk_u32x2){a2, b2};
+                });
+            });
+        });
+    }
+
+    stamp(1);
+    __syncthreads();                        // the planes are complete (the only barrier of the kernel)
+    stamp(2);
+    sk_static_for<0, WP>([&](auto pc) { w_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 0>{}); });
+
+    sk_static_for<0, NT>([&](auto stepc) {
+        constexpr int i = decltype(stepc)::value, S = i % D, tile = i / NSR, st = i % NSR;
+        constexpr bool HAS_LOAD = i + D - 1 < NT, HAS_NEXT = i + 1 < NT;
+        if constexpr (st == 0) {
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if constexpr (HAS_LOAD) point_w(std::integral_constant<int, i + D - 1>{});
+        const unsigned short* abase = planes + (size_t)li * RS_PB + 64 * st + 8 * lq;
+        sk_bf16x8 af[2][3];
+        sk_static_for<0, 3>([&](auto pp) { af[0][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(abase + decltype(pp)::value * PLANE); });
+        sk_static_for<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, b = g / MT, t = g % MT;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g + 1 < G) {
+                constexpr int b1 = (g + 1) / MT, t1 = (g + 1) % MT;
+                const unsigned short* ap = abase + (size_t)t1 * 16 * RS_PB + 32 * b1;
+                sk_static_for<0, 3>([&](auto pp) { af[(g + 1) & 1][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(ap + decltype(pp)::value * PLANE); });
+            }
+            if constexpr (HAS_LOAD)
+                sk_static_for<g * LW / G, (g + 1) * LW / G>([&](auto lc) { load_w1(std::integral_constant<int, (S + D - 1) % D>{}, lc); });
+            if constexpr (b == 0 || HAS_NEXT) {
+                sk_static_for<t * WP / MT, (t + 1) * WP / MT>([&](auto pc) {
+                    if constexpr (b == 0) w_piece(std::integral_constant<int, S>{}, std::integral_constant<int, 1>{}, pc, std::integral_constant<int, 1>{});
+                    else w_piece(std::integral_constant<int, (S + 1) % D>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 1>{});
+                });
+            }
+            sk_static_for<0, NCT>([&](auto cc) {       // smallest terms first
+                constexpr int c = decltype(cc)::value;
+                const sk_bf16x8 b0 = __builtin_bit_cast(sk_bf16x8, bq[0][c][0]), b1_ = __builtin_bit_cast(sk_bf16x8, bq[0][c][1]),
+                                b2 = __builtin_bit_cast(sk_bf16x8, bq[0][c][2]);
+                f32x4 v = acc[t][c];
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][2], b0, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][0], b2, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][1], b1_, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][1], b0, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][0], b1_, v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[g & 1][0], b0, v, 0, 0, 0);
+                acc[t][c] = v;
+            });
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if constexpr (HAS_LOAD) __builtin_amdgcn_sched_group_barrier(0x020, (g + 1) * LW / G - g * LW / G, 0);
+#pragma unroll
+            for (int k = 0; k < 6 * NCT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);
+            }
+            if constexpr (t == MT - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                sk_static_for<0, NCT * 3>([&](auto q) { bq[0][decltype(q)::value / 3][decltype(q)::value % 3] = bq[1][decltype(q)::value / 3][decltype(q)::value % 3]; });
+            }
+        });
+        stamp(3 + 2 * i);
+        if constexpr (st == NSR - 1) {
+            // ---- the tile is done: accumulators -> this wave's LDS strip [ROWS][32] -> 16-byte row segments of the slab / output
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int t = 0; t < MT; ++t)
+#pragma unroll
+                for (int c = 0; c < NCT; ++c)
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) strip[(16 * t + 4 * lq + j) * 32 + 16 * c + li] = acc[t][c][j];
+            const bool direct = a.nsplit == 1;
+            float* const outp = direct ? a.out : a.out + (size_t)z * a.M * a.N;
+            const int ldo = direct ? a.ldo : a.N;
+            const int colb = n0 + 128 * tile + 32 * wave + 4 * (lane & 7);
+#pragma unroll
+            for (int it = 0; it < ROWS / 8; ++it) {
+                const int m = (lane >> 3) + 8 * it;
+                f32x4 v = *reinterpret_cast<const f32x4*>(strip + m * 32 + 4 * (lane & 7));
+                if (m < a.M && colb + 3 < a.N) {
+                    if (direct && a.bias && !STAMPS) v += *reinterpret_cast<const f32x4*>(a.bias + colb);
+                    *reinterpret_cast<f32x4*>(outp + (size_t)m * ldo + colb) = v;
+                } else if (m < a.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (colb + e < a.N) outp[(size_t)m * ldo + colb + e] = v[e] + ((direct && a.bias) ? a.bias[colb + e] : 0.f);
+                }
+            }
+            stamp(4 + 2 * i);
+        }
+    });
+    stamp(31);
+}
+
+// shapes the resident-activation kernel takes: <= 64 rows, N a multiple of 4 and at least 2048 wide, whole 256-deep k ranges
+bool gemm_resident_x3_fits(const GemmArgs& a) {
+    static int on = -1;
+    if (on < 0) { const char* e = getenv("ICZ_GEMM_RESIDENT_X3"); on = e ? atoi(e) : 1; }
+    if (!on || a.M <= 32 || a.M > 64 || a.N < 2048 || a.N % 4 || a.accumulate) return false;
+    int tot = 0;
+    for (int s = 0; s < a.nseg; ++s) {
+        if (a.seg[s].K % 64 || a.seg[s].gather) return false;
+        tot += a.seg[s].K / 64;
+    }
+    return tot % 4 == 0 && tot >= 8;
+}
+int gemm_resident_x3_nsplit(const GemmArgs& a) {
+    int tot = 0;
+    for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / 64;
+    return tot / 4;
+}
+static unsigned long long* g_sk_stamps = nullptr;       // development only (ICZ_SKINNY_ABL=4): 32 stamps for up to 4096 workgroups
+int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
+    GemmArgs a = a_in;
+    if (sk_env("ICZ_SKINNY_ABL", 0) == 4) {
+        if (!g_sk_stamps) ICZ_CHECK_HIP(hipMalloc((void**)&g_sk_stamps, sizeof(unsigned long long) * 32 * 4096));
+        a.bias = reinterpret_cast<const float*>(g_sk_stamps);
+        constexpr size_t lds2 = rs_lds_bytes<4, 4, 2, 3>();
+        static bool attr2 = false;
+        if (!attr2) { ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, 4, 2, 3, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds2)); attr2 = true; }
+        hipLaunchKernelGGL((gemm_resident_x3_kernel<4, 4, 2, 3, true>), dim3(cdiv(a.N, 256), 1, a.nsplit), dim3(256), lds2, stream, a);
+        ICZ_CHECK_HIP(hipGetLastError());
+        return ICZ_OK;
+    }
+    ICZ_REQUIRE(gemm_resident_x3_fits(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == 4,
+                "gemm_resident_x3: launch does not match the kernel's fixed decomposition (nsplit %d)", a.nsplit);
+    ICZ_REQUIRE(a.nsplit == 1 || a.ldo == a.N || true, "");
+    static bool attr = false;
+    constexpr size_t lds = rs_lds_bytes<4, 4, 2, 3>();
+    if (!attr) {
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, 4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, 4, 2, 3>), dim3(cdiv(a.N, 256), 1, a.nsplit), dim3(256), lds, stream, a);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
 
 bool gemm_skinny_x3_enabled() {
     static int on = -1;
@@ -468,7 +728,6 @@ int gemm_skinny_x3_tile_n(const GemmArgs& a) {
     if (force < 0) force = sk_env("ICZ_GEMM_SKINNY_NCT", 0);
     if (force == 1) return 64;
     if (force == 2) return 128;
-    if (force == 4) return 256;
     // 128 columns per workgroup (half the activation traffic per weight byte) where split-K still yields ~256 workgroups;
     // narrow outputs and the un-split vocabulary projection (N = 10102, K = 1024: 158 workgroups of 64 columns) take 64
     return (a.N >= 2048 && a.N <= 8192) ? 128 : 64;
@@ -487,8 +746,6 @@ static int sk_launch(const GemmArgs& a, dim3 grid, hipStream_t stream) {
     return ICZ_OK;
 }
 
-static unsigned long long* g_sk_stamps = nullptr;       // development only (ICZ_SKINNY_ABL=4): 32 stamps for up to 4096 workgroups
-
 int gemm_skinny_x3(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     if (sk_env("ICZ_SKINNY_ABL", 0) >= 4) {
@@ -502,10 +759,6 @@ int gemm_skinny_x3(const GemmArgs& a_in, hipStream_t stream) {
     const bool tall = a.M > 64;
     bool xpl = true;
     for (int sg = 0; sg < a.nseg; ++sg) xpl = xpl && a.seg[sg].Apl != nullptr;
-    if (bn == 256 && abl == 0) {      // development: 256-column tiles
-        if (xpl) { if (tall) return sk_launch<8, 4, 3, 0, 4, true>(a, grid, stream); else return sk_launch<4, 4, 3, 0, 4, true>(a, grid, stream); }
-        if (tall) return sk_launch<8, 4, 3, 0, 4, false>(a, grid, stream); else return sk_launch<4, 4, 3, 0, 4, false>(a, grid, stream);
-    }
     if (xpl && abl == 0) {      // activations pre-split by their producers
         if (nw == 8) {
             if (tall) { if (bn == 128) return sk_launch<8, 2, 3, 0, 8, true>(a, grid, stream); else return sk_launch<8, 1, 3, 0, 8, true>(a, grid, stream); }
@@ -516,14 +769,12 @@ int gemm_skinny_x3(const GemmArgs& a_in, hipStream_t stream) {
     }
     if (xpl && abl == 4) return sk_launch<4, 2, 3, 4, 4, true>(a, grid, stream);
 #define ICZ_SK(MT_, NCT_, D_, ABL_) return sk_launch<MT_, NCT_, D_, ABL_>(a, grid, stream)
-    if (abl == 0 && nw == 8 && depth >= 3 && depth <= 4) {
-        if (depth == 3) {
+    if (abl == 0 && nw == 8 && depth == 3) {
+        {
             if (tall) { if (bn == 128) return sk_launch<8, 2, 3, 0, 8>(a, grid, stream); else return sk_launch<8, 1, 3, 0, 8>(a, grid, stream); }
             else { if (bn == 128) return sk_launch<4, 2, 3, 0, 8>(a, grid, stream); else return sk_launch<4, 1, 3, 0, 8>(a, grid, stream); }
         }
-        if (tall) return sk_launch<8, 2, 4, 0, 8>(a, grid, stream); else return sk_launch<4, 2, 4, 0, 8>(a, grid, stream);
     }
-    if (abl == 4 && nw == 8) { if (tall) return sk_launch<8, 2, 3, 4, 8>(a, grid, stream); else return sk_launch<4, 2, 3, 4, 8>(a, grid, stream); }
     if (abl == 11) return sk_launch<4, 2, 3, 11, 4>(a, grid, stream);
     if (abl == 12) return sk_launch<4, 2, 3, 12, 4>(a, grid, stream);
     if (abl == 13) return sk_launch<4, 2, 3, 13, 4>(a, grid, stream);
@@ -532,13 +783,8 @@ int gemm_skinny_x3(const GemmArgs& a_in, hipStream_t stream) {
         if (tall) { if (bn == 128) ICZ_SK(8, 2, 3, 0); else ICZ_SK(8, 1, 3, 0); }
         else { if (bn == 128) ICZ_SK(4, 2, 3, 0); else ICZ_SK(4, 1, 3, 0); }
     }
-    // development variants (tools/): deeper rings and ablations, 128-column tiles only
-    if (abl == 0 && depth == 4) { if (tall) ICZ_SK(8, 2, 4, 0); else ICZ_SK(4, 2, 4, 0); }
-    if (abl == 0 && depth == 5) { if (tall) ICZ_SK(8, 2, 5, 0); else ICZ_SK(4, 2, 5, 0); }
-    if (abl == 1) { if (tall) ICZ_SK(8, 2, 3, 1); else ICZ_SK(4, 2, 3, 1); }
-    if (abl == 2) { if (tall) ICZ_SK(8, 2, 3, 2); else ICZ_SK(4, 2, 3, 2); }
-    if (abl == 3) { if (tall) ICZ_SK(8, 2, 3, 3); else ICZ_SK(4, 2, 3, 3); }
-    if (abl == 4) { if (tall) ICZ_SK(8, 2, 3, 4); else ICZ_SK(4, 2, 3, 4); }
+    // development variants (tools/perf_skinny_stamps.py): time stamps and ablations at 64 rows, 128-column tiles, 4 waves
+    if (abl == 4) ICZ_SK(4, 2, 3, 4);
 #undef ICZ_SK
     set_error("gemm_skinny_x3: no such variant (ICZ_SKINNY_ABL=%d ICZ_SKINNY_D=%d)", abl, depth);
     return ICZ_ERR_INVALID;

@@ -220,3 +220,27 @@ def test_scheduled_sampling_schedule_and_captioner_plumbing():
     st.ss_prob = 0.0
     st._ss_push(h2)
     assert h2.calls[-1] == (0.0, None, None)
+
+
+def test_host_reference_cooker_matches_the_python_statement():
+    """icz_ciderd_cook_host (host code of libicz: n-gram counting in the scorer's dict order, tf-idf weights, norms, bigram
+    length; ciderD_scorer.py:17-32, 128-153) against the Python statement of the same in ciderd.ReferenceCooker.cook_image:
+    every array bit-identical -- with out-of-vocabulary words in the references AND in the document-frequency table, empty
+    and one-word references, repeated n-grams."""
+    from simpleimagecaptionzoo_amd.ciderd import ReferenceCooker
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    v = synthetic_vocab(300)
+    words = [v.ix2word[i] for i in range(300)]
+    train = synthetic_references(200, words + ["oov%d" % i for i in range(40)], seed=0)
+    df = document_frequency(train)
+    ck = ReferenceCooker(df["document_frequency"], df["ref_len"], v.word2ix)
+    refs = synthetic_references(24, words + ["oov%d" % i for i in range(60)], seed=3)
+    refs[3] = ["", "w1", "w1 w1 w1 w1 w1", "w2 w3 w2 w3 w2 w3", "oov3 oov3 zzz", "<pad>"]
+    refs[7] = ["w5 w6 w7 w8 w9 w10 w11 w12 w13 w14 w15 w16 w17 w18 w19 w20 w21 w22 w23 w24"]
+    want = [ck.cook_image(refs[i]) for i in range(24)]
+    got = ck.cook_images([refs[i] for i in range(24)])
+    for a, b in zip(want, got):
+        for x, y in zip(a, b):
+            assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+    assert any((a[1] >= 300).any() for a in want)          # private ids of out-of-vocabulary words are in play
