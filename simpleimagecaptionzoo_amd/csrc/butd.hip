@@ -182,7 +182,8 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
-        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, off);
+        if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, off);
+        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, off);
     }
     {   // attention
         GemmArgs g = {};
@@ -220,7 +221,8 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
-        hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, s.drop_out);
+        if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, s.drop_out);
+        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, s.drop_out);
     }
     {   // predict: logits = drop(h2) w_pred^T + b   (K = H is short: no split-K, bias fused)
         GemmArgs g = {};
