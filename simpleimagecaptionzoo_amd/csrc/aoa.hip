@@ -186,8 +186,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd};
     DropCfg off = {0, nullptr, nullptr, 0, 0};
-    if (a.nsplit >= lstm4_min_slabs() && Hd % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(Hd, 256), rows), dim3(64), 0, st, a, off);
-        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(Hd, 256), rows), dim3(256), 0, st, a, off);
+    launch_lstm_point(a, off, st);
     hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
     ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128 + 4);

@@ -182,8 +182,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
-        if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, off);
-        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, off);
+        launch_lstm_point(a, off, st);
     }
     {   // attention
         GemmArgs g = {};
@@ -221,15 +220,28 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
-        if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, s.drop_out);
-        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, s.drop_out);
+        launch_lstm_point(a, s.drop_out, st);
     }
-    {   // predict: logits = drop(h2) w_pred^T + b   (K = H is short: no split-K, bias fused)
+    {   // predict: logits = drop(h2) w_pred^T + b
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {s.h2drop_out ? s.h2drop_out : h2drop, w_pred, H, H, H, nullptr};
-        g.M = rows; g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : Vp; g.bias = P.predict_b;
-        g.nsplit = 1;
+        g.M = rows; g.N = Vp; g.out = ws; g.ldo = Vp;
+        // At 33 - 64 rows the un-split GEMM is 158 workgroups of 64 columns that each re-read the whole activation matrix
+        // (as many bytes as their weights: 25 us for 41 MB); the resident-activation kernel over the padded vocabulary (the
+        // pad rows of w_pred are zero) takes 256 columns and a quarter of K per workgroup (17.5 us) and leaves four slabs,
+        // which a slab-summing consumer (greedy argmax, multinomial draw) adds up together with the bias.
+        const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
+        static int pred_slabs = -1;          // ICZ_PREDICT_SLABS=0: keep the un-split GEMM (A/B runs)
+        if (pred_slabs < 0) { const char* e = getenv("ICZ_PREDICT_SLABS"); pred_slabs = e ? atoi(e) : 1; }
+        if (pred_slabs && s.pred_nsplit && gemm_resident_x3_fits(g) && gemm_slab_floats(rows, Vp, gemm_resident_x3_nsplit(g)) <= ws_cap) {
+            g.nsplit = gemm_resident_x3_nsplit(g);
+            *s.pred_nsplit = g.nsplit;
+        } else {           // K = H is short: no split-K, bias fused
+            g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : Vp; g.bias = P.predict_b;
+            g.nsplit = 1;
+            if (s.pred_nsplit) *s.pred_nsplit = 1;
+        }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     }
     ICZ_CHECK_HIP(hipGetLastError());
@@ -268,8 +280,14 @@ int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out,
         s.h1_in = h1[cur]; s.c1_in = c1[cur]; s.h2_in = h2[cur]; s.c2_in = c2[cur];
         s.h1_out = h1[cur ^ 1]; s.c1_out = c1[cur ^ 1]; s.h2_out = h2[cur ^ 1]; s.c2_out = c2[cur ^ 1];
         if (alphas_out) { s.alpha_out2 = alphas_out + (size_t)t * dims.R; s.alpha2_stride = max_len * dims.R; }
+        int pns = 1;
+        s.pred_nsplit = &pns;
         ICZ_TRY(step(s, st));
-        hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
+        if (pns > 1)
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, (const float*)ws, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx,
+                               pns, (size_t)B * Vp, (const float*)P.predict_b);
+        else
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
         hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
                            P.embed_weight, dims.E, emb, it, ids_out, max_len, t);
         cur ^= 1;

@@ -28,6 +28,9 @@ struct StepIO {
     float* h2drop_out;               // [rows,H]
     float* logits_out;               // [rows,V]
     int logits_ld;                   // row stride of logits_out (0 = V)
+    int* pred_nsplit;                // non-null: the caller's consumer of the logits can sum split-K slabs (argmax_part_kernel,
+                                     // sample_select_kernel): step() may leave the predict GEMM's slabs [ns][rows][Vp] in the
+                                     // chain's workspace instead of finished logits and reports ns here (1 = logits_out is final)
     float* ws_alt;                   // split-K slab workspace / attention scores of this chain (null = the handle's):
     float* scores_alt;               // two decode chains running concurrently must not share them
     DropCfg drop_emb, drop_att, drop_out;
@@ -135,7 +138,7 @@ struct Butd {
     const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr; const int64_t* cur_captions = nullptr;
     std::vector<int> rows_t;
     int ensure_train(int B, int T);
-    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false);
+    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false, int* pred_nsplit = nullptr);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_mask_sum(float* out, hipStream_t st);
     int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,

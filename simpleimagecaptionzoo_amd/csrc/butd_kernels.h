@@ -234,6 +234,75 @@ __global__ __launch_bounds__(64) void lstm_point4_kernel(LstmPointArgs a, DropCf
     }
 }
 
+// Gate-per-wave form, grid (H / 256, rows), 256 threads: wave q sums gate q of the workgroup's 256 hidden units (16 bytes per
+// lane and slab, the loads of up to eight slabs independent), the four gates meet in LDS and thread j finishes unit j.  Four
+// times the waves of the four-unit kernel with the same 16-byte accesses: at 12 - 16 slabs (16.8 MB at 64 rows) that kernel
+// has ONE wave per compute unit waiting on 64 KB (9.5 us in the SCST trace); here four waves per compute unit wait on 16 KB
+// each.  Same summation order per element (slabs ascending, pre, b_ih, b_hh): results bit-identical to the other two kernels.
+__global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, DropCfg dc) {
+    __shared__ __attribute__((aligned(16))) float sg[4][256];
+    const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
+    const int H = a.H, G = 4 * H;
+    const int j0 = blockIdx.x * 256, j4 = j0 + lane * 4;
+    const size_t MN = (size_t)a.rows * G;
+    if (j4 < H) {
+        const size_t off = (size_t)row * G + (size_t)q * H + j4;
+        const float* p = a.slab + off;
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        int z = 0;
+        for (; z + 8 <= a.nsplit; z += 8) {
+            f32x4 v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + i) * MN);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) s += v[i];
+        }
+        for (; z + 4 <= a.nsplit; z += 4) {
+            f32x4 v[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + i) * MN);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) s += v[i];
+        }
+        for (; z < a.nsplit; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * MN);
+        if (a.pre) {
+            const int pr = a.pre_row ? a.pre_row[row] : row;
+            s += *reinterpret_cast<const f32x4*>(a.pre + (size_t)pr * G + (size_t)q * H + j4);
+        }
+        s += *reinterpret_cast<const f32x4*>(a.b_ih + (size_t)q * H + j4);
+        s += *reinterpret_cast<const f32x4*>(a.b_hh + (size_t)q * H + j4);
+        *reinterpret_cast<f32x4*>(&sg[q][lane * 4]) = s;
+    }
+    __syncthreads();
+    const int j = j0 + tid;
+    if (j >= H) return;
+    const float cp = a.c_prev[(size_t)row * H + j];
+    const float gi = sigmoidf_(sg[0][tid]), gf = sigmoidf_(sg[1][tid]), gg = tanhf(sg[2][tid]), go = sigmoidf_(sg[3][tid]);
+    const float cn = gf * cp + gi * gg;
+    const float hn = go * tanhf(cn);
+    a.h_out[(size_t)row * H + j] = hn;
+    a.c_out[(size_t)row * H + j] = cn;
+    if (a.gates_out) {
+        float* go_ = a.gates_out + (size_t)row * G + j;
+        go_[0] = gi; go_[H] = gf; go_[2 * H] = gg; go_[3 * H] = go;
+    }
+    if (a.hdrop_out) {
+        float hd = hn;
+        if (dc.mode) hd = dc.keep((uint64_t)row * H + j) ? hn * 2.0f : 0.f;
+        a.hdrop_out[(size_t)row * H + j] = hd;
+    }
+}
+
+// picks the pointwise kernel for a slab count (ICZ_LSTM_POINT = 1 / 4 / 0 forces the one-unit / four-unit / gate-per-wave kernel)
+inline void launch_lstm_point(const LstmPointArgs& a, const DropCfg& dc, hipStream_t st) {
+    static int force = -1;
+    if (force < 0) { const char* e = getenv("ICZ_LSTM_POINT"); force = e ? atoi(e) : 0; }
+    const dim3 grid(cdiv(a.H, 256), a.rows);
+    if (a.H % 4 != 0 || force == 1) hipLaunchKernelGGL(lstm_point_kernel, grid, dim3(256), 0, st, a, dc);
+    else if (force == 4 && a.nsplit >= lstm4_min_slabs()) hipLaunchKernelGGL(lstm_point4_kernel, grid, dim3(64), 0, st, a, dc);
+    else hipLaunchKernelGGL(lstm_point_gw_kernel, grid, dim3(256), 0, st, a, dc);
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // SoftAttention scores (:57-59):  score[row,r] = w_aff . drop(relu(enc_ctx[img,r,:] + dec_ctx[row,:])) + b_aff
 // with dec_ctx[row,:] = sum_z slab[z,row,:] + b_dec (the dec_att GEMM's split-K partials are summed here).
@@ -258,6 +327,20 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t MN = (size_t)a.rows * a.A;
+    const int img = a.img_of_row ? a.img_of_row[row] : row;
+    constexpr int NB = 3;
+    // the projected features do not depend on dec_ctx: the loads of the wave's first group of regions (its only one at 36
+    // regions, A <= 1024) are issued before the split-K slabs are summed, so both round trips overlap
+    f32x4 xf[NB][4];
+    if (part + nparts * wave < a.R) {
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+            const int r = part + nparts * (wave + 4 * b);
+            const float* e = a.enc_ctx + ((size_t)img * a.R + (r < a.R ? r : part + nparts * wave)) * a.A;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) xf[b][u] = *reinterpret_cast<const f32x4*>(e + min(lane * 4 + 256 * u, a.A - 4));
+        }
+    }
     for (int c = tid * 4; c < a.A; c += 1024) {
         const size_t off = (size_t)row * a.A + c;
         f32x4 s = *reinterpret_cast<const f32x4*>(a.dec_slab + off);
@@ -267,10 +350,8 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
         if (a.dec_ctx_out && part == 0) *reinterpret_cast<f32x4*>(a.dec_ctx_out + off) = s;
     }
     __syncthreads();
-    const int img = a.img_of_row ? a.img_of_row[row] : row;
     const float baff = a.b_aff[0];
     const float sc = dc.mode ? 2.0f : 1.0f;
-    constexpr int NB = 3;
     const bool shared_bits = dc.mode == 2 && (a.A & 255) == 0;       // whole 256-column strips: every lane runs every c0 iteration
     for (int i0 = wave; part + nparts * i0 < a.R; i0 += 4 * NB) {
         int rr[NB];
@@ -287,10 +368,17 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
         }
         for (int c0 = lane * 4; c0 < a.A; c0 += 1024) {
             f32x4 x[NB][4];
+            if (i0 == wave && c0 == lane * 4) {
 #pragma unroll
-            for (int b = 0; b < NB; ++b)
+                for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int u = 0; u < 4; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(e[b] + min(c0 + 256 * u, a.A - 4));
+                    for (int u = 0; u < 4; ++u) x[b][u] = xf[b][u];
+            } else {
+#pragma unroll
+                for (int b = 0; b < NB; ++b)
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(e[b] + min(c0 + 256 * u, a.A - 4));
+            }
             // Philox keep-bits: a call covers 128 consecutive columns = one half-wave of one u; the 8 blocks of each of the NB
             // regions are computed once (lane 8 b + block) and handed round by shuffles instead of 64 lanes calling it 4 NB times
             uint32_t kq[NB][4];
@@ -409,6 +497,21 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
     __shared__ float sal[64];
     __shared__ __attribute__((aligned(16))) float spart[128 * 4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+    const int cg = tid & 127, half = tid >> 7;
+    const int d = blockIdx.y * 512 + cg * 4;
+    const bool valid = d < D;
+    const int img = img_of_row ? img_of_row[row] : row;
+    const int Rh = (R + 1) / 2;
+    const int r_lo = half ? Rh : 0, r_hi = half ? R : Rh;
+    const float* f = feats + (size_t)img * R * D + (valid ? d : 0);
+    // the feature loads do not depend on the weights: the first two rounds (all of them at 36 regions) are issued before the
+    // scores are read, so the softmax runs while they are in flight instead of in front of them
+    constexpr int RB = 9;
+    f32x4 x0[RB], x1[RB];
+#pragma unroll
+    for (int u = 0; u < RB; ++u) x0[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r_lo + u, r_hi - 1) * D);
+#pragma unroll
+    for (int u = 0; u < RB; ++u) x1[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r_lo + RB + u, r_hi - 1) * D);
     const float scv = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
     const float mx = wave_max(scv);
     const float ex = lane < R ? expf(scv - mx) : 0.f;
@@ -422,17 +525,15 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
         }
     }
     __syncthreads();
-    const int cg = tid & 127, half = tid >> 7;
-    const int d = blockIdx.y * 512 + cg * 4;
-    const bool valid = d < D;
-    const int img = img_of_row ? img_of_row[row] : row;
-    const int Rh = (R + 1) / 2;
-    const int r_lo = half ? Rh : 0, r_hi = half ? R : Rh;
-    const float* f = feats + (size_t)img * R * D + (valid ? d : 0);
     f32x4 acc = {0.f, 0.f, 0.f, 0.f};
     if (valid) {
-        constexpr int RB = 9;
-        for (int r0 = r_lo; r0 < r_hi; r0 += RB) {
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+            if (r_lo + u < r_hi) acc += x0[u] * sal[r_lo + u];
+#pragma unroll
+        for (int u = 0; u < RB; ++u)
+            if (r_lo + RB + u < r_hi) acc += x1[u] * sal[r_lo + RB + u];
+        for (int r0 = r_lo + 2 * RB; r0 < r_hi; r0 += RB) {
             f32x4 x[RB];
 #pragma unroll
             for (int u = 0; u < RB; ++u) x[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r0 + u, r_hi - 1) * D);
@@ -519,8 +620,11 @@ __device__ __forceinline__ f32x4 sum_slabs4(const float* p, int ns, size_t slab_
 __device__ __forceinline__ void argmax_combine(float& best, int& bi, float ob, int oi) {
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
 }
+// ns > 1: `logits` holds the ns split-K slabs of the predict GEMM (slab z at + z * slab_stride, no bias yet): the logit is their
+// sum in slab order + bias[v] (the resident-activation GEMM of gemm_skinny_x3.hip leaves four slabs at 33 - 64 rows).
 __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ logits, int V, int ldl, int P,
-                                                          float* __restrict__ part_val, int* __restrict__ part_idx) {
+                                                          float* __restrict__ part_val, int* __restrict__ part_idx,
+                                                          int ns = 1, size_t slab_stride = 0, const float* __restrict__ bias = nullptr) {
     __shared__ float sv[4];
     __shared__ int si[4];
     const int row = blockIdx.x, p = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -529,9 +633,18 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restric
     const float* l = logits + (size_t)row * ldl;
     float best = -INFINITY;
     int bi = 0x7fffffff;
-    for (int v = v0 + tid; v < v1; v += 256) {
-        const float x = l[v];
-        if (x > best) { best = x; bi = v; }
+    if (ns > 1) {
+        for (int v = v0 + tid; v < v1; v += 256) {
+            float x = l[v];
+            for (int z = 1; z < ns; ++z) x += l[(size_t)z * slab_stride + v];
+            x += bias[v];
+            if (x > best) { best = x; bi = v; }
+        }
+    } else {
+        for (int v = v0 + tid; v < v1; v += 256) {
+            const float x = l[v];
+            if (x > best) { best = x; bi = v; }
+        }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) argmax_combine(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
@@ -640,6 +753,9 @@ struct SampleSelArgs {
     // optional fused epilogue: the next step's input embedding emb_next[row,:] = drop(relu(table[it_next[row],:])) (the
     // embed_kernel of step t + 1, :77-81) with that step's dropout configuration
     const float* emb_table; float* emb_next; int E; DropCfg emb_drop;
+    // ns > 1: `logits` holds the ns split-K slabs of the predict GEMM (slab z at + z * slab_stride, no bias yet); the kernel
+    // sums them in slab order, adds bias[v] and leaves the finished row in logits_store (the saved logits of backward)
+    int ns; size_t slab_stride; const float* bias; float* logits_store;
 };
 constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS, every pass is LDS-bound
 __device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
@@ -790,7 +906,17 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     const float* l = a.logits + (size_t)row * a.ldl;
     // one coalesced pass over HBM/L2; every later pass (any access pattern) runs out of LDS
     float mx = -INFINITY;
-    for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
+    if (a.ns > 1) {
+        float* ls = a.logits_store + (size_t)row * a.ldl;
+        for (int v = tid; v < a.V; v += SEL_THREADS) {
+            float x = l[v];
+            for (int z = 1; z < a.ns; ++z) x += l[(size_t)z * a.slab_stride + v];
+            x += a.bias[v];
+            ls[v] = x; srow[v] = x; mx = fmaxf(mx, x);
+        }
+    } else {
+        for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
+    }
     mx = block_max_n(mx, smf, NW);
     float se = 0.f;
     for (int v = tid; v < a.V; v += SEL_THREADS) se += expf(srow[v] - mx);
@@ -802,7 +928,12 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     const int drawn = block_inverse_cdf(srow, a.V, u, smd, smi);
     if (tid == 0) {
         const int d = drawn;
-        const float lp = (l[d] - mx) - lse;
+        float ld = l[d];
+        if (a.ns > 1) {          // the same sum, in the same order, as the pass above
+            for (int z = 1; z < a.ns; ++z) ld += l[(size_t)z * a.slab_stride + d];
+            ld += a.bias[d];
+        }
+        const float lp = (ld - mx) - lse;
         bool unf = a.unfinished[row] != 0;
         unf = unf && (d != 2);
         a.unfinished[row] = unf ? 1 : 0;

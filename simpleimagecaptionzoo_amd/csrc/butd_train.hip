@@ -101,7 +101,7 @@ static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base
 
 // ------------------------------------------------------------------------------------------------
 // forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
-int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready) {
+int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit) {
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
     const size_t Vp = round4(dims.V);
     const size_t slot = (size_t)t * Bs;
@@ -121,6 +121,7 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     s.drop_emb = make_drop(d_seed, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
     s.drop_att = make_drop(d_seed, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
     s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
+    s.pred_nsplit = pred_nsplit;
     return step(s, st);
 }
 
@@ -197,9 +198,14 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
     }
     hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok, B, T);
     for (int t = 0; t < T; ++t) {
-        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0));
+        int pns = 1;
+        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0, &pns));
         SampleSelArgs a = {};
         a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
+        if (pns > 1) {          // the predict GEMM left split-K slabs in the chain's workspace (train_step: tb.X[0])
+            a.logits = tb.X[0]; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b;
+            a.logits_store = tb.logit + (size_t)t * B * Vp;
+        }
         a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = tb.unf; a.n_unfinished = tb.nunf;

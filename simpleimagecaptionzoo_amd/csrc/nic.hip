@@ -116,8 +116,7 @@ int Nic::image_step(const float* feats, int rows, float* h_out, float* c_out, fl
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, zeros, h_out, c_out, gates_out, nullptr, rows, H};
     DropCfg off = {0, nullptr, nullptr, 0, 0};
-    if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, off);
-        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, off);
+    launch_lstm_point(a, off, st);
     return ICZ_OK;
 }
 
@@ -136,8 +135,7 @@ int Nic::token_step(int rows, const int64_t* tokens, bool emb_ready, const float
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "nic: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, c_in, h_out, c_out, gates_out, hdrop_out, rows, H};
-    if (a.nsplit >= lstm4_min_slabs() && H % 4 == 0) hipLaunchKernelGGL(lstm_point4_kernel, dim3(cdiv(H, 256), rows), dim3(64), 0, st, a, drop_out);
-        else hipLaunchKernelGGL(lstm_point_kernel, dim3(cdiv(H, 256), rows), dim3(256), 0, st, a, drop_out);
+    launch_lstm_point(a, drop_out, st);
     GemmArgs p = {};
     p.nseg = 1;
     p.seg[0] = {hdrop_out, w_pred, H, H, H, nullptr};
