@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 R, D, H, E, A, V, T = 36, 2048, 1024, 1024, 1024, 10102, 20
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8 TB/s
 MFMA_F32_PEAK_TFLOPS = 157.3
+RESIDENT_X3 = os.environ.get("ICZ_GEMM_RESIDENT_X3", "1") not in ("", "0")     # the library's default: on
 
 
 def build_engine(device, B):
@@ -222,14 +223,15 @@ def fp32_gemm_child(steps, warmup, batch):
     """The same bench with the split-precision (3 x bf16) GEMM kernels switched off: ICZ_GEMM_*_X3 = 0 selects the fp32-MFMA
     kernels everywhere.  The switches are read once per process, hence a child process (started, not exec'ed into)."""
     import subprocess
-    env = dict(os.environ, ICZ_GEMM_TN_X3="0", ICZ_GEMM_NN_X3="0", ICZ_GEMM_NT_X3BIG="0", ICZ_GEMM_X3="0", ICZ_GEMM_SKINNY_X3="0")
+    env = dict(os.environ, ICZ_GEMM_TN_X3="0", ICZ_GEMM_NN_X3="0", ICZ_GEMM_NT_X3BIG="0", ICZ_GEMM_X3="0", ICZ_GEMM_SKINNY_X3="0",
+               ICZ_GEMM_RESIDENT_X3="0")
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch),
                               "--headline-only"], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         return {"value": j["value"], "ms_per_step": j["ms_per_step"], "note": "ICZ_GEMM_TN_X3=0 ICZ_GEMM_NN_X3=0 ICZ_GEMM_NT_X3BIG=0 "
-                "ICZ_GEMM_SKINNY_X3=0: every GEMM on v_mfma_f32_16x16x4_f32"}
+                "ICZ_GEMM_SKINNY_X3=0 ICZ_GEMM_RESIDENT_X3=0: every GEMM on v_mfma_f32_16x16x4_f32"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -326,6 +328,7 @@ def main():
         run(batches[:1])
         torch.cuda.synchronize()
         if rank == 0:
+            lib().icz_prof_select(1 if RESIDENT_X3 else 0)      # the dominant kernel only
             lib().icz_prof_begin()
         run(batches[1:4])
         torch.cuda.synchronize()
@@ -348,10 +351,11 @@ def main():
         "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
-        "arithmetic": "fp32 throughout (float64 CIDEr-D): the 64-row decoder-step GEMMs on the fp32-input MFMA; the 128 x 128-tile GEMMs "
-                      "(weight gradients, the dgrad over all time steps, forward GEMMs of 128+ rows) multiply fp32 operands as three "
-                      "bf16 pieces each (24 mantissa bits, six bf16 MFMAs per product, fp32 accumulation): fp32-level error, held to "
-                      "3e-6 of the largest output against float64 in tests/test_gpu_butd.py and inside every parity bound of tests/; "
+        "arithmetic": "fp32 storage and fp32 accumulation throughout (float64 CIDEr-D).  The LSTM-gate and vocabulary-projection GEMMs of "
+                      "the decoder steps (64 rows) and the 128 x 128-tile GEMMs (weight gradients, the dgrad over all time steps, forward "
+                      "GEMMs of 128+ rows) multiply fp32 operands as three bf16 pieces each (24 mantissa bits, six bf16 MFMAs per "
+                      "product): fp32-level error, held to 3e-6 of the largest output against float64 in tests/test_gpu_butd.py and "
+                      "inside every parity bound of tests/; the remaining GEMMs (dec_att, per-step dgrad) use the fp32-input MFMA; "
                       "`fp32_mfma_gemms` is the same bench with every GEMM on the fp32-input MFMA",
         "config": {"workload": "BUTDDetection SCST step (greedy + sampled rollout + CIDEr-D reward + REINFORCE backward "
                                "+ clamp + Adam), batch %d per GPU, 36x2048 features, H=E=A=1024, V=10102, 20 decode steps" % B,
@@ -380,21 +384,27 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
     kern = max(pair - max(empty_pair - 1.7, 0.0), 1e-3) if pair > 0 else 0.0
     gbs = bytes_pl / (kern * 1e-6) / 1e9 if kern > 0 else 0.0
     tf = flops_pl / (kern * 1e-6) / 1e12 if kern > 0 else 0.0
-    # The decoder-step GEMMs run on the fp32-input MFMA (157.3 TFLOP/s: the vector rate) unless ICZ_GEMM_SKINNY_X3=1 selects the
-    # split-precision kernel (6 bf16 MFMAs per fp32 product: 2.5 PFLOP/s / 6 = 417 TFLOP/s of fp32-equivalent products)
-    x3 = os.environ.get("ICZ_GEMM_SKINNY_X3", "0") not in ("", "0")
+    # Round 2: the LSTM-gate and vocabulary-projection GEMMs of a decoder step (64 rows) run on gemm_resident_x3_kernel, which
+    # multiplies fp32 operands as three bf16 pieces (6 bf16 MFMAs per fp32 product: 2.5 PFLOP/s / 6 = 417 TFLOP/s of
+    # fp32-equivalent products), so that the weight stream from HBM is what bounds it; with ICZ_GEMM_RESIDENT_X3=0 they fall
+    # back to the fp32-input MFMA kernel (157.3 TFLOP/s: the vector rate), which is bound by the matrix pipe.
+    x3 = RESIDENT_X3
     mfma_peak = 2500.0 / 6.0 if x3 else MFMA_F32_PEAK_TFLOPS
     t_hbm, t_mfma = bytes_pl / (HBM_PEAK_GBS * 1e9), flops_pl / (mfma_peak * 1e12)
     traffic, src = None, None
     try:
         pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
-        nt = [v for k, v in pmc["kernels"].items() if "gemm_skinny_x3_kernel" in k or "gemm_nt_kernel" in k]
+        want = "gemm_resident_x3_kernel" if x3 else "gemm_nt_kernel"
+        nt = [v for k, v in pmc["kernels"].items() if want in k]
         traffic = max(nt, key=lambda v: v["launches"])["hbm_bytes_per_launch"]
-        src = "profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters cannot be read in-process)"
+        src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters "
+               "cannot be read in-process); above the algorithmic bytes by the split-K slabs the kernel writes (12 - 16 slabs of "
+               "rows x N floats per gate GEMM, 4 per vocabulary projection), which its consumers sum")
     except Exception:
         pass
-    roof = {"kernel": "decoder-step forward GEMMs at 64 rows (LSTM gates, dec_att, predict, prologue hoists): " +
-                      ("gemm_skinny_x3_kernel (split precision)" if x3 else "gemm_nt_kernel<4,1,false,128,4,true> (fp32-input MFMA)")}
+    roof = {"kernel": ("gemm_resident_x3_kernel<4,4,2,3> (split precision, activations resident in LDS): the LSTM-gate GEMMs and the "
+                       "vocabulary projection of every decoder step at 64 rows" if x3 else
+                       "decoder-step forward GEMMs at 64 rows: gemm_nt_kernel<4,1,false,128,4,true> (fp32-input MFMA)")}
     if t_mfma >= t_hbm:
         roof.update({"bound": "mfma", "achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak})
     else:
@@ -402,11 +412,11 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
     roof.update({"traffic": traffic, "traffic_source": src, "avg_launch_us": kern, "event_pair_us": pair, "empty_kernel_pair_us": empty_pair,
                  "launches": launches, "bytes_per_launch": bytes_pl, "flops_per_launch": flops_pl,
                  "roofline_us_per_launch": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
-                 "l1_path_note": "measured in round 2 (csrc/gemm_skinny_x3.hip, MEASURED): at 64 rows these GEMMs are bound by the bytes a "
-                                 "compute unit pulls through its vector-memory path, weights AND the activation tile every workgroup "
-                                 "re-reads from L2 (~14 B/cycle/CU for both together), plus ~30 % of fixed prologue / epilogue per launch",
-                 "measured": "HIP event pair around every launch (eager single-stream re-run of bench steps right after the timed region) "
-                             "minus the pair around an empty kernel + 1.7 us",
+                 "bytes_note": "algorithmic bytes per launch = (M K + N K + M N) x 4: activations, weights and output once each "
+                               "(DESIGN.md section 4); what a compute unit actually pulls in is 1.5x that: every workgroup re-reads its "
+                               "64 x 256 activation block from L2 and writes a 64 x 256 slab (gemm_skinny_x3.hip, MEASURED)",
+                 "measured": "HIP event pair around every launch of this kernel (eager single-stream re-run of bench steps right after the "
+                             "timed region) minus the pair around an empty kernel + 1.7 us",
                  "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS})
     return roof
 

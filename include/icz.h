@@ -348,6 +348,10 @@ int icz_gemm_nt_planes(const float* X, int32_t ldx, uint16_t* planes, const floa
  * pair; end synchronises on them and reports the average duration [us] and the ALGORITHMIC bytes / flops per launch
  * (A read once + W read once + C written once; 2MNK). */
 int icz_prof_begin(void);
+/* Which launches icz_prof_begin brackets: 0 (default) = every forward GEMM of a decoder step at 33..64 rows, whatever kernel
+ * takes it; 1 = only the launches of the resident-activation split-precision kernel (gemm_resident_x3_kernel: the LSTM-gate
+ * and vocabulary-projection GEMMs, the dominant kernel of the SCST step since round 2). */
+int icz_prof_select(int32_t which);
 /* Average time [us] of an event pair around an EMPTY kernel on `stream` (n pairs): what the pair itself and the dispatch
  * of the bracketed kernel add to every duration icz_prof_end reports. */
 int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us);

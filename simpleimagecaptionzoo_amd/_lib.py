@@ -166,6 +166,7 @@ def lib():
         "icz_ciderd_cook_host": (C.c_int, [vp, vp, i64, C.c_double, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
         "icz_ciderd_reward_indexed": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
+        "icz_prof_select": (C.c_int, [i32]),
         "icz_prof_pair_overhead": (C.c_int, [vp, i32, C.POINTER(C.c_double)]),
         "icz_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
         "icz_adam_clamp_multi": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, i32, vp]),

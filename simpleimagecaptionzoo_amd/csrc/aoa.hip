@@ -202,11 +202,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
     hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out,
                        (const float*)meanf, s.img_of_row, s.u_next, s.d_ctx_next);
-    GemmArgs p = {};
-    p.nseg = 1;
-    p.seg[0] = {s.ctxdrop, w_pred, Hd, Hd, Hd, nullptr};
-    p.M = rows; p.N = dims.V; p.out = s.logits; p.ldo = Vp; p.bias = P.predict_b; p.nsplit = 1;
-    ICZ_TRY(gemm_f32(GEMM_NT, p, st));
+    ICZ_TRY(gemm_predict(s.ctxdrop, Hd, w_pred, P.predict_b, rows, dims.V, Vp, s.logits, Vp, ws, ws_floats, s.pred_nsplit, st));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -244,8 +240,14 @@ int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
         s.emb_ready = t > 0;
         s.u_ready = t > 0;                       // left by the previous step's GLU kernel (evaluation mode: no dropout)
         if (t + 1 < T) { s.u_next = u; s.d_ctx_next = s.d_ctx; }
+        int pns = 1;
+        s.pred_nsplit = &pns;
         ICZ_TRY(step(s, st));
-        hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
+        if (pns > 1)
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, (const float*)ws, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx,
+                               pns, (size_t)B * Vp, (const float*)P.predict_b);
+        else
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
         hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
                            P.embed_weight, dims.E, emb, it, ids_out, T, t, 1);
         cur ^= 1;

@@ -31,6 +31,7 @@ struct AoaStepIO {
     bool u_ready;                    // s.u was written by the previous step's GLU kernel (skip aoa_u_kernel)
     float* u_next;                   // where this step's GLU kernel leaves the next step's u (null: it does not)
     DropP d_ctx_next;                // the next step's ctx dropout
+    int* pred_nsplit;                // non-null: the caller's consumer sums split-K slabs of the predict GEMM (gemm_predict)
 };
 
 struct Aoa {

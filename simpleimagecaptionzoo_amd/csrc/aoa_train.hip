@@ -309,9 +309,14 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
         io.emb_ready = t > 0;           // written by the previous step's sample_select_kernel
         io.u_ready = t > 0;             // written by the previous step's GLU kernel
         if (t + 1 < T) { const AoaStepIO nx = train_io(B, t + 1, true); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
+        int pns = 1;
+        io.pred_nsplit = &pns;
         ICZ_TRY(step(io, st));
         SampleSelArgs a = {};
         a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
+        if (pns > 1) {          // the predict GEMM left split-K slabs in the bank's workspace
+            a.logits = ws; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b; a.logits_store = tlogit + slot * Vp;
+        }
         a.uniforms = rng.uniforms ? rng.uniforms + slot : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = unf; a.n_unfinished = nunf; a.seq_out = seq_out; a.logp_out = logp_out;

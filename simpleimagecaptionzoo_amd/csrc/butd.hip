@@ -222,27 +222,10 @@ int Butd::step(const StepIO& s, hipStream_t st) {
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
         launch_lstm_point(a, s.drop_out, st);
     }
-    {   // predict: logits = drop(h2) w_pred^T + b
-        GemmArgs g = {};
-        g.nseg = 1;
-        g.seg[0] = {s.h2drop_out ? s.h2drop_out : h2drop, w_pred, H, H, H, nullptr};
-        g.M = rows; g.N = Vp; g.out = ws; g.ldo = Vp;
-        // At 33 - 64 rows the un-split GEMM is 158 workgroups of 64 columns that each re-read the whole activation matrix
-        // (as many bytes as their weights: 25 us for 41 MB); the resident-activation kernel over the padded vocabulary (the
-        // pad rows of w_pred are zero) takes 256 columns and a quarter of K per workgroup (17.5 us) and leaves four slabs,
-        // which a slab-summing consumer (greedy argmax, multinomial draw) adds up together with the bias.
+    {   // predict: logits = drop(h2) w_pred^T + b  (finished logits, or split-K slabs in the chain's workspace for a consumer that sums them)
         const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
-        static int pred_slabs = -1;          // ICZ_PREDICT_SLABS=0: keep the un-split GEMM (A/B runs)
-        if (pred_slabs < 0) { const char* e = getenv("ICZ_PREDICT_SLABS"); pred_slabs = e ? atoi(e) : 1; }
-        if (pred_slabs && s.pred_nsplit && gemm_resident_x3_fits(g) && gemm_slab_floats(rows, Vp, gemm_resident_x3_nsplit(g)) <= ws_cap) {
-            g.nsplit = gemm_resident_x3_nsplit(g);
-            *s.pred_nsplit = g.nsplit;
-        } else {           // K = H is short: no split-K, bias fused
-            g.N = V; g.out = s.logits_out ? s.logits_out : logits; g.ldo = s.logits_ld ? s.logits_ld : Vp; g.bias = P.predict_b;
-            g.nsplit = 1;
-            if (s.pred_nsplit) *s.pred_nsplit = 1;
-        }
-        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        ICZ_TRY(gemm_predict(s.h2drop_out ? s.h2drop_out : h2drop, H, w_pred, P.predict_b, rows, V, Vp, s.logits_out ? s.logits_out : logits,
+                             s.logits_ld ? s.logits_ld : Vp, ws, ws_cap, s.pred_nsplit, st));
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;

@@ -634,11 +634,22 @@ __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restric
     float best = -INFINITY;
     int bi = 0x7fffffff;
     if (ns > 1) {
-        for (int v = v0 + tid; v < v1; v += 256) {
+        // 16-byte loads where the row, the slab stride and the slice start allow it (v0 is a multiple of 4 by construction)
+        const bool vec = ((ldl | (int)(slab_stride & 3)) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)bias) & 15) == 0;
+        const int v1v = vec ? v0 + ((v1 - v0) & ~3) : v0;
+        for (int v = v0 + tid * 4; v < v1v; v += 1024) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(l + v);
+            for (int z = 1; z < ns; ++z) x += *reinterpret_cast<const f32x4*>(l + (size_t)z * slab_stride + v);
+            x += *reinterpret_cast<const f32x4*>(bias + v);
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (x[j] > best) { best = x[j]; bi = v + j; }
+        }
+        for (int v = v1v + tid; v < v1; v += 256) {
             float x = l[v];
             for (int z = 1; z < ns; ++z) x += l[(size_t)z * slab_stride + v];
             x += bias[v];
-            if (x > best) { best = x; bi = v; }
+            if (x > best || (x == best && v < bi)) { best = x; bi = v; }
         }
     } else {
         for (int v = v0 + tid; v < v1; v += 256) {
@@ -908,7 +919,18 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     float mx = -INFINITY;
     if (a.ns > 1) {
         float* ls = a.logits_store + (size_t)row * a.ldl;
-        for (int v = tid; v < a.V; v += SEL_THREADS) {
+        const bool vec = ((a.ldl | (int)(a.slab_stride & 3)) & 3) == 0 &&
+                         (((uintptr_t)a.logits | (uintptr_t)a.bias | (uintptr_t)a.logits_store) & 15) == 0;
+        const int Vv = vec ? (a.V & ~3) : 0;
+        for (int v = tid * 4; v < Vv; v += 4 * SEL_THREADS) {
+            f32x4 x = *reinterpret_cast<const f32x4*>(l + v);
+            for (int z = 1; z < a.ns; ++z) x += *reinterpret_cast<const f32x4*>(l + (size_t)z * a.slab_stride + v);
+            x += *reinterpret_cast<const f32x4*>(a.bias + v);
+            *reinterpret_cast<f32x4*>(ls + v) = x;
+            *reinterpret_cast<f32x4*>(srow + v) = x;
+            mx = fmaxf(mx, fmaxf(fmaxf(x[0], x[1]), fmaxf(x[2], x[3])));
+        }
+        for (int v = Vv + tid; v < a.V; v += SEL_THREADS) {
             float x = l[v];
             for (int z = 1; z < a.ns; ++z) x += l[(size_t)z * a.slab_stride + v];
             x += a.bias[v];

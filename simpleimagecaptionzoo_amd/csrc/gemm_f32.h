@@ -83,6 +83,16 @@ int gemm_skinny_x3(const GemmArgs& a, hipStream_t stream);
 bool gemm_resident_x3_fits(const GemmArgs& a);
 int gemm_resident_x3_nsplit(const GemmArgs& a);
 int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
+// Vocabulary projection of a decoder step: logits[rows, V] = x[rows, H] w_pred^T + bias, w_pred stored [Vp, H] with zero pad rows.
+// At 33 - 64 rows the un-split GEMM is V / 64 workgroups that each re-read the whole activation matrix (as many bytes as their
+// weights: 25 us for 41 MB at V = 10102); the resident-activation kernel over the padded vocabulary takes 256 columns and a
+// quarter of K per workgroup (17.5 us) and leaves split-K slabs [ns][rows][Vp] in `ws`, which a slab-summing consumer
+// (argmax_part_kernel, sample_select_kernel) adds up together with the bias.  pred_nsplit == nullptr: the caller's consumer
+// needs finished logits -> always the un-split GEMM into `logits` (row stride ldl).  Otherwise *pred_nsplit reports what was
+// done: 1 = finished logits in `logits`, > 1 = that many slabs in `ws` (no bias yet).  ICZ_PREDICT_SLABS=0 keeps the un-split GEMM.
+int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
+                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st);
+
 struct Planes;
 int split3_planes(const float* x, int rows, int K, int ld, Planes pl, hipStream_t st);
 

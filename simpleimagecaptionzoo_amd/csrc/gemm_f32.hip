@@ -1094,6 +1094,7 @@ struct GemmProf {
     size_t used = 0;
     double bytes = 0.0, flops = 0.0;
     unsigned seen = 0, every = 1;     // bracket every `every`-th launch (ICZ_PROF_EVERY): fewer event packets in the stream
+    int select = 0;                   // 0: every skinny forward GEMM (NT, 33..64 rows); 1: the resident-activation kernel only
 };
 static GemmProf g_prof;
 static thread_local bool g_capturing = false;
@@ -1320,7 +1321,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         const bool resident = gemm_resident_x3_fits(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == 4;
         const bool skinny = !resident && gemm_skinny_x3_fits(a);
         // inside a stream capture the two records become event nodes of the graph: every replay refreshes them
-        if (g_prof.on && (mt == 4 || skinny || resident) && (g_prof.seen++ % g_prof.every) == 0) {
+        if (g_prof.on && (g_prof.select == 1 ? resident : (mt == 4 || skinny || resident)) && (g_prof.seen++ % g_prof.every) == 0) {
             if (g_prof.used + 2 <= g_prof.ev.size()) {
                 e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
                 g_prof.used += 2;
@@ -1415,6 +1416,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
 }
 
 bool gemm_prof_on() { return g_prof.on; }
+void gemm_prof_select(int which) { g_prof.select = which; }
 void gemm_prof_begin() {
     g_prof.on = true; g_prof.used = 0; g_prof.bytes = 0.0; g_prof.flops = 0.0; g_prof.seen = 0;
     // the whole pool is created here: events cannot be created while a stream capture is in progress
@@ -1470,6 +1472,11 @@ int gemm_prof_pair_overhead(hipStream_t stream, int n, double* avg_us) {
 extern "C" {
 int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us) { return icz::gemm_prof_pair_overhead((hipStream_t)stream, n, avg_us); }
 int icz_prof_begin(void) { icz::gemm_prof_begin(); return ICZ_OK; }
+int icz_prof_select(int32_t which) {
+    if (which < 0 || which > 1) { icz::set_error("icz_prof_select: %d (0 = all skinny forward GEMMs, 1 = resident-activation kernel)", which); return ICZ_ERR_INVALID; }
+    icz::gemm_prof_select(which);
+    return ICZ_OK;
+}
 int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
     return icz::gemm_prof_end(avg_us, bytes_per_launch, flops_per_launch, launches);
 }

@@ -706,6 +706,25 @@ int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
     return ICZ_OK;
 }
 
+int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
+                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st) {
+    static int pred_slabs = -1;
+    if (pred_slabs < 0) pred_slabs = sk_env("ICZ_PREDICT_SLABS", 1);
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {x, w_pred, H, H, H, nullptr};
+    g.M = rows; g.N = Vp; g.out = ws; g.ldo = Vp;
+    if (pred_slabs && pred_nsplit && ws && gemm_resident_x3_fits(g) && gemm_slab_floats(rows, Vp, gemm_resident_x3_nsplit(g)) <= ws_cap_floats) {
+        g.nsplit = gemm_resident_x3_nsplit(g);
+        *pred_nsplit = g.nsplit;
+    } else {           // K = H is short: no split-K, bias fused
+        g.N = V; g.out = logits; g.ldo = ldl; g.bias = bias;
+        g.nsplit = 1;
+        if (pred_nsplit) *pred_nsplit = 1;
+    }
+    return gemm_f32(GEMM_NT, g, st);
+}
+
 // ------------------------------------------------------------------------------------------------
 
 bool gemm_skinny_x3_enabled() {

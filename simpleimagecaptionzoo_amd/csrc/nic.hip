@@ -58,7 +58,7 @@ struct Nic {
     int refresh(hipStream_t st);
     int image_step(const float* feats, int rows, float* h_out, float* c_out, float* gates_out, hipStream_t st);
     int token_step(int rows, const int64_t* tokens, bool emb_ready, const float* h_in, const float* c_in, float* h_out, float* c_out,
-                   float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st);
+                   float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit = nullptr);
     int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
     int ensure_train(int B, int T);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
@@ -122,7 +122,7 @@ int Nic::image_step(const float* feats, int rows, float* h_out, float* c_out, fl
 
 // embed -> LSTMCell -> predict(dropout(h))   (NIC_Model.py:112-114)
 int Nic::token_step(int rows, const int64_t* tokens, bool emb_ready, const float* h_in, const float* c_in, float* h_out, float* c_out,
-                    float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st) {
+                    float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit) {
     const int H = dims.H, E = dims.E, V = dims.V;
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     if (!emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, tokens, emb_out, rows, E, off, 0);
@@ -136,11 +136,7 @@ int Nic::token_step(int rows, const int64_t* tokens, bool emb_ready, const float
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, c_in, h_out, c_out, gates_out, hdrop_out, rows, H};
     launch_lstm_point(a, drop_out, st);
-    GemmArgs p = {};
-    p.nseg = 1;
-    p.seg[0] = {hdrop_out, w_pred, H, H, H, nullptr};
-    p.M = rows; p.N = V; p.out = logits_out; p.ldo = Vp; p.bias = P.predict_b; p.nsplit = 1;
-    ICZ_TRY(gemm_f32(GEMM_NT, p, st));
+    ICZ_TRY(gemm_predict(hdrop_out, H, w_pred, P.predict_b, rows, V, Vp, logits_out, Vp, ws, ws_floats, pred_nsplit, st));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -153,8 +149,13 @@ int Nic::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     int cur = 0;
     for (int t = 0; t < T; ++t) {
-        ICZ_TRY(token_step(B, it, t > 0, h[cur], c[cur], h[cur ^ 1], c[cur ^ 1], emb, nullptr, hdrop, logits, off, st));
-        hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
+        int pns = 1;
+        ICZ_TRY(token_step(B, it, t > 0, h[cur], c[cur], h[cur ^ 1], c[cur ^ 1], emb, nullptr, hdrop, logits, off, st, &pns));
+        if (pns > 1)
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, (const float*)ws, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx,
+                               pns, (size_t)B * Vp, (const float*)P.predict_b);
+        else
+            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
         hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
                            P.embed_weight, dims.E, emb, it, ids_out, T, t, 0);
         cur ^= 1;
@@ -231,11 +232,13 @@ int Nic::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq
     ICZ_TRY(image_step(feats, B, th + sH, tc + sH, tg, st));
     for (int t = 0; t < T; ++t) {
         const size_t slot = (size_t)t * B;
+        int pns = 1;
         ICZ_TRY(token_step(B, tok + slot, false, th + (slot + B) * H, tc + (slot + B) * H, th + (slot + 2 * B) * H, tc + (slot + 2 * B) * H,
                            temb + slot * E, tg + (slot + B) * 4 * H, thd + slot * H, tlogit + slot * Vp,
-                           nic_drop(d_seed, true, rng.out_mask, sH, t), st));
+                           nic_drop(d_seed, true, rng.out_mask, sH, t), st, &pns));
         SampleSelArgs a = {};
         a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
+        if (pns > 1) { a.logits = ws; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b; a.logits_store = tlogit + slot * Vp; }
         a.uniforms = rng.uniforms ? rng.uniforms + slot : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = unf; a.n_unfinished = nunf; a.seq_out = seq_out; a.logp_out = logp_out;

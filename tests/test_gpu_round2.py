@@ -505,3 +505,39 @@ def test_optimizer_state_is_saved_next_to_the_checkpoint(golden_dir, tmp_path):
     run(b, ob_, [3])
     for (k, x), (_, y) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
         assert torch.equal(x, y), k
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_predict_slab_path_matches_the_unsplit_gemm(tmp_path):
+    """At 33 - 64 rows the vocabulary projection of a decoder step goes through the resident-activation kernel and leaves four
+    split-K slabs that the argmax / multinomial kernels sum (gemm_predict, gemm_skinny_x3.hip); ICZ_PREDICT_SLABS=0 keeps the
+    un-split GEMM with finished logits.  Same 64 rows, same Philox seeds, BUTD / AoA / NIC at full width, one child process per
+    setting (the switch is read once per process): identical greedy tokens; sampled tokens identical except where a draw sits
+    within fp32 rounding of a CDF boundary (the two GEMMs differ by 1.4e-6 rms in the logits, tools/dbg_pred_err.py; each of the
+    10102 boundaries of each of the 384 draws is a chance: at most two rows per family may leave, and only to the neighbouring
+    token); log-probs of the drawn tokens within 3e-5 on the rows that agree; the gradient of the output bias (built from the
+    saved logits the multinomial kernel writes) within 1e-6 when every row agrees."""
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    res = {}
+    for flag in ("1", "0"):
+        out = str(tmp_path / ("slab%s.npz" % flag))
+        env = dict(os.environ, ICZ_PREDICT_SLABS=flag)
+        r = subprocess.run([sys.executable, os.path.join(here, "slab_ab_worker.py"), out], env=env, capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[flag] = dict(np.load(out))
+    a, b = res["1"], res["0"]
+    for fam in ("butd", "aoa", "nic"):
+        assert np.array_equal(a[fam + "_greedy"], b[fam + "_greedy"]), fam
+        sa, sb = a[fam + "_seq"], b[fam + "_seq"]
+        first = _first_divergence(sa, sb)
+        rows = np.where(first >= 0)[0]
+        assert len(rows) <= 2, (fam, rows)
+        for r_ in rows:
+            assert abs(int(sa[r_, first[r_]]) - int(sb[r_, first[r_]])) <= 2, (fam, r_, sa[r_], sb[r_])
+        same = first < 0
+        np.testing.assert_allclose(a[fam + "_lp"][same], b[fam + "_lp"][same], atol=3e-5, err_msg=fam)
+        if same.all():
+            np.testing.assert_allclose(a[fam + "_dbias"], b[fam + "_dbias"], atol=1e-6, err_msg=fam)
+        assert (sa > 0).any() and np.isfinite(a[fam + "_lp"]).all()

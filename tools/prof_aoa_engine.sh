@@ -1,0 +1,10 @@
+#!/bin/bash
+# rocprofv3 kernel stats of tools/perf_aoa_engine.py (13 AoA SCST steps through the Engine) -> gpurun_out/prof_r02/aoa_kernel_stats.csv
+ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$ROOT/gpurun_out/prof_r02
+mkdir -p $OUT
+cd /tmp && export TMPDIR=/tmp
+rm -rf /tmp/p_aoa
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_aoa -- python3 $ROOT/tools/perf_aoa_engine.py > $OUT/aoa_engine.log 2> $OUT/aoa_stats.err
+cp $(find /tmp/p_aoa -name '*kernel_stats.csv' | head -1) $OUT/aoa_kernel_stats.csv
+tail -2 $OUT/aoa_engine.log
