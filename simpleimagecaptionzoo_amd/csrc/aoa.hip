@@ -181,7 +181,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     g.seg[1] = {s.u, P.lstm_w_ih + E, Hd, E + Hd, Hd, nullptr};
     g.seg[2] = {s.h_in, P.lstm_w_hh, Hd, Hd, Hd, nullptr};
     g.M = rows; g.N = 4 * Hd; g.out = ws; g.ldo = 4 * Hd;
-    g.nsplit = gemm_pick_split(g, STEP_WGS);
+    g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "aoa: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd};
@@ -197,7 +197,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};
     zg.seg[1] = {s.qn, P.dec.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
     zg.M = rows; zg.N = 2 * Hd; zg.out = ws; zg.ldo = 2 * Hd;
-    zg.nsplit = gemm_pick_split(zg, STEP_WGS);
+    zg.nsplit = gemm_fit_split(GEMM_NT, zg, gemm_pick_split(zg, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(zg.M, zg.N, zg.nsplit) <= ws_floats, "aoa: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
     hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out,

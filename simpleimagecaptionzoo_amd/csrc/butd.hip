@@ -176,9 +176,10 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {embp, P.td_w_ih + H + D, E, H + D + E, E, nullptr};
         g.seg[2] = {s.h1_in, P.td_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-        g.nsplit = gemm_pick_split(g, STEP_WGS);
+        const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
+        g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_cap);
         ns = g.nsplit;
-        ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_floats && (size_t)rows * 4 * H <= ws_floats, "butd: workspace too small");
+        ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_cap && (size_t)rows * 4 * H <= ws_cap, "butd: workspace too small");
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
@@ -215,8 +216,10 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {s.h1_out, P.lm_w_ih + D, H, D + H, H, nullptr};
         g.seg[2] = {s.h2_in, P.lm_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-        g.nsplit = gemm_pick_split(g, STEP_WGS);
+        const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;
+        g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_cap);
         ns = g.nsplit;
+        ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_cap && (size_t)rows * 4 * H <= ws_cap, "butd: workspace too small");
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};

@@ -1059,8 +1059,17 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
         const int kend = a.nsplit > 1 ? min(a.seg[0].K, kbeg + a.chunks_per_split * 128) : a.seg[0].K;
         run_segment(a.seg[0], kbeg, kend);
     } else {
+        // several K segments: the split's range [gbeg, gend) of the concatenated K is cut at the segment borders
+        const int gbeg = a.nsplit > 1 ? (int)blockIdx.z * a.chunks_per_split * 128 : 0;
+        const int gend = a.nsplit > 1 ? gbeg + a.chunks_per_split * 128 : 0x7fffffff;
+        int off = 0;
 #pragma unroll 1
-        for (int sgi = 0; sgi < a.nseg; ++sgi) run_segment(a.seg[sgi], 0, a.seg[sgi].K);
+        for (int sgi = 0; sgi < a.nseg; ++sgi) {
+            const int K = a.seg[sgi].K;
+            const int kb = max(gbeg - off, 0), ke = min(gend - off, K);
+            if (kb < ke) run_segment(a.seg[sgi], kb, ke);
+            off += K;
+        }
     }
     // acc[i][u][q] <-> row m0 + mbase + 32 i + (q & 3) + 8 (q >> 2) + 4 h, column n0 + nbase + 32 u + r
     const bool direct = a.nsplit == 1;
@@ -1172,7 +1181,10 @@ static bool nt_x3big(const GemmArgs& a) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return false;
     const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
-    return a.nseg == 1 ? tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128 : tiles >= 128;
+    if (a.nseg == 1) return tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128;
+    int tot = 0;                                   // several segments: their concatenation is split as well (gemm_pick_split)
+    for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / 128;
+    return tiles * (tot / 8 > 0 ? tot / 8 : 1) >= 128;
 }
 static int nt_waves(const GemmArgs& a) {
     static int force = -1;
@@ -1200,8 +1212,20 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
         // 128 x 128 tiles, two workgroups per CU.  Measured at 2304 rows (tools/perf_gemm_nt_big.py, us for split 1 / 2 / 3 / 4):
         // N 1024 K 1024: 48 / 55 / 50 / 63;  N 1024 K 2048: 86 / 89 / 77 / 96;  N 2048 K 2048: 165 / 164 / 148 / 153;
         // N 3072 K 1024: 92 / 115 / 124 / 135  ->  up to 1.75 rounds of workgroups, at least 5 chunks of 128 per split
-        if (a.nseg > 1) return 1;
-        const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128), tot = a.seg[0].K / 128;
+        const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
+        if (a.nseg > 1) {
+            // several K segments (the LSTM gates of a beam-search step: 160 tiles at 640 rows, each pulling 4 MB through its
+            // compute unit, 96 of the 256 CUs idle): one round of at most 512 workgroups, at least 8 chunks of 128 per split
+            int tot = 0;
+            for (int sg = 0; sg < a.nseg; ++sg) tot += a.seg[sg].K / 128;
+            static int ms = -1;
+            if (ms < 0) { const char* e = getenv("ICZ_GEMM_NT_X3BIG_MSPLIT"); ms = e ? atoi(e) : 1; }
+            int s = ms ? 512 / (tiles > 0 ? tiles : 1) : 1;
+            if (s > tot / 8) s = tot / 8;
+            if (s < 1) s = 1;
+            return cdiv(tot, cdiv(tot, s));
+        }
+        const int tot = a.seg[0].K / 128;
         int s = 896 / tiles;
         if (s > tot / 5) s = tot / 5;
         if (s < 1) s = 1;
@@ -1300,7 +1324,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     bool tail = false;
     for (int s = 0; s < a.nseg; ++s) tail |= (a.seg[s].K % GEMM_BK) != 0;
     if (layout == GEMM_NT) {
-        if (nt_x3big(a) && (a.nseg == 1 || a.nsplit == 1)) {
+        if (nt_x3big(a)) {
             static bool attr = false;
             if (!attr) {
                 ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4, true, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));

@@ -111,7 +111,7 @@ int Nic::image_step(const float* feats, int rows, float* h_out, float* c_out, fl
     g.nseg = 1;
     g.seg[0] = {feats, P.w_ih, E, E, E, nullptr};
     g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-    g.nsplit = gemm_pick_split(g, STEP_WGS);
+    g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "nic: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, zeros, h_out, c_out, gates_out, nullptr, rows, H};
@@ -131,7 +131,7 @@ int Nic::token_step(int rows, const int64_t* tokens, bool emb_ready, const float
     g.seg[0] = {emb_out, P.w_ih, E, E, E, nullptr};
     g.seg[1] = {h_in, P.w_hh, H, H, H, nullptr};
     g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
-    g.nsplit = gemm_pick_split(g, STEP_WGS);
+    g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "nic: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, c_in, h_out, c_out, gates_out, hdrop_out, rows, H};
