@@ -120,6 +120,173 @@ __global__ __launch_bounds__(256) void beam_rowtopk_kernel(const float* __restri
     }
 }
 
+// The same result from a row held in registers (16-byte loads, one pass over memory) and a threshold instead of per-thread
+// sorted lists.  The sorted insertion above is VALU-bound: a wave skips an element only when none of its 64 lanes inserts it,
+// so nearly all of the 40 x 8-deep insertion chains execute (36 us per step at 640 rows).  Here every thread takes the maximum
+// of its 4 NV4 candidate scores; tau = the n-th largest of the 256 thread maxima (n = active beams; equal maxima of different
+// threads count separately).  At least n scores are >= tau, so every member of the row's top n is: the threads append their
+// scores >= tau to an LDS list (a handful unless the row is full of ties) and one wave picks the top n of the list by
+// (score descending, index ascending) -- the order of a top-k over the flattened scores.  A list that overflows (massive ties,
+// e.g. constant logits) sends the workgroup through the insertion algorithm on the LDS-staged scores instead.
+// Needs V <= 1024 NV4, 16-byte aligned rows (ldl % 4 == 0).  The log-sum-exp is summed in a different element order than in
+// the kernel above (thread t holds elements 4 (t + 256 u) + j): scores may differ in the last bit.
+constexpr int BEAM_CAND_CAP = 128;
+template <int NV4>
+__global__ __launch_bounds__(256) void beam_rowtopk_reg_kernel(const float* __restrict__ logits, int V, int ldl, int k, int step,
+                                                               const int* __restrict__ n_act, const float* __restrict__ run,
+                                                               float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+    __shared__ float smf[4];
+    __shared__ float s_val[4];
+    __shared__ int s_idx[4], s_who[4];
+    __shared__ int s_cnt, s_taken;
+    __shared__ float s_cv[BEAM_CAND_CAP];
+    __shared__ int s_ci[BEAM_CAND_CAP];
+    extern __shared__ __attribute__((aligned(16))) float s_row[];          // overflow path only: 1024 NV4 floats
+    const int row = blockIdx.x, img = row / k, r = row % k, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int na = n_act[img];
+    const int nr = (step == 1) ? 1 : na;          // step 1 scores row 0 only (:273-274)
+    if (r >= nr) return;
+    const float* l = logits + (size_t)row * ldl;
+    f32x4 x[NV4];
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) {
+        const int v = 4 * (tid + 256 * u);
+        x[u] = v < V ? *reinterpret_cast<const f32x4*>(l + v) : (f32x4){-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) if (v + j >= V) x[u][j] = -INFINITY;
+    }
+    if (tid == 0) { s_cnt = 0; s_taken = 0; }
+    float mx = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) mx = fmaxf(mx, fmaxf(fmaxf(x[u][0], x[u][1]), fmaxf(x[u][2], x[u][3])));
+    mx = block_max_256(mx, smf);
+    float se = 0.f;
+#pragma unroll
+    for (int u = 0; u < NV4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) se += expf(x[u][j] - mx);          // exp(-inf) = 0 for the slots beyond V
+    se = block_sum_256(se, smf);
+    const float ls = logf(se);
+    const float rs = (step == 1) ? 0.f : run[row];
+    float tmax = -INFINITY;
+#pragma unroll
+    for (int u = 0; u < NV4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            x[u][j] = rs + ((x[u][j] - mx) - ls);                      // the candidate score (beyond V: -inf)
+            tmax = fmaxf(tmax, x[u][j]);
+        }
+    // tau: rounds of block maximum over the thread maxima not yet counted, until na of them are
+    float tau = -INFINITY;
+    {
+        float cur = tmax;
+        for (int round = 0; round < BEAM_MAX_K; ++round) {
+            const float m = block_max_256(cur, smf);
+            const bool hit = cur == m && m > -INFINITY;
+            const unsigned long long b = __ballot(hit);
+            if (lane == 0 && b) atomicAdd(&s_taken, __popcll(b));
+            if (hit) cur = -INFINITY;
+            __syncthreads();
+            tau = m;
+            const int taken = s_taken;
+            __syncthreads();
+            if (taken >= na || m == -INFINITY) break;
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < NV4; ++u)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x[u][j] >= tau && x[u][j] > -INFINITY) {
+                const int pos = atomicAdd(&s_cnt, 1);
+                if (pos < BEAM_CAND_CAP) { s_cv[pos] = x[u][j]; s_ci[pos] = 4 * (tid + 256 * u) + j; }
+            }
+    __syncthreads();
+    const int cnt = s_cnt;
+    if (cnt <= BEAM_CAND_CAP) {
+        if (wave != 0) return;
+        float v0 = lane < cnt ? s_cv[lane] : -INFINITY, v1 = lane + 64 < cnt ? s_cv[lane + 64] : -INFINITY;
+        int i0 = lane < cnt ? s_ci[lane] : 0x7fffffff, i1 = lane + 64 < cnt ? s_ci[lane + 64] : 0x7fffffff;
+        for (int j = 0; j < na; ++j) {
+            float best = v0;
+            int bi = i0;
+            if (v1 > best || (v1 == best && i1 < bi)) { best = v1; bi = i1; }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float ob = __shfl_xor(best, o, 64);
+                const int oi = __shfl_xor(bi, o, 64);
+                if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
+            }
+            if (i0 == bi) { v0 = -INFINITY; i0 = 0x7fffffff; }      // taken (indices are unique)
+            if (i1 == bi) { v1 = -INFINITY; i1 = 0x7fffffff; }
+            if (lane == 0) { cand_val[row * BEAM_MAX_K + j] = best; cand_idx[row * BEAM_MAX_K + j] = bi; }
+        }
+        return;
+    }
+    // ---- overflow: the insertion algorithm of beam_rowtopk_kernel on the scores, staged in LDS in index order
+#pragma unroll
+    for (int u = 0; u < NV4; ++u) *reinterpret_cast<f32x4*>(s_row + 4 * (tid + 256 * u)) = x[u];
+    __syncthreads();
+    float tv[BEAM_MAX_K];
+    int ti[BEAM_MAX_K];
+#pragma unroll
+    for (int j = 0; j < BEAM_MAX_K; ++j) { tv[j] = -INFINITY; ti[j] = 0x7fffffff; }
+    float worst = -INFINITY;
+    int worst_i = 0x7fffffff;
+    for (int v = tid; v < V; v += 256) {
+        float val = s_row[v];
+        int idx = v;
+        if (!(val > worst || (val == worst && idx < worst_i))) continue;
+#pragma unroll
+        for (int j = 0; j < BEAM_MAX_K; ++j) {
+            const bool take = (j < na) & ((val > tv[j]) | ((val == tv[j]) & (idx < ti[j])));
+            const float ov = tv[j]; const int oi = ti[j];
+            tv[j] = take ? val : ov; ti[j] = take ? idx : oi;
+            val = take ? ov : val; idx = take ? oi : idx;
+        }
+#pragma unroll
+        for (int j = 0; j < BEAM_MAX_K; ++j) {
+            worst = (j == na - 1) ? tv[j] : worst;
+            worst_i = (j == na - 1) ? ti[j] : worst_i;
+        }
+    }
+    int head = 0;
+    for (int j = 0; j < na; ++j) {
+        float best = -INFINITY;
+        int bi = 0x7fffffff;
+#pragma unroll
+        for (int q = 0; q < BEAM_MAX_K; ++q)
+            if (q == head) { best = tv[q]; bi = ti[q]; }
+        int who = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float ob = __shfl_xor(best, o, 64);
+            const int oi = __shfl_xor(bi, o, 64), ow = __shfl_xor(who, o, 64);
+            if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; who = ow; }
+        }
+        if (lane == 0) { s_val[wave] = best; s_idx[wave] = bi; s_who[wave] = who; }
+        __syncthreads();
+        best = s_val[0]; bi = s_idx[0]; who = s_who[0];
+#pragma unroll
+        for (int w = 1; w < 4; ++w)
+            if (s_val[w] > best || (s_val[w] == best && s_idx[w] < bi)) { best = s_val[w]; bi = s_idx[w]; who = s_who[w]; }
+        if (tid == who) ++head;
+        if (tid == 0) { cand_val[row * BEAM_MAX_K + j] = best; cand_idx[row * BEAM_MAX_K + j] = bi; }
+        __syncthreads();
+    }
+}
+
+// per-row candidates of one beam step: the register kernel where the vocabulary fits it, else the sweep kernel
+inline void launch_beam_rowtopk(hipStream_t st, int rows, const float* logits, int V, int ldl, int k, int step, const int* n_act,
+                                const float* run, float* cand_val, int* cand_idx) {
+    static int use_reg = -1;
+    if (use_reg < 0) { const char* e = getenv("ICZ_BEAM_TOPK_REG"); use_reg = e ? atoi(e) : 1; }
+    const bool ok = use_reg && ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0;
+    if (ok && V <= 1024 * 3) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<3>), dim3(rows), dim3(256), sizeof(float) * 1024 * 3, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
+    else if (ok && V <= 1024 * 10) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<10>), dim3(rows), dim3(256), sizeof(float) * 1024 * 10, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
+    else hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
+}
+
 __global__ __launch_bounds__(64) void beam_merge_kernel(BeamArgs a, const float* __restrict__ cand_val, const int* __restrict__ cand_idx) {
     __shared__ float pick_val[BEAM_MAX_K];
     __shared__ int pick_idx[BEAM_MAX_K];

@@ -463,8 +463,7 @@ int Nic::beam_search(const float* feats, int n_img, int k, int max_steps, float*
         ICZ_TRY(token_step(rows, it, false, h[0], c[0], h[1], c[1], emb, nullptr, hdrop, logits, off, st));
         BeamArgs a = {logits, dims.V, Vp, k, step, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + step};
-        hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run,
-                           bm.cand_val, bm.cand_idx);
+        launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx);
         hipLaunchKernelGGL(beam_merge_kernel, dim3(n_img), dim3(64), 0, st, a, (const float*)bm.cand_val, (const int*)bm.cand_idx);
         hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h[1], c[1], h[1], c[1], h[0], c[0], h[0], c[0]);
         sb ^= 1;

@@ -541,3 +541,33 @@ def test_predict_slab_path_matches_the_unsplit_gemm(tmp_path):
         if same.all():
             np.testing.assert_allclose(a[fam + "_dbias"], b[fam + "_dbias"], atol=1e-6, err_msg=fam)
         assert (sa > 0).any() and np.isfinite(a[fam + "_lp"]).all()
+
+
+@pytest.mark.parametrize("V", [600, 3000])
+def test_beam_topk_with_massive_ties_takes_the_lowest_indices(V):
+    """The per-row top-k of a beam step keeps a candidate list of the scores >= the n-th largest thread maximum; a row full of
+    equal scores overflows the list and takes the insertion path instead (beam_kernels.h).  Ties must go to the lowest flat
+    index (the order of a top-k over the flattened [k, V] scores, BUTD_Model.py:271-276).  Output layer with zero weights, so
+    the logits are the bias: 200 tokens tie at the top, among them <pad>, <sta> and <end>."""
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    R_, D_, H_, E_, A_ = 4, 16, 8, 8, 8
+    params = random_butd_params(R_, D_, H_, E_, A_, V, "cuda", seed=5)
+    params["predict.weight_g"].zero_()
+    rs = np.random.RandomState(V)
+    top = np.concatenate([[0, 1, 2], 3 + rs.choice(V - 3, 197, replace=False)])
+    bias = np.zeros(V, dtype=np.float32)
+    bias[top] = 1.0
+    params["predict.bias"].copy_(torch.from_numpy(bias))
+    h = ButdHandle(R_, D_, H_, E_, A_, V, 3 * 5, 20)
+    h.bind(params)
+    feats = torch.relu(torch.randn(3, R_, D_, device="cuda"))
+    # k = 5, one step: the five lowest tied indices are 0, 1, 2 and two more -> <end> is among them -> [<sta>, <end>]
+    seqs, lens = h.beam_search(feats, 5, 1)
+    assert lens.cpu().tolist() == [2, 2, 2] and (seqs[:, :2].cpu() == torch.tensor([1.0, 2.0])).all()
+    # k = 1: the single best of a full tie is token 0 at every step, never <end>
+    seqs, lens = h.beam_search(feats, 1, 4)
+    assert lens.cpu().tolist() == [5, 5, 5] and (seqs[:, :5].cpu() == torch.tensor([1.0, 0, 0, 0, 0])).all()
+    # k = 2: tokens 0 and 1 at step 1; at step 2 the two best flat indices are row 0's tokens 0 and 1
+    seqs, lens = h.beam_search(feats, 2, 2)
+    assert lens.cpu().tolist() == [3, 3, 3] and (seqs[:, :3].cpu() == torch.tensor([1.0, 0, 0])).all()
