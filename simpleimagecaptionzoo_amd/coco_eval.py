@@ -7,7 +7,11 @@ cider.py:34-56 -> cider_scorer.py:96-195) returns the corpus CIDEr.  Neither pyc
   * `load_annotations` reads the COCO caption json directly ({image_id: [caption, ...]}, what COCO.imgToAnns holds);
   * `ptb_lite_tokenize` is a rule-based stand-in for `PTBTokenizer -preserveLines -lowerCase` followed by the reference's
     punctuation filter (ptbtokenizer.py:24-25,66-68).  PARITY UNPINNED: the jar cannot run in this image, so there are
-    no golden vectors for the tokeniser itself (it agrees with PTB on plain captions; rare symbols may differ);
+    no golden vectors for the tokeniser itself (it agrees with PTB on plain captions; rare symbols may differ).  The rules that are
+    implemented are the documented Penn-Treebank conventions (contractions n't / 's / 're / 've / 'll / 'd / 'm split off,
+    cannot -> can not, gonna -> gon na, brackets to -lrb- / -rrb-, $ % & # as tokens, digit groups like 1,000 and 3:30
+    kept whole, sentence-final periods split, abbreviations kept), each with an explicit expectation in
+    tests/test_cpu_abi_and_host.py;
   * `Cider.compute_score` scores on the device with the CIDEr-D kernel of the SCST reward (csrc/ciderd.hip): the
     per-image formula is the same (clipped tf-idf cosine x Gaussian length penalty), only the document frequencies differ
     -- here they are counted over the evaluated references themselves (cider_scorer.py:96-107,164).  Scores are bit-exact
@@ -26,15 +30,17 @@ from .synth import document_frequency
 PUNCTUATIONS = ["''", "'", "``", "`", "-LRB-", "-RRB-", "-LCB-", "-RCB-", ".", "?", "!", ",", ":", "-", "--", "...", ";"]
 
 _BRACKETS = {"(": "-lrb-", ")": "-rrb-", "[": "-lsb-", "]": "-rsb-", "{": "-lcb-", "}": "-rcb-"}
+_ABBREV = {"mr.", "mrs.", "ms.", "dr.", "st.", "jr.", "sr.", "vs.", "etc.", "no.", "inc.", "co.", "ave.", "mt."}      # kept with their period
 _CONTRACTION = re.compile(r"(?i)\b(can)(not)\b")
 _SUFFIX = re.compile(r"(?i)([a-z0-9])('ll|'re|'ve|n't|'s|'m|'d)\b")
-_SPLIT = re.compile(r"(\.\.\.|--|[\"(){}\[\]?!,:;]|``|'')")
+_SPLIT = re.compile(r"(\.\.\.|--|[\"(){}\[\]?!;$%&#]|(?<!\d)[,:]|[,:](?!\d)|``|'')")      # "1,000" and "3:30" stay whole
 
 
 def ptb_lite_tokenize(sentence):
     """One caption -> lower-cased, space-joined PTB-style tokens without punctuation tokens."""
     s = sentence.replace("\n", " ").lower()
     s = _CONTRACTION.sub(r"\1 \2", s)
+    s = re.sub(r"\b(gon|wan)(na)\b|\b(got)(ta)\b|\b(lem|gim)(me)\b", lambda m: " ".join(g for g in m.groups() if g), s)   # PTB: gon na, got ta, lem me
     s = _SUFFIX.sub(r"\1 \2", s)
     s = _SPLIT.sub(r" \1 ", s)
     out = []
@@ -43,7 +49,7 @@ def ptb_lite_tokenize(sentence):
             tok = "''"
         tok = _BRACKETS.get(tok, tok)
         # a sentence-final period is its own token; periods inside abbreviations / numbers stay attached
-        while len(tok) > 1 and tok.endswith(".") and not re.fullmatch(r"\.+|([a-z]\.)+|\d+(\.\d+)+\.?", tok):
+        while len(tok) > 1 and tok.endswith(".") and tok not in _ABBREV and not re.fullmatch(r"\.+|([a-z]\.)+|\d+(\.\d+)+\.?", tok):
             tok = tok[:-1]
             out.append(tok)
             tok = "."

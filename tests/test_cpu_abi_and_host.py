@@ -127,6 +127,14 @@ def test_ptb_lite_tokenizer_and_annotation_loader(tmp_path):
     assert ptb_lite_tokenize("The dog's toy isn't here... it's the cats' toy") == "the dog 's toy is n't here it 's the cats toy"
     assert ptb_lite_tokenize('He said "hello" (twice) at 3 o\'clock.') == "he said hello -lrb- twice -rrb- at 3 o'clock"
     assert ptb_lite_tokenize("") == "" and ptb_lite_tokenize(" . ") == ""
+    # Penn-Treebank conventions beyond plain captions (UNPINNED against the Stanford jar, see coco_eval.py): each is the
+    # documented PTB3 behaviour, lower-cased, punctuation tokens of ptbtokenizer.py:24-25 dropped afterwards
+    assert ptb_lite_tokenize("I'm gonna say we've got 1,000 kites at 3:30, OK?") == "i 'm gon na say we 've got 1,000 kites at 3:30 ok"
+    assert ptb_lite_tokenize("You cannot park here; they'd tow it.") == "you can not park here they 'd tow it"
+    assert ptb_lite_tokenize("A $5 pizza & 50% off") == "a $ 5 pizza & 50 % off"
+    assert ptb_lite_tokenize("Mr. Smith's U.S. flag.") == "mr. smith 's u.s. flag"
+    assert ptb_lite_tokenize("a well-lit, snow-covered street") == "a well-lit snow-covered street"
+    assert ptb_lite_tokenize("children: two boys, a girl") == "children two boys a girl"
     ann = {"annotations": [{"image_id": 7, "caption": "A cat."}, {"image_id": 9, "caption": "Dogs!"}, {"image_id": 7, "caption": "Cat sits"}]}
     p = tmp_path / "ann.json"
     p.write_text(json.dumps(ann))
