@@ -96,6 +96,7 @@ def secondary(eng, opt, words, device, B):
     dt = (_t.perf_counter() - t0) / 10
     out["xe_step"] = {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B,
                       "note": "Engine.training_epoch, captions of 9..18 tokens, label smoothing 0.1"}
+    out["xe_step_spatial49"] = xe_spatial(device, B, xb)
     # decoding on freshly initialised weights (the trained-for-a-few-steps ones above may or may not emit <end>: the beam
     # search stops early when every beam has finished, which would make the number depend on the training state)
     from simpleimagecaptionzoo_amd.butd import ButdHandle
@@ -136,6 +137,37 @@ def secondary(eng, opt, words, device, B):
     del h, f128, f64
     out["aoa_scst_step"] = aoa_scst(words, device, B)
     return out
+
+
+def xe_spatial(device, B, xb):
+    """BASELINE config 2 at N = 1: BUTDSpatial XE training step (7 x 7 grid = 49 regions of 2048 features, BUTD_Model.py:321-440 +
+    Engine.py:169-188), batch B, through BUTDSpatial_Eng.training_epoch; same captions as `xe_step`."""
+    import time as _t
+    from simpleimagecaptionzoo_amd.engine import BUTDSpatial_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    try:
+        eng = BUTDSpatial_Eng({"model_type": "BUTDSpatial", "atten_dim": A, "embed_dim": E, "hidden_dim": H}, "SYN", synthetic_vocab(V),
+                              data_dir="/tmp/", device=device, max_batch=B)
+        opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+        sb = []
+        for ids, _, caps, lens, _supp in xb:
+            sb.append((ids, None, caps, lens, {"bu_feats": torch.relu(torch.randn(B, 49, D, device=device))}))
+
+        class _Crit:
+            smoothing = 0.1
+
+        def run(n):
+            eng.training_epoch([sb[i % 2] for i in range(n)], opt, _Crit(), tqdm_visible=False)
+        run(3)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        run(10)
+        torch.cuda.synchronize()
+        dt = (_t.perf_counter() - t0) / 10
+        return {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B, "regions": 49,
+                "note": "BUTDSpatial_Eng.training_epoch (BASELINE config 2 at N = 1): 49 grid regions x 2048, captions of 9..18 tokens"}
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def aoa_scst(words, device, B):
