@@ -172,73 +172,12 @@ __global__ __launch_bounds__(256) void lstm_point_kernel(LstmPointArgs a, DropCf
     }
 }
 
-// The same with four hidden units per thread and one wave per workgroup (grid (H / 256, rows)): 16-byte accesses, every load
-// of a thread independent of the others.  The resident-activation gate GEMM (gemm_skinny_x3.hip) leaves 12 - 16 split-K
-// slabs: the one-unit-per-thread kernel then issues 64 four-byte wave loads per thread (8.3 us at 64 rows); this one moves
-// the same 16.8 MB in a quarter of the instructions.  Same summation order per element (slabs ascending, pre, b_ih, b_hh).
-// slab count from which the four-unit kernel is used (ICZ_LSTM4_MIN_SLABS, development: 99 switches it off)
-inline int lstm4_min_slabs() {
-    static int v = -1;
-    if (v < 0) { const char* e = getenv("ICZ_LSTM4_MIN_SLABS"); v = e ? atoi(e) : 8; }
-    return v;
-}
-__global__ __launch_bounds__(64) void lstm_point4_kernel(LstmPointArgs a, DropCfg dc) {
-    const int row = blockIdx.y;
-    const int j = (blockIdx.x * 64 + threadIdx.x) * 4;
-    if (j >= a.H) return;
-    const int H = a.H, G = 4 * H;
-    const size_t MN = (size_t)a.rows * G;
-    const int pr = (a.pre && a.pre_row) ? a.pre_row[row] : row;
-    f32x4 gt[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-        const size_t off = (size_t)row * G + q * H + j;
-        f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        int z = 0;
-        for (; z + 4 <= a.nsplit; z += 4) {
-            const f32x4 v0 = *reinterpret_cast<const f32x4*>(a.slab + (size_t)z * MN + off);
-            const f32x4 v1 = *reinterpret_cast<const f32x4*>(a.slab + (size_t)(z + 1) * MN + off);
-            const f32x4 v2 = *reinterpret_cast<const f32x4*>(a.slab + (size_t)(z + 2) * MN + off);
-            const f32x4 v3 = *reinterpret_cast<const f32x4*>(a.slab + (size_t)(z + 3) * MN + off);
-            s += v0; s += v1; s += v2; s += v3;
-        }
-        for (; z < a.nsplit; ++z) s += *reinterpret_cast<const f32x4*>(a.slab + (size_t)z * MN + off);
-        if (a.pre) s += *reinterpret_cast<const f32x4*>(a.pre + (size_t)pr * G + q * H + j);
-        s += *reinterpret_cast<const f32x4*>(a.b_ih + q * H + j);
-        s += *reinterpret_cast<const f32x4*>(a.b_hh + q * H + j);
-        gt[q] = s;
-    }
-    const f32x4 cp = *reinterpret_cast<const f32x4*>(a.c_prev + (size_t)row * H + j);
-    f32x4 gi, gf, gg, go, cn, hn;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-        gi[e] = sigmoidf_(gt[0][e]); gf[e] = sigmoidf_(gt[1][e]); gg[e] = tanhf(gt[2][e]); go[e] = sigmoidf_(gt[3][e]);
-        cn[e] = gf[e] * cp[e] + gi[e] * gg[e];
-        hn[e] = go[e] * tanhf(cn[e]);
-    }
-    *reinterpret_cast<f32x4*>(a.h_out + (size_t)row * H + j) = hn;
-    *reinterpret_cast<f32x4*>(a.c_out + (size_t)row * H + j) = cn;
-    if (a.gates_out) {
-        float* go_ = a.gates_out + (size_t)row * G + j;
-        *reinterpret_cast<f32x4*>(go_) = gi; *reinterpret_cast<f32x4*>(go_ + H) = gf;
-        *reinterpret_cast<f32x4*>(go_ + 2 * H) = gg; *reinterpret_cast<f32x4*>(go_ + 3 * H) = go;
-    }
-    if (a.hdrop_out) {
-        f32x4 hd = hn;
-        if (dc.mode) {
-            const uint32_t k = dc.keep4((uint64_t)row * H + j);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) hd[e] = ((k >> e) & 1u) ? hn[e] * 2.0f : 0.f;
-        }
-        *reinterpret_cast<f32x4*>(a.hdrop_out + (size_t)row * H + j) = hd;
-    }
-}
-
 // Gate-per-wave form, grid (H / 256, rows), 256 threads: wave q sums gate q of the workgroup's 256 hidden units (16 bytes per
-// lane and slab, the loads of up to eight slabs independent), the four gates meet in LDS and thread j finishes unit j.  Four
-// times the waves of the four-unit kernel with the same 16-byte accesses: at 12 - 16 slabs (16.8 MB at 64 rows) that kernel
+// lane and slab, the loads of up to eight slabs independent), the four gates meet in LDS and thread j finishes unit j.  The
+// resident-activation gate GEMM (gemm_skinny_x3.hip) leaves 12 - 16 split-K slabs (16.8 MB at 64 rows): the one-unit kernel
+// above then issues 64 four-byte wave loads per thread (8.3 us), a four-units-per-thread form with one wave per workgroup
 // has ONE wave per compute unit waiting on 64 KB (9.5 us in the SCST trace); here four waves per compute unit wait on 16 KB
-// each.  Same summation order per element (slabs ascending, pre, b_ih, b_hh): results bit-identical to the other two kernels.
+// each (5.1 us).  Same summation order per element (slabs ascending, pre, b_ih, b_hh): bit-identical to the kernel above.
 __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, DropCfg dc) {
     __shared__ __attribute__((aligned(16))) float sg[4][256];
     const int row = blockIdx.y, tid = threadIdx.x, lane = tid & 63, q = tid >> 6;
@@ -293,13 +232,12 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
     }
 }
 
-// picks the pointwise kernel for a slab count (ICZ_LSTM_POINT = 1 / 4 / 0 forces the one-unit / four-unit / gate-per-wave kernel)
+// the gate-per-wave kernel wherever the hidden size allows 16-byte accesses (ICZ_LSTM_POINT=1: the one-unit kernel, A/B runs)
 inline void launch_lstm_point(const LstmPointArgs& a, const DropCfg& dc, hipStream_t st) {
     static int force = -1;
     if (force < 0) { const char* e = getenv("ICZ_LSTM_POINT"); force = e ? atoi(e) : 0; }
     const dim3 grid(cdiv(a.H, 256), a.rows);
     if (a.H % 4 != 0 || force == 1) hipLaunchKernelGGL(lstm_point_kernel, grid, dim3(256), 0, st, a, dc);
-    else if (force == 4 && a.nsplit >= lstm4_min_slabs()) hipLaunchKernelGGL(lstm_point4_kernel, grid, dim3(64), 0, st, a, dc);
     else hipLaunchKernelGGL(lstm_point_gw_kernel, grid, dim3(256), 0, st, a, dc);
 }
 
