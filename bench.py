@@ -192,9 +192,35 @@ def aoa_scst(words, device, B):
     run(10)
     torch.cuda.synchronize()
     dt = (_t.perf_counter() - t0) / 10
-    return {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B,
-            "note": "AoADetection_Eng.SCST_training_epoch: refiner x2 (eval + train mode), greedy + sampled rollout, CIDEr-D reward, "
-                    "REINFORCE backward of the decoder, clamp + Adam"}
+    out = {"captions_per_s": B / dt, "ms_per_step": dt * 1e3, "batch": B,
+           "note": "AoADetection_Eng.SCST_training_epoch: refiner x2 (eval + train mode), greedy + sampled rollout, CIDEr-D reward, "
+                   "REINFORCE backward of the decoder, clamp + Adam"}
+    out["roofline"] = aoa_roofline(B)
+    return out
+
+
+def aoa_roofline(B, steps_in_profile=13):
+    """Roofline entry of the AoA step's dominant kernel, from the COMMITTED rocprofv3 summary (profiles/, tools/prof_aoa_engine.sh:
+    13 steps), not from this run: the 128 x 128 split-precision NT GEMM of the refiner (per pass one 2048 -> 1024 projection and
+    six layers of a fused Q/K/V projection 1024 -> 3072 and an AoA linear 2048 -> 2048 over B x 36 rows; two passes per step)."""
+    import csv
+    try:
+        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_aoa_scst_kernel_stats.csv"))))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        k = [r for r in rows if "gemm_tn128_x3_kernel<1, 4, true, true>" in r["Name"]][0]
+        M = B * R
+        flops_step = 2.0 * (2.0 * M * 1024 * 2048 + 6 * (2.0 * M * 3072 * 1024 + 2.0 * M * 2048 * 2048))
+        launches = float(k["Calls"]) / steps_in_profile
+        us = float(k["AverageNs"]) / 1e3
+        tf = flops_step / launches / (us * 1e-6) / 1e12
+        peak = 2500.0 / 6.0
+        return {"kernel": "gemm_tn128_x3_kernel<1,4,true,true> (refiner GEMMs, split precision)", "bound": "mfma", "achieved": tf,
+                "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None, "avg_launch_us": us, "launches_per_step": launches,
+                "share_of_kernel_time": float(k["TotalDurationNs"]) / tot, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS,
+                "source": "profiles/r02_aoa_scst_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/perf_aoa_engine.py at the "
+                          "committed code, NOT this run); peak = 2.5 PFLOP/s bf16 / 6 MFMAs per fp32 product"}
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def cpu_baseline(eng, batch, words, df, rows):

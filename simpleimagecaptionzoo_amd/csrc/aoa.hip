@@ -188,10 +188,25 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     launch_lstm_point(a, off, st);
     hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
-    ICZ_TRY(lin(s.qn, rows, Hd, P.dec.q_w, P.dec.q_b, Hd, s.Qp, st));
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128 + 4);
-    hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
-                       region_rows(), s.d_att);
+    {   // query projection; when it is split over K its slabs go straight to the attention kernel, which sums them
+        GemmArgs qg = {};
+        qg.nseg = 1;
+        qg.seg[0] = {s.qn, P.dec.q_w, Hd, Hd, Hd, nullptr};
+        qg.M = rows; qg.N = Hd; qg.ldo = Hd;
+        qg.nsplit = gemm_fit_split(GEMM_NT, qg, gemm_pick_split(qg, STEP_WGS), ws_floats);
+        if (qg.nsplit == 1) {
+            qg.out = s.Qp; qg.bias = P.dec.q_b;
+            ICZ_TRY(gemm_f32(GEMM_NT, qg, st));
+            hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
+                               region_rows(), s.d_att);
+        } else {
+            qg.out = ws;
+            ICZ_TRY(gemm_f32(GEMM_NT, qg, st));
+            hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, (const float*)ws, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out,
+                               R, Hd, NH, region_rows(), s.d_att, qg.nsplit, (size_t)rows * Hd, (const float*)P.dec.q_b, s.Qp);
+        }
+    }
     GemmArgs zg = {};
     zg.nseg = 2;
     zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};

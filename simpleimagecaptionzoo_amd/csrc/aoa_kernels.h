@@ -352,10 +352,15 @@ __device__ __forceinline__ void aoa_stage_kv(const float* __restrict__ K, const 
 // first two waves owns key r; all four waves stage the image's K / V head tiles (most of the kernel's time: each tile is
 // used by one query only); with region counts only the valid rows are staged and the masked keys get P = 0.
 // Saves P and Pd ([rows, NH, R]) when requested (backward).
+// qns > 1: the query projection arrives as qns split-K slabs in `Qp` (slab z at + z * q_stride, no bias): the workgroup sums
+// its head's d columns in slab order, adds q_bias and leaves the finished values in Qp_store (backward reads them) -- the
+// slab_reduce launch between the projection GEMM and this kernel (40 per SCST step) is gone.
 __global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restrict__ Qp, const float* __restrict__ Kd,
                                                            const float* __restrict__ Vd, const int32_t* __restrict__ img_of_row,
                                                            float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
-                                                           int R, int Hd, int NH, RegionRows rr, DropP dp) {
+                                                           int R, int Hd, int NH, RegionRows rr, DropP dp,
+                                                           int qns = 1, size_t q_stride = 0, const float* __restrict__ q_bias = nullptr,
+                                                           float* __restrict__ Qp_store = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128], red [4]
     const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = Hd / NH, ld = d + 1;
@@ -368,7 +373,16 @@ __global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restri
     const int len = rr.count(img);
     const size_t base = rr.first(img) * Hd + (size_t)hd * d;
     aoa_stage_kv<256>(Kd + base, Vd + base, sk, sv, len, d, Hd, tid);
-    for (int j = tid; j < d; j += 256) sq[j] = Qp[(size_t)row * Hd + (size_t)hd * d + j];
+    for (int j = tid; j < d; j += 256) {
+        const size_t qi = (size_t)row * Hd + (size_t)hd * d + j;
+        float q = Qp[qi];
+        if (qns > 1) {
+            for (int z = 1; z < qns; ++z) q += Qp[(size_t)z * q_stride + qi];
+            q += q_bias[hd * d + j];
+            Qp_store[qi] = q;
+        }
+        sq[j] = q;
+    }
     __syncthreads();
     float s = -INFINITY;
     if (tid < len) {
