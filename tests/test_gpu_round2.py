@@ -571,3 +571,90 @@ def test_beam_topk_with_massive_ties_takes_the_lowest_indices(V):
     # k = 2: tokens 0 and 1 at step 1; at step 2 the two best flat indices are row 0's tokens 0 and 1
     seqs, lens = h.beam_search(feats, 2, 2)
     assert lens.cpu().tolist() == [3, 3, 3] and (seqs[:, :3].cpu() == torch.tensor([1.0, 0, 0])).all()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+def test_fullsize_aoa_scst_step_64x20_matches_oracle():
+    """BASELINE config 5 at the size it is timed on (`secondary.aoa_scst_step`): one whole AoADetection SCST step -- refiner in
+    evaluation and in training mode (all four dropout sites of the six layers injected), greedy and sampled rollout of 64 images x
+    20 steps as the two concurrent chains (`icz_aoa_scst_rollouts`), CIDEr-D reward, REINFORCE loss and the decoder gradients --
+    against the CPU oracle on the same features / parameters / uniforms / keep-masks.  Same excuse rule as the BUTD step above."""
+    from oracle import aoa as oa
+    from oracle import butd as ob
+    from oracle import ciderd as oc
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, make_aoa_rng
+    from simpleimagecaptionzoo_amd.ciderd import CiderDReward
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    B, T, Hd, NH = 64, 20, 1024, 8
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    dfd = document_frequency(synthetic_references(2000, words, seed=0))
+    torch.manual_seed(17)
+    cap = AoADetection_Captioner(V, max_batch=B, max_beam=1).cuda()
+    with torch.no_grad():
+        cap.decoder.predict.weight_g.mul_(6.0)
+        for l in cap.aoa_refine.aoa_layers:          # clones() starts the six layers identical; make them differ
+            for p_ in l.parameters():
+                p_.add_(torch.randn_like(p_) * 0.01)
+    h = cap._handle()
+    g = torch.Generator(device="cpu")
+    g.manual_seed(4321)
+    feats_c = torch.relu(torch.randn(B, R, D, generator=g))
+    feats = feats_c.cuda()
+    rs = np.random.RandomState(5)
+    keep = lambda shape, p: (rs.rand(*shape) >= p)
+    masks = {"proj": keep((B, R, Hd), 0.5), "ref_att": keep((6, B, NH, R, R), 0.1), "ref_aoa": keep((6, B, R, 2 * Hd), 0.3),
+             "ref_sc": keep((6, B, R, Hd), 0.1), "emb": keep((T, B, E), 0.5), "ctx": keep((T, B, Hd), 0.5),
+             "att": keep((T, B, NH, R), 0.1), "out": keep((T, B, Hd), 0.5)}
+    u = rs.rand(T, B).astype(np.float32)
+    dev = "cuda"
+    rng = make_aoa_rng(0, torch.tensor(u, device=dev), {k: torch.tensor(v.astype(np.uint8), device=dev) for k, v in masks.items()})
+    greedy, seq, lp = h.rollouts(feats, T, rng)
+    greedy, seq, lp = greedy.cpu().numpy(), seq.cpu().numpy(), lp.cpu().numpy()
+
+    # ---- oracle (gradients only for the decoder: the only parameters in the reference's optimizer, AoA_Model.py:669-674)
+    p = {k: v.detach().cpu().clone().requires_grad_(k.startswith("decoder.")) for k, v in cap.state_dict().items()}
+    with torch.no_grad():
+        w_greedy, w_glog = oa.greedy(feats_c, p, T)
+    w_seq, w_lp = oa.sample_rl(feats_c, p, u.astype(np.float64), masks, T, early_exit=False)
+    div = _first_divergence(greedy, w_greedy.numpy())
+    excused = 0
+    for b in np.nonzero(div >= 0)[0]:
+        top2 = torch.topk(w_glog[b, div[b]], 2).values
+        assert float(top2[0] - top2[1]) < 1e-4, ("greedy row %d differs at step %d with margin %g" % (b, div[b], float(top2[0] - top2[1])))
+        excused += 1
+    assert excused <= 2, "greedy: %d rows excused" % excused
+    sdiv = _first_divergence(seq, w_seq.numpy())
+    assert (sdiv >= 0).sum() <= 2, "sampled: %d rows differ" % int((sdiv >= 0).sum())
+    for b in np.nonzero(sdiv >= 0)[0]:              # a draw within fp32 rounding of a CDF boundary lands on the neighbouring token
+        assert abs(int(seq[b, sdiv[b]]) - int(w_seq[b, sdiv[b]])) <= 2, (b, seq[b], w_seq[b])
+    ok = sdiv < 0
+    np.testing.assert_allclose(lp[ok], w_lp.detach().numpy()[ok], atol=1e-4)
+
+    # ---- reward: bit-exact on the ids the device produced
+    refs = synthetic_references(B, words, seed=9)
+    gts = {i: refs[i] for i in range(B)}
+    scorer = CiderDReward(dfd["document_frequency"], dfd["ref_len"], vocab.word2ix, dev)
+    reward = scorer.reward(torch.tensor(seq, device=dev), torch.tensor(greedy, device=dev), gts, list(range(B)))
+    w_reward = oc.self_critical_reward(seq, greedy, gts, list(range(B)), dict(enumerate(words)),
+                                       oc.DocFreq(dfd["document_frequency"], dfd["ref_len"]))
+    assert np.array_equal(reward.cpu().numpy(), w_reward)
+
+    # ---- REINFORCE loss and decoder gradients
+    rw = w_reward.copy()
+    rw[~ok] = 0.0
+    rw = rw + rs.randn(B, 1).astype(np.float32) * ok[:, None].astype(np.float32)
+    grads = h.new_grads()
+    loss, msum = h.sample_backward(torch.tensor(rw, device=dev), grads)
+    w_seq_m = torch.from_numpy(np.where(ok[:, None], w_seq.numpy(), seq))
+    w_loss = ob.reward_criterion(w_lp, w_seq_m, torch.from_numpy(rw))
+    w_loss.backward()
+    assert abs(loss.item() - w_loss.item()) < 1e-4, (loss.item(), w_loss.item())
+    for k, gt in grads.items():
+        if k == "decoder.aoa_block.linear_K.bias":
+            continue                                   # identically zero (softmax shift invariance)
+        want = p[k].grad.numpy()
+        scale = max(1e-6, float(np.abs(want).max()))
+        err = float(np.abs(gt.cpu().numpy() - want).max())
+        assert err <= 3e-4 * scale + 1e-7, (k, err, scale)
