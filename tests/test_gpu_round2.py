@@ -658,3 +658,41 @@ def test_fullsize_aoa_scst_step_64x20_matches_oracle():
         scale = max(1e-6, float(np.abs(want).max()))
         err = float(np.abs(gt.cpu().numpy() - want).max())
         assert err <= 3e-4 * scale + 1e-7, (k, err, scale)
+
+
+@pytest.mark.parametrize("regime", ["nat", "end_biased"])
+def test_fullsize_aoa_beam5_matches_oracle(regime):
+    """BASELINE config 5 decodes with beam 5: AoA beam search at full width over 64 images = 320 decoder rows (many-row
+    split-precision GEMMs with split-K over the LSTM's three K segments, register top-k at V = 10102); 4 of the images against
+    the oracle's one-image beam search (AoA_Model.py:403-502), in the natural regime and with <end> competing in mid-sentence."""
+    from oracle import aoa as oa
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner
+    n_img, k, steps = 64, 5, 20
+    torch.manual_seed(23)
+    cap = AoADetection_Captioner(V, max_batch=n_img, max_beam=k).cuda()
+    with torch.no_grad():
+        cap.decoder.predict.weight_g.mul_(6.0)
+    h = cap._handle()
+    feats = torch.relu(torch.randn(n_img, R, D, device="cuda"))
+    imgs = [0, 21, 40, 63]
+    if regime == "end_biased":
+        ids = h.greedy(feats, steps).cpu().numpy()
+        tok = int(np.bincount(ids[ids > 3].ravel()).argmax())
+        with torch.no_grad():
+            cap.decoder.predict.weight_v[2] = cap.decoder.predict.weight_v[tok]
+            cap.decoder.predict.weight_g[2] = cap.decoder.predict.weight_g[tok]
+            cap.decoder.predict.bias[2] = cap.decoder.predict.bias[tok] - 0.2
+        h = cap._handle()                  # refreshes the weight-normed copies
+        early = [i for i in range(n_img) if tok in ids[i, :6]]
+        imgs = (early + imgs)[:4]
+    seqs, lens = h.beam_search(feats, k, steps)
+    seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+    p = {kk: v.detach().cpu().clone() for kk, v in cap.state_dict().items()}
+    finished = 0
+    for i in imgs:
+        want = oa.beam_search(feats[i:i + 1].cpu(), p, k, steps).numpy().ravel()
+        got = seqs[i, :lens[i]]
+        assert got.shape == want.shape and np.array_equal(got, want), (regime, i, got.tolist(), want.tolist())
+        finished += int(want[-1] == 2)
+    if regime == "end_biased":
+        assert finished >= 1
