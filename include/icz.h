@@ -336,13 +336,6 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
                  float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,
                  size_t workspace_floats, void* stream);
 size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
-/* The decoder-step form of the NT GEMM (33..128 rows, K a multiple of 64): the activations' three bf16 pieces come as planes
- * written beside the fp32 tensor by its producer (here: split into `planes`, 3 * M * ldx uint16 of scratch, by a helper
- * kernel first), so the GEMM stages them without re-splitting.  Same results as icz_gemm_f32 on that shape. */
-int icz_gemm_nt_planes(const float* X, int32_t ldx, uint16_t* planes, const float* W, int32_t ldw, const float* bias, float* C,
-                       int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace, size_t workspace_floats,
-                       void* stream);
-
 /* Live timing of the dominant kernel (gemm_nt_kernel<4>: every forward GEMM of the decoder step) with HIP events on
  * its launch stream, for bench.py's roofline line.  Between begin and end every launch is bracketed by an event
  * pair; end synchronises on them and reports the average duration [us] and the ALGORITHMIC bytes / flops per launch

@@ -242,9 +242,8 @@ def make_rng(seed=0, uniforms=None, emb_mask=None, att_mask=None, out_mask=None)
     return r
 
 
-def gemm(layout, X, W, bias=None, nsplit=0, planes=False):
-    """Test/bench entry for icz_gemm_f32.  layout 'nt': X[M,K] W[N,K]; 'nn': X[M,K] W[K,N]; 'tn': X[K,M] W[K,N].
-    planes=True (NT, 33..128 rows): icz_gemm_nt_planes, the decoder-step form with pre-split activations."""
+def gemm(layout, X, W, bias=None, nsplit=0):
+    """Test/bench entry for icz_gemm_f32.  layout 'nt': X[M,K] W[N,K]; 'nn': X[M,K] W[K,N]; 'tn': X[K,M] W[K,N]."""
     code = {"nt": 0, "nn": 1, "tn": 2}[layout]
     if layout == "nt":
         M, K = X.shape
@@ -258,11 +257,6 @@ def gemm(layout, X, W, bias=None, nsplit=0, planes=False):
     out = torch.empty(M, N, device=X.device, dtype=torch.float32)
     ws = torch.empty(max(lib().icz_gemm_workspace_floats(M, N), max(nsplit, 1) * M * N), device=X.device,
                      dtype=torch.float32)
-    if planes:
-        pl = torch.empty(3 * M * X.stride(0), device=X.device, dtype=torch.int16)
-        check(lib().icz_gemm_nt_planes(ptr(X), X.stride(0), ptr(pl), ptr(W), W.stride(0), ptr(bias), ptr(out), N, M, N, K, nsplit, ptr(ws),
-                                       ws.numel(), stream_ptr()))
-        return out
     check(lib().icz_gemm_f32(code, ptr(X), X.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), N, M, N, K,
                              nsplit, ptr(ws), ws.numel(), stream_ptr()))
     return out

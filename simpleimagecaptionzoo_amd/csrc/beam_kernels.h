@@ -279,9 +279,7 @@ __global__ __launch_bounds__(256) void beam_rowtopk_reg_kernel(const float* __re
 // per-row candidates of one beam step: the register kernel where the vocabulary fits it, else the sweep kernel
 inline void launch_beam_rowtopk(hipStream_t st, int rows, const float* logits, int V, int ldl, int k, int step, const int* n_act,
                                 const float* run, float* cand_val, int* cand_idx) {
-    static int use_reg = -1;
-    if (use_reg < 0) { const char* e = getenv("ICZ_BEAM_TOPK_REG"); use_reg = e ? atoi(e) : 1; }
-    const bool ok = use_reg && ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0;
+    const bool ok = ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0;
     if (ok && V <= 1024 * 3) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<3>), dim3(rows), dim3(256), sizeof(float) * 1024 * 3, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
     else if (ok && V <= 1024 * 10) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<10>), dim3(rows), dim3(256), sizeof(float) * 1024 * 10, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
     else hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);

@@ -4,7 +4,6 @@
 #include <vector>
 
 #include "butd_impl.h"
-#include "split3_planes.h"
 
 namespace icz {
 
@@ -411,31 +410,5 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
     return gemm_f32((GemmLayout)layout, g, st);
 }
 
-
-int icz_gemm_nt_planes(const float* X, int32_t ldx, uint16_t* planes, const float* W, int32_t ldw, const float* bias, float* C, int32_t ldc,
-                       int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace, size_t workspace_floats, void* stream) {
-    ICZ_REQUIRE(X && planes && W && C, "icz_gemm_nt_planes: null argument");
-    hipStream_t st = (hipStream_t)stream;
-    Planes pl = {planes, (long long)M * ldx};
-    ICZ_TRY(split3_planes(X, M, K, ldx, pl, st));
-    GemmArgs g = {};
-    g.nseg = 1;
-    g.seg[0] = {X, W, ldx, ldw, K, nullptr, planes, (long long)M * ldx};
-    g.M = M; g.N = N; g.out = C; g.ldo = ldc; g.bias = bias;
-    ICZ_REQUIRE(gemm_skinny_x3_fits(g), "icz_gemm_nt_planes: shape outside the skinny kernel's range (33..128 rows, K %% 64 == 0)");
-    g.nsplit = nsplit > 0 ? nsplit : gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, Butd::STEP_WGS, GEMM_NT), workspace_floats);
-    g.nsplit = gemm_normalize_split(GEMM_NT, g, g.nsplit);
-    if (g.nsplit > 1) {
-        ICZ_REQUIRE(workspace && gemm_slab_floats(M, N, g.nsplit) <= workspace_floats && ldc == N, "icz_gemm_nt_planes: split-K workspace");
-        g.out = workspace; g.bias = nullptr;
-        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
-        const size_t MN = (size_t)M * N;
-        ICZ_REQUIRE(MN % 4 == 0, "icz_gemm_nt_planes: M*N must be a multiple of 4 for the split-K reduce");
-        hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, workspace, g.nsplit, MN, N, bias, C);
-        ICZ_CHECK_HIP(hipGetLastError());
-        return ICZ_OK;
-    }
-    return gemm_f32(GEMM_NT, g, st);
-}
 
 }  // extern "C"

@@ -232,12 +232,10 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
     }
 }
 
-// the gate-per-wave kernel wherever the hidden size allows 16-byte accesses (ICZ_LSTM_POINT=1: the one-unit kernel, A/B runs)
+// the gate-per-wave kernel wherever the hidden size allows 16-byte accesses
 inline void launch_lstm_point(const LstmPointArgs& a, const DropCfg& dc, hipStream_t st) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ICZ_LSTM_POINT"); force = e ? atoi(e) : 0; }
     const dim3 grid(cdiv(a.H, 256), a.rows);
-    if (a.H % 4 != 0 || force == 1) hipLaunchKernelGGL(lstm_point_kernel, grid, dim3(256), 0, st, a, dc);
+    if (a.H % 4 != 0) hipLaunchKernelGGL(lstm_point_kernel, grid, dim3(256), 0, st, a, dc);
     else hipLaunchKernelGGL(lstm_point_gw_kernel, grid, dim3(256), 0, st, a, dc);
 }
 

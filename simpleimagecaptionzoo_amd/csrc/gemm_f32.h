@@ -42,11 +42,6 @@ struct GemmSeg {
     int K;
     // optional row gather for A (NT only): row m of A is A + gather[m]*lda, with ReLU applied on load
     const int64_t* gather;
-    // optional (NT, skinny split-precision kernel): the three bf16 pieces of A, written by A's producer (split3_planes.h):
-    // piece p of element (m, k) at Apl[p * Apl_stride + m * lda + perm(k)], perm = the kernel's k order inside 32-blocks.
-    // All segments of a launch must carry them for the kernel to use them (else it splits A itself).
-    const unsigned short* Apl;
-    long long Apl_stride;
 };
 
 struct GemmArgs {
@@ -73,14 +68,10 @@ int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit);
 // the largest split <= nsplit whose slabs fit the given capacity
 int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capacity_floats);
 
-// gemm_skinny_x3.hip: NT at 33..128 rows with split-precision operands (the decoder-step GEMMs); ICZ_GEMM_SKINNY_X3=0 keeps
-// the fp32-MFMA kernel.  Stage depth 64 (a.chunks_per_split counts 64-deep chunks), column tile 64 or 128.
-bool gemm_skinny_x3_enabled();
-bool gemm_skinny_x3_fits(const GemmArgs& a);
-int gemm_skinny_x3_tile_n(const GemmArgs& a);
-int gemm_skinny_x3(const GemmArgs& a, hipStream_t stream);
-// the LSTM-gate form (activations resident in LDS; see gemm_skinny_x3.hip): fixed decomposition, nsplit = K chunks / 4
+// gemm_resident_x3.hip: NT at 33..64 rows with split-precision operands and the activations of a workgroup's k range resident in
+// LDS (LSTM gates, vocabulary projection, per-step dgrad on transposed weights): fixed decomposition, nsplit = stages / stages per range
 bool gemm_resident_x3_fits(const GemmArgs& a);
+int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup (4 or 3)
 int gemm_resident_x3_nsplit(const GemmArgs& a);
 int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
 // Vocabulary projection of a decoder step: logits[rows, V] = x[rows, H] w_pred^T + bias, w_pred stored [Vp, H] with zero pad rows.
@@ -93,7 +84,10 @@ int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
 int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
                  float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st);
 
-struct Planes;
-int split3_planes(const float* x, int rows, int K, int ld, Planes pl, hipStream_t st);
+// Library switches, read from the environment once at first use (defaults = the product configuration): ICZ_GEMM_TN_X3,
+// ICZ_GEMM_NN_X3, ICZ_GEMM_NT_X3BIG, ICZ_GEMM_RESIDENT_X3 (0: the fp32-input MFMA kernels -- bench.py's fp32_mfma_gemms leg),
+// ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch).
+struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, predict_slabs; unsigned prof_every; };
+const GemmSwitches& gemm_switches();
 
 }  // namespace icz

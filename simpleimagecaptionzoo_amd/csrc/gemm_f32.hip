@@ -325,15 +325,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
 // accumulated in fp32 by v_mfma_f32_32x32x16_bf16: six bf16 MFMAs do the work of sixteen fp32 ones.  The weights stay fp32
 // in memory (same bytes as before) and are split in registers on their way to the matrix pipe (VALU work in the shadow of
 // the MFMAs); the activation tile is split once per stage when it is staged into LDS.  Operands must be finite.
-// MEASURED (round 1), hence opt-in (ICZ_GEMM_X3=1): results stay inside every parity bound of the GPU suite (token-exact
-// decodes, 2e-4 gradients), the matrix work of a 128-deep stage drops from 1.86 to 0.64 us -- and the stage still takes
-// 2.1 us (fp32 kernel: 1.9-2.4): without its MFMAs the kernel runs at 1.3-1.5 us per stage, i.e. the weight stream with one
-// stage of loads in flight per wave is now the limit (6.4 TB/s at best), and the two do not overlap at one wave per SIMD.
-// Three stages in flight (256 VGPRs, ring partly in AGPRs: 2.3-2.9 us) and two workgroups per CU on one LDS buffer (52 KB)
-// were slower or equal in the SCST step: 8.2-8.7 k captions/s against 8.6 k for the fp32 kernel.
-// Workgroup = 64 rows x 64 columns; wave (cg, kh): columns 32 cg .. 32 cg + 31, k half kh of every 128-deep stage; the two
-// k halves meet in LDS at the end.  Operand maps (32x32x16 bf16): lane (r = lane & 31, h = lane >> 5) holds A[row r][8h+j],
-// B[8h+j][col r], j = 0..7;  C: col = lane & 31, row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5).
+// Used by the 128 x 128-tile kernels below (operand reuse: gemm_tn128_x3_kernel) and, in its own translation unit, by the
+// resident-activation decoder-step kernel (gemm_skinny_x3.hip).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -352,233 +345,6 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& p0, uint32_t&
     ra -= __uint_as_float(p1 << 16);
     rb -= __uint_as_float(p1 & 0xffff0000u);
     p2 = cvt_pk_bf16(ra, rb);
-}
-
-constexpr int X3_BK = 128, X3_PB = X3_BK + 8;                   // bf16 elements per staged activation row (272 B: 17 x 16 B)
-#ifndef ICZ_X3_NBUF
-#define ICZ_X3_NBUF 2
-#endif
-constexpr int X3_NBUF = ICZ_X3_NBUF;                            // staging buffers (1: 52 KB, two workgroups per CU)
-constexpr size_t X3_LDS = (size_t)X3_NBUF * 3 * 64 * X3_PB * 2;      // buffers x three planes x 64 rows
-
-__global__ __launch_bounds__(256) void gemm_nt_x3_kernel(GemmArgs a) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char x3_smem[];
-    unsigned short* const planes = reinterpret_cast<unsigned short*>(x3_smem);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int cg = wave & 1, kh = wave >> 1, r = lane & 31, h = lane >> 5;
-    const int n0 = blockIdx.x * 64, m0 = blockIdx.y * 64, z = blockIdx.z;
-    int tot = 0;
-#pragma unroll
-    for (int s = 0; s < GEMM_MAX_SEG; ++s)
-        if (s < a.nseg) tot += a.seg[s].K / X3_BK;
-    const int c_begin = z * a.chunks_per_split;
-    const int c_end = min(tot, c_begin + a.chunks_per_split);
-    const int ncol = n0 + 32 * cg + r;
-    const size_t ncol_c = ncol < a.N ? ncol : a.N - 1;
-
-    f32x16 acc[2];
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 16; ++q) acc[i][q] = 0.f;
-
-    // activation staging: 64 rows x 32 float4 = 8 float4 per thread and stage
-    constexpr int XL = 8;
-    f32x4 xr[XL];
-    size_t xrow[XL];
-    int xkk[XL], xlds[XL];
-#pragma unroll
-    for (int j = 0; j < XL; ++j) {
-        const int idx = tid + 256 * j, row = idx >> 5;
-        int m = m0 + row;
-        if (m > a.M - 1) m = a.M - 1;
-        xrow[j] = (size_t)m;
-        xkk[j] = 4 * (idx & 31);
-        xlds[j] = row * X3_PB + xkk[j];
-    }
-    // two stage cursors: the activation loads run one stage ahead of the MFMAs, the weight loads three (a stage is 0.64 us
-    // of matrix work: one stage of loads in flight does not cover the memory latency)
-    struct Cur { int seg, k0, segK; };
-    Cur cx = {0, 0, 0}, cw = {0, 0, 0};
-    const float* wp = nullptr;
-    const float* xp[XL];
-    auto seek = [&](Cur& c, int stage) {
-        int q = stage;
-        c.seg = 0;
-#pragma unroll
-        for (int s = 0; s < GEMM_MAX_SEG - 1; ++s) {
-            if (c.seg == s && s < a.nseg - 1) {
-                const int nst = a.seg[s].K / X3_BK;
-                if (q >= nst) { q -= nst; c.seg = s + 1; }
-            }
-        }
-        c.k0 = q * X3_BK;
-        c.segK = a.seg[c.seg].K;
-    };
-    auto point_w = [&]() { const GemmSeg& g = a.seg[cw.seg]; wp = g.B + ncol_c * g.ldb + cw.k0 + 64 * kh + 8 * h; };
-    auto point_x = [&]() {
-        const GemmSeg& g = a.seg[cx.seg];
-#pragma unroll
-        for (int j = 0; j < XL; ++j) xp[j] = g.A + xrow[j] * g.lda + cx.k0 + xkk[j];
-    };
-    auto advance_w = [&]() {
-        cw.k0 += X3_BK;
-        if (cw.k0 >= cw.segK && cw.seg < a.nseg - 1) { ++cw.seg; cw.k0 = 0; cw.segK = a.seg[cw.seg].K; point_w(); }
-        else wp += X3_BK;
-    };
-    auto advance_x = [&]() {
-        cx.k0 += X3_BK;
-        if (cx.k0 >= cx.segK && cx.seg < a.nseg - 1) { ++cx.seg; cx.k0 = 0; cx.segK = a.seg[cx.seg].K; point_x(); }
-        else {
-#pragma unroll
-            for (int j = 0; j < XL; ++j) xp[j] += X3_BK;
-        }
-    };
-    auto load_x = [&]() {
-#pragma unroll
-        for (int j = 0; j < XL; ++j) xr[j] = *reinterpret_cast<const f32x4*>(xp[j]);
-    };
-    auto load_w = [&](f32x4 (&w)[4][2]) {
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            w[b][0] = *reinterpret_cast<const f32x4*>(wp + 16 * b);
-            w[b][1] = *reinterpret_cast<const f32x4*>(wp + 16 * b + 4);
-        }
-    };
-    auto store_stage = [&](int buf) {
-        unsigned short* base = planes + (size_t)buf * 3 * 64 * X3_PB;
-#pragma unroll
-        for (int j = 0; j < XL; ++j) {
-            uint32_t a0, a1, a2, b0, b1, b2;
-            split3(xr[j][0], xr[j][1], a0, a1, a2);
-            split3(xr[j][2], xr[j][3], b0, b1, b2);
-            *reinterpret_cast<u32x2*>(base + xlds[j]) = (u32x2){a0, b0};
-            *reinterpret_cast<u32x2*>(base + 64 * X3_PB + xlds[j]) = (u32x2){a1, b1};
-            *reinterpret_cast<u32x2*>(base + 2 * 64 * X3_PB + xlds[j]) = (u32x2){a2, b2};
-        }
-    };
-    // One 128-deep stage of this wave's k half: 4 blocks of 16.  The LDS fragments of block b + 1 are read before the MFMAs
-    // of block b (register double buffer) and, when `wnext` is given, the next stage's weight loads go out one block at a
-    // time between the MFMA groups: issued in one burst at the top of the stage they put 256 x 32 KB on the fabric at once
-    // and then leave it idle while the matrix pipe runs (memory time and MFMA time add up, see gemm_nt_kernel).
-    auto compute = [&](int buf, const f32x4 (&w)[4][2], f32x4 (&wnext)[4][2], bool do_load) {
-        const unsigned short* base = planes + (size_t)buf * 3 * 64 * X3_PB + r * X3_PB + 64 * kh + 8 * h;
-        bf16x8 xf[2][3][2];
-#pragma unroll
-        for (int p = 0; p < 3; ++p)
-#pragma unroll
-            for (int i = 0; i < 2; ++i) xf[0][p][i] = *reinterpret_cast<const bf16x8*>(base + p * 64 * X3_PB + i * 32 * X3_PB);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-            if (b < 3) {
-#pragma unroll
-                for (int p = 0; p < 3; ++p)
-#pragma unroll
-                    for (int i = 0; i < 2; ++i)
-                        xf[(b + 1) & 1][p][i] = *reinterpret_cast<const bf16x8*>(base + p * 64 * X3_PB + i * 32 * X3_PB + 16 * (b + 1));
-            }
-            if (do_load) {
-                wnext[b][0] = *reinterpret_cast<const f32x4*>(wp + 16 * b);
-                wnext[b][1] = *reinterpret_cast<const f32x4*>(wp + 16 * b + 4);
-            }
-            uint32_t s0[4], s1[4], s2[4];
-            split3(w[b][0][0], w[b][0][1], s0[0], s1[0], s2[0]);
-            split3(w[b][0][2], w[b][0][3], s0[1], s1[1], s2[1]);
-            split3(w[b][1][0], w[b][1][1], s0[2], s1[2], s2[2]);
-            split3(w[b][1][2], w[b][1][3], s0[3], s1[3], s2[3]);
-            const u32x4 q0 = {s0[0], s0[1], s0[2], s0[3]}, q1 = {s1[0], s1[1], s1[2], s1[3]}, q2 = {s2[0], s2[1], s2[2], s2[3]};
-            const bf16x8 w0 = __builtin_bit_cast(bf16x8, q0), w1 = __builtin_bit_cast(bf16x8, q1), w2 = __builtin_bit_cast(bf16x8, q2);
-            __builtin_amdgcn_sched_barrier(0);
-            {
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {       // smallest terms first
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][2][i], w0, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w2, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][1][i], w1, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][1][i], w0, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w1, acc[i], 0, 0, 0);
-                    acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(xf[b & 1][0][i], w0, acc[i], 0, 0, 0);
-                }
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-    };
-
-    const int n = c_end - c_begin;
-    // weight register ring of depth WD: stage i multiplies w[i % WD] and loads stage i + WD - 1 into w[(i + WD - 1) % WD].
-    // Depth 4 (three stages ahead) was measured slower than depth 2: at 256 VGPRs the ring lives partly in AGPRs.
-    constexpr int WD = 2;
-    f32x4 w0[4][2], w1[4][2], w2[4][2], w3[4][2];
-    if (n > 0) {
-        seek(cx, c_begin);
-        seek(cw, c_begin);
-        point_x();
-        point_w();
-        load_x();
-        load_w(w0);
-        if (WD == 4) {
-            if (n > 1) { advance_w(); load_w(w1); }
-            if (n > 2) { advance_w(); load_w(w2); }
-        }
-        store_stage(0);
-        __syncthreads();
-        // stage idx: X(idx + 1) is loaded at its top and stored at its end; W(idx + WD - 1) is loaded between its MFMA groups
-        auto stage = [&](int buf, const f32x4 (&wuse)[4][2], f32x4 (&wload)[4][2], int idx) {
-            const bool nx = idx + 1 < n, nw = idx + WD - 1 < n;
-            if (nx) { advance_x(); load_x(); }
-            if (nw) advance_w();
-            __builtin_amdgcn_sched_barrier(0);
-            compute(X3_NBUF == 2 ? buf : 0, wuse, wload, nw);
-            if (X3_NBUF == 1) __syncthreads();
-            if (nx) store_stage(X3_NBUF == 2 ? (buf ^ 1) : 0);
-            __syncthreads();
-        };
-        int i = 0;
-        if (WD == 4) {
-            for (; i + 4 <= n; i += 4) {
-                stage(0, w0, w3, i);
-                stage(1, w1, w0, i + 1);
-                stage(0, w2, w1, i + 2);
-                stage(1, w3, w2, i + 3);
-            }
-            if (i < n) stage(0, w0, w3, i);
-            if (i + 1 < n) stage(1, w1, w0, i + 1);
-            if (i + 2 < n) stage(0, w2, w1, i + 2);
-        } else {
-            for (; i + 2 <= n; i += 2) {
-                stage(0, w0, w1, i);
-                stage(1, w1, w0, i + 1);
-            }
-            if (i < n) stage(0, w0, w1, i);
-        }
-    }
-    // the two k halves meet in LDS (the staging buffers are free now): waves kh = 1 hand their tiles to waves kh = 0
-    __syncthreads();
-    float* red = reinterpret_cast<float*>(x3_smem) + cg * 64 * 32;
-    if (kh == 1) {
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) red[(32 * i + (q & 3) + 8 * (q >> 2) + 4 * h) * 32 + r] = acc[i][q];
-    }
-    __syncthreads();
-    if (kh == 0 && ncol < a.N) {
-        const bool direct = a.nsplit == 1;
-        const float bias = (direct && a.bias) ? a.bias[ncol] : 0.f;
-        float* out = direct ? a.out : a.out + (size_t)z * a.M * a.N;
-        const int ldo = direct ? a.ldo : a.N;
-#pragma unroll
-        for (int i = 0; i < 2; ++i)
-#pragma unroll
-            for (int q = 0; q < 16; ++q) {
-                const int row = 32 * i + (q & 3) + 8 * (q >> 2) + 4 * h, m = m0 + row;
-                if (m < a.M) {
-                    float* o = out + (size_t)m * ldo + ncol;
-                    const float v = acc[i][q] + red[row * 32 + r] + bias;
-                    *o = (direct && a.accumulate) ? (*o + v) : v;
-                }
-            }
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1119,22 +885,31 @@ static void prof_account(const GemmArgs& a) {
 
 size_t gemm_slab_floats(int M, int N, int nsplit) { return nsplit > 1 ? (size_t)nsplit * M * N : 0; }
 
+// Library switches: read from the environment ONCE, at first use.  They exist for bench.py's fp32-MFMA leg and the slab A/B test.
+const GemmSwitches& gemm_switches() {
+    static const GemmSwitches sw = [] {
+        auto on = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; };
+        GemmSwitches s;
+        s.tn_x3 = on("ICZ_GEMM_TN_X3"); s.nn_x3 = on("ICZ_GEMM_NN_X3"); s.nt_x3big = on("ICZ_GEMM_NT_X3BIG");
+        s.resident_x3 = on("ICZ_GEMM_RESIDENT_X3"); s.predict_slabs = on("ICZ_PREDICT_SLABS");
+        const char* e = getenv("ICZ_PROF_EVERY");
+        s.prof_every = e && atoi(e) > 1 ? (unsigned)atoi(e) : 1u;
+        return s;
+    }();
+    return sw;
+}
+
 // NT pipeline-stage depth: 128 when every segment's K is a multiple of 128 and the tile is full height (MT = 4)
 static int nt_stage_k(const GemmArgs& a) {
-    if (gemm_resident_x3_fits(a) || gemm_skinny_x3_fits(a)) return 64;
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ICZ_GEMM_BK"); force = e ? atoi(e) : 0; }
+    if (gemm_resident_x3_fits(a)) return 64;
     if (a.M <= 32) return 64;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return 64;
-    return force == 64 ? 64 : 128;
+    return 128;
 }
 // NN pipeline-stage depth: 128 when every segment's K is a multiple of 128 (halves the barriers and gives the next
 // stage's loads 128 MFMAs per wave to land behind)
 static int nn_stage_k(const GemmArgs& a) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ICZ_GEMM_NN_BK"); force = e ? atoi(e) : 0; }
-    if (force == 64) return 64;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return 64;
     return 128;
@@ -1142,42 +917,19 @@ static int nn_stage_k(const GemmArgs& a) {
 // NN shapes that go to the split-precision 128 x 128-tile kernel: one segment, at least 128 rows and columns, K in whole
 // 128-deep chunks, plain output (ICZ_GEMM_NN_X3=0: the fp32-MFMA kernel)
 static bool nn_x3(const GemmArgs& a) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ICZ_GEMM_NN_X3"); on = e ? atoi(e) : 1; }
-    return on && a.nseg == 1 && a.M >= 128 && a.N >= 128 && a.seg[0].K % 128 == 0 && !a.bias && a.N % 4 == 0;
+    return gemm_switches().nn_x3 && a.nseg == 1 && a.M >= 128 && a.N >= 128 && a.seg[0].K % 128 == 0 && !a.bias && a.N % 4 == 0;
 }
 static int stage_k(GemmLayout layout, const GemmArgs& a) {
     return layout == GEMM_NT ? nt_stage_k(a) : (layout == GEMM_NN ? nn_stage_k(a) : GEMM_BK);
 }
 
-// NT column-tile width: 128 (two 16-column tiles per wave) when that still leaves enough tiles, else 64
-// spread-load variant for the skinny decoder-step GEMMs (see the kernel body); ICZ_GEMM_SPREAD=0 keeps the burst for A/B runs
-static bool nt_spread(const GemmArgs& a) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ICZ_GEMM_SPREAD"); force = e ? atoi(e) : 1; }
-    // measured: -9.5 % at M = 64, -3 % at M = 2304 (refiner / prologue GEMMs), +4 % at M = 320 (beam rows)
-    return force != 0 && (a.M <= 64 || a.M >= 1024);
-}
-// split-precision kernel (gemm_nt_x3_kernel) for the skinny shapes: OFF unless ICZ_GEMM_X3=1 (measured: same results within
-// the parity bounds -- the whole GPU suite passes with it -- but no faster in the SCST step, see the kernel's header);
-// ICZ_GEMM_X3_MAXM widens / narrows the row range
-static bool nt_x3(const GemmArgs& a) {
-    static int on = -1, maxm = 64;
-    if (on < 0) {
-        const char* e = getenv("ICZ_GEMM_X3"); on = e ? atoi(e) : 0;
-        const char* m = getenv("ICZ_GEMM_X3_MAXM"); if (m) maxm = atoi(m);
-    }
-    if (!on || a.M <= 32 || a.M > maxm) return false;
-    for (int s = 0; s < a.nseg; ++s)
-        if (a.seg[s].K % 128) return false;
-    return true;
-}
+// spread-load variant of the fp32 NT kernel (see the kernel body).  Measured: -9.5 % at M = 64, -3 % at M = 2304 (refiner /
+// prologue GEMMs), +4 % at M = 320 (beam rows)
+static bool nt_spread(const GemmArgs& a) { return a.M <= 64 || a.M >= 1024; }
 // NT shapes with many rows (AoA refiner, beam-search steps, prologue hoists) that go to the split-precision 128 x 128-tile
 // kernel: whole 128-deep chunks, enough tiles to fill at least half of the CUs (one K segment may also be split)
 static bool nt_x3big(const GemmArgs& a) {
-    static int on = -1;
-    if (on < 0) { const char* e = getenv("ICZ_GEMM_NT_X3BIG"); on = e ? atoi(e) : 1; }
-    if (!on || a.M < 128 || a.N < 128 || gemm_skinny_x3_fits(a)) return false;
+    if (!gemm_switches().nt_x3big || a.M < 128 || a.N < 128) return false;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return false;
     const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
@@ -1186,25 +938,7 @@ static bool nt_x3big(const GemmArgs& a) {
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / 128;
     return tiles * (tot / 8 > 0 ? tot / 8 : 1) >= 128;
 }
-static int nt_waves(const GemmArgs& a) {
-    static int force = -1;
-    if (force < 0) { const char* e = getenv("ICZ_GEMM_NW"); force = e ? atoi(e) : 0; }
-    if (force != 8) return 4;
-    if (a.M <= 32 || a.N < 1024 || nt_stage_k(a) != 128) return 4;
-    return 8;
-}
-// NT column-tile width: 16 columns per wave; 8-wave workgroups (two waves per SIMD sharing one staged A chunk) -> 128
-// ICZ_GEMM_NTW=2 (development): two 16-column tiles per wave on the 64-row decoder-step shapes -> 128 columns per workgroup,
-// half the activation bytes per weight byte through the L1 path (see gemm_skinny_x3.hip, MEASURED)
-static int nt_ntw(const GemmArgs& a) {
-    static int ntw = -1;
-    if (ntw < 0) { const char* e = getenv("ICZ_GEMM_NTW"); ntw = e ? atoi(e) : 1; }
-    if (ntw != 2 || a.M <= 32 || a.M > 64 || a.N < 2048 || a.N > 8192) return 1;
-    for (int s = 0; s < a.nseg; ++s)
-        if (a.seg[s].K % 128) return 1;
-    return 2;
-}
-static int nt_tile_n(const GemmArgs& a) { return gemm_skinny_x3_fits(a) ? gemm_skinny_x3_tile_n(a) : 16 * nt_waves(a) * nt_ntw(a); }
+static int nt_tile_n(const GemmArgs& a) { return 64; }      // fp32 NT kernel: four waves x one 16-column tile
 
 int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
     if (layout == GEMM_NT && gemm_resident_x3_fits(a)) return gemm_resident_x3_nsplit(a);      // fixed: 256-deep k ranges
@@ -1218,9 +952,7 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
             // compute unit, 96 of the 256 CUs idle): one round of at most 512 workgroups, at least 8 chunks of 128 per split
             int tot = 0;
             for (int sg = 0; sg < a.nseg; ++sg) tot += a.seg[sg].K / 128;
-            static int ms = -1;
-            if (ms < 0) { const char* e = getenv("ICZ_GEMM_NT_X3BIG_MSPLIT"); ms = e ? atoi(e) : 1; }
-            int s = ms ? 512 / (tiles > 0 ? tiles : 1) : 1;
+            int s = 512 / (tiles > 0 ? tiles : 1);
             if (s > tot / 8) s = tot / 8;
             if (s < 1) s = 1;
             return cdiv(tot, cdiv(tot, s));
@@ -1231,9 +963,7 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
         if (s < 1) s = 1;
         return cdiv(tot, cdiv(tot, s));
     }
-    if (X3_NBUF == 1 && layout == GEMM_NT && a.M > 32 && nt_x3(a)) target_wgs *= 2;       // two workgroups of the split-precision kernel per CU
     int tiles = cdiv(a.N, layout == GEMM_NT ? nt_tile_n(a) : GEMM_BN) * cdiv(a.M, GEMM_BM);
-    if (layout == GEMM_NT && gemm_skinny_x3_fits(a)) tiles = cdiv(a.N, nt_tile_n(a));        // one row tile of up to 128 rows
     int tot = total_chunks(a, stage_k(layout, a));
     int s = target_wgs / (tiles > 0 ? tiles : 1);
     if (s < 1) s = 1;
@@ -1342,10 +1072,9 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         const int bn = nt_tile_n(a);
         dim3 grid(cdiv(a.N, bn), cdiv(a.M, mt * 16), a.nsplit);
         hipEvent_t e0 = nullptr, e1 = nullptr;
-        const bool resident = gemm_resident_x3_fits(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == 4;
-        const bool skinny = !resident && gemm_skinny_x3_fits(a);
+        const bool resident = gemm_resident_x3_fits(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == gemm_resident_x3_stages(a);
         // inside a stream capture the two records become event nodes of the graph: every replay refreshes them
-        if (g_prof.on && (g_prof.select == 1 ? resident : (mt == 4 || skinny || resident)) && (g_prof.seen++ % g_prof.every) == 0) {
+        if (g_prof.on && (g_prof.select == 1 ? resident : (mt == 4 || resident)) && (g_prof.seen++ % g_prof.every) == 0) {
             if (g_prof.used + 2 <= g_prof.ev.size()) {
                 e0 = g_prof.ev[g_prof.used]; e1 = g_prof.ev[g_prof.used + 1];
                 g_prof.used += 2;
@@ -1360,25 +1089,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
             if (e1) (void)hipEventRecord(e1, stream);
             return st;
         }
-        if (skinny) {
-            const int st = gemm_skinny_x3(a, stream);
-            if (e1) (void)hipEventRecord(e1, stream);
-            return st;
-        }
-        if (mt == 4 && nt_x3(a)) {
-            static bool attr_done = false;
-            if (!attr_done) {
-                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_nt_x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)X3_LDS));
-                attr_done = true;
-            }
-            hipLaunchKernelGGL(gemm_nt_x3_kernel, grid, block, X3_LDS, stream, a);
-        }
-        else if (mt == 1) ICZ_NT(1, 1, 64);
+        if (mt == 1) ICZ_NT(1, 1, 64);
         else if (mt == 2) ICZ_NT(2, 1, 64);
-        else if (nt_ntw(a) == 2) hipLaunchKernelGGL((gemm_nt_kernel<4, 2, false, 128, 4, false>), grid, block, 0, stream, a);
-        else if (nt_stage_k(a) == 128 && nt_waves(a) == 8) {
-            hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 8>), grid, dim3(512), 0, stream, a);
-        }
         else if (nt_stage_k(a) == 128 && nt_spread(a)) hipLaunchKernelGGL((gemm_nt_kernel<4, 1, false, 128, 4, true>), grid, block, 0, stream, a);
         else if (nt_stage_k(a) == 128) ICZ_NT(4, 1, 128);
         else ICZ_NT(4, 1, 64);
@@ -1386,11 +1098,7 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         if (e1) (void)hipEventRecord(e1, stream);
     } else if (layout == GEMM_NN) {
         dim3 grid(cdiv(a.N, GEMM_BN), cdiv(a.M, GEMM_BM), a.nsplit);
-        {
-            static int sp = -1;
-            if (sp < 0) { const char* e = getenv("ICZ_GEMM_NN_SPREAD"); sp = e ? atoi(e) : 1; }
-            a.spread = sp;
-        }
+        a.spread = 1;
         if (nn_x3(a)) {      // batched dgrad GEMMs (all time steps at once): split-precision 128 x 128 tiles
             static bool attr = false;
             if (!attr) {
@@ -1406,28 +1114,23 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
         else if (tail) hipLaunchKernelGGL(gemm_nn_kernel<true>, grid, block, 0, stream, a);
         else hipLaunchKernelGGL(gemm_nn_kernel<false>, grid, block, 0, stream, a);
     } else {
-        static int big = -1;
-        if (big < 0) { const char* e = getenv("ICZ_GEMM_TN128"); big = e ? atoi(e) : 1; }
         // at least one 128 x 128 tile per CU, else the 64 x 64 kernel (4x the workgroups) fills the chip better
-        if (big && a.nsplit == 1 && a.nseg == 1 && cdiv(a.M, 128) * cdiv(a.N, 128) >= 256 && a.seg[0].K % 32 == 0 && a.seg[0].K >= 64) {
-            static int x3 = -1;
-            if (x3 < 0) {
-                const char* e = getenv("ICZ_GEMM_TN_X3"); x3 = e ? atoi(e) : 2;       // 0: fp32-MFMA kernel; 1 / 2 / 3: variants of the split-precision one
-                if (x3) {
-                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));
-                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
-                    ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
-                }
+        if (a.nsplit == 1 && a.nseg == 1 && cdiv(a.M, 128) * cdiv(a.N, 128) >= 256 && a.seg[0].K % 32 == 0 && a.seg[0].K >= 64) {
+            const bool x3 = gemm_switches().tn_x3;        // off: the fp32-MFMA kernel
+            static bool attr = false;
+            if (x3 && !attr) {
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<1, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(1)));
+                ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_tn128_x3_kernel<2, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)t3_lds(2)));
+                attr = true;
             }
             const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), 1);
             const int tiles = (int)(g128.x * g128.y);
-            if (x3 == 0) hipLaunchKernelGGL(gemm_tn128_kernel, g128, block, 0, stream, a);
+            if (!x3) hipLaunchKernelGGL(gemm_tn128_kernel, g128, block, 0, stream, a);
             // measured (4096 x {1024, 3072, 4096} x 1280, 10112 x 1024 x 1280): more than one round of tiles -> one LDS buffer and
             // two workgroups per CU (251 us / 171 TFLOP/s-equivalent at 4096 x 4096 against 369 us for the fp32 kernel); one
             // round -> two buffers and eight waves (73 against 100 us at 4096 x 1024)
-            else if (tiles > 256 && x3 != 3) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4>), g128, block, t3_lds(1), stream, a);
-            else if (x3 == 2 || x3 == 3) hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8>), g128, dim3(512), t3_lds(2), stream, a);
-            else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 4>), g128, block, t3_lds(2), stream, a);
+            else if (tiles > 256) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4>), g128, block, t3_lds(1), stream, a);
+            else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8>), g128, dim3(512), t3_lds(2), stream, a);
             ICZ_CHECK_HIP(hipGetLastError());
             return ICZ_OK;
         }
@@ -1445,7 +1148,7 @@ void gemm_prof_begin() {
     g_prof.on = true; g_prof.used = 0; g_prof.bytes = 0.0; g_prof.flops = 0.0; g_prof.seen = 0;
     // the whole pool is created here: events cannot be created while a stream capture is in progress
     while (g_prof.ev.size() < 8192) { hipEvent_t e; if (hipEventCreate(&e) != hipSuccess) break; g_prof.ev.push_back(e); }
-    { const char* e = getenv("ICZ_PROF_EVERY"); g_prof.every = e ? (unsigned)atoi(e) : 1; if (g_prof.every < 1) g_prof.every = 1; }
+    g_prof.every = gemm_switches().prof_every;
 }
 int gemm_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches) {
     g_prof.on = false;

@@ -2,7 +2,7 @@
 # usage: tools/prof_any.sh <tag> <python script and args...>  -> gpurun_out/prof_r02/<tag>_kernel_stats.csv + top kernels on stdout
 tag=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r02
+OUT=$ROOT/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_$tag
