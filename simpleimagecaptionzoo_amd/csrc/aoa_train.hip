@@ -325,7 +325,7 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
             a.emb_table = P.embed_weight; a.emb_next = temb + (slot + B) * dims.E; a.E = dims.E;
             a.emb_drop = dropbits(true, rng.emb_mask, (slot + B) * dims.E, RNG_EMB, t + 1);
         }
-        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
+        launch_sample_select(st, B, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;

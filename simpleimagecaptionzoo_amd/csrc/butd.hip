@@ -104,6 +104,39 @@ int Butd::refresh(hipStream_t st) {
     hipLaunchKernelGGL(weight_norm_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
     ICZ_CHECK_HIP(hipGetLastError());
     fresh = true;
+    wt_fresh = false;
+    if (wt_lm_ih) ICZ_TRY(refresh_transposes(st));
+    return ICZ_OK;
+}
+
+// the transposed copies serve 33..64-row dgrad steps through gemm_resident_x3: K = 4H in whole k ranges, N = D + H / H wide enough
+bool Butd::wt_possible() const {
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0] = {w_enc, w_enc, 4 * dims.H, 4 * dims.H, 4 * dims.H, nullptr};     // placeholders: only the shape is looked at
+    g.M = 64; g.N = dims.D + dims.H;
+    GemmArgs p = g, q = g;
+    p.N = q.N = dims.H;
+    p.nseg = 2; p.seg[1] = p.seg[0];
+    return dims.H % 64 == 0 && dims.D % 64 == 0 && gemm_resident_x3_fits(g) && gemm_resident_x3_pair_fits(p, q);
+}
+
+int Butd::refresh_transposes(hipStream_t st) {
+    ICZ_REQUIRE(bound && wt_lm_ih, "butd: no transposed weight buffers");
+    const int H = dims.H, D = dims.D, E = dims.E;
+    TransposeTable tt = {};
+    int nb = 0;
+    auto add = [&](const float* src, int ld, int cols, float* dst) {
+        tt.j[tt.count++] = {src, ld, 4 * H, cols, dst, nb};
+        nb += (4 * H / 64) * (cols / 64);
+    };
+    add(P.lm_w_ih, D + H, D + H, wt_lm_ih);
+    add(P.lm_w_hh, H, H, wt_lm_hh);
+    add(P.td_w_ih, H + D + E, H, wt_td_ih_h2);          // the h2 columns only: mean features and embedding have no recurrent gradient
+    add(P.td_w_hh, H, H, wt_td_hh);
+    hipLaunchKernelGGL(transpose_multi_kernel, dim3(nb), dim3(256), 0, st, tt);
+    ICZ_CHECK_HIP(hipGetLastError());
+    wt_fresh = true;
     return ICZ_OK;
 }
 

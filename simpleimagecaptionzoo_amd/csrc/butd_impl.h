@@ -89,6 +89,13 @@ struct Butd {
     float* d_msum_global = nullptr;      // data-parallel loss normaliser (0 = use the local one)
     float* ws = nullptr;
     size_t ws_floats = 0;
+    // Transposed copies of the LSTM weights: the per-step dgrad products of BPTT, dx = dy W, run as NT products on W^T through the
+    // resident-activation kernel (weights streamed once, split-precision MFMA) instead of the fp32 NN kernel.  Allocated with the
+    // first training buffers where the sizes fit that kernel, refreshed once per optimiser step (refresh / first backward after it).
+    float *wt_lm_ih = nullptr, *wt_lm_hh = nullptr, *wt_td_ih_h2 = nullptr, *wt_td_hh = nullptr;
+    bool wt_fresh = false;
+    bool wt_possible() const;
+    int refresh_transposes(hipStream_t st);
 
     ~Butd();
     int alloc(void** p, size_t bytes);

@@ -629,6 +629,36 @@ __global__ void set_scalars_kernel(uint64_t* seed_p, uint64_t seed, float* f_p, 
     if (f_p) *f_p = f;
 }
 
+// dst[c][r] = src[r * ld + c] for up to four matrices in one launch (rows, cols multiples of 64; dst row stride = rows): the
+// transposed LSTM weight copies behind the per-step dgrad GEMMs of BPTT, refreshed once per optimiser step.
+struct TransposeJob { const float* src; int ld, rows, cols; float* dst; int block0; };
+struct TransposeTable { TransposeJob j[4]; int count; };
+__global__ __launch_bounds__(256) void transpose_multi_kernel(TransposeTable tab) {
+    __shared__ float tile[64][65];
+    int ji = 0;
+    for (int k = 1; k < tab.count; ++k) if ((int)blockIdx.x >= tab.j[k].block0) ji = k;
+    const TransposeJob& jb = tab.j[ji];
+    const int b = blockIdx.x - jb.block0, ntc = jb.cols / 64;
+    const int r0 = (b / ntc) * 64, c0 = (b % ntc) * 64;
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int r = ty + 16 * i;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(jb.src + (size_t)(r0 + r) * jb.ld + c0 + 4 * tx);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) tile[r][4 * tx + e] = v[e];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int c = ty + 16 * i;
+        f32x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = tile[4 * tx + e][c];
+        *reinterpret_cast<f32x4*>(jb.dst + (size_t)(c0 + c) * jb.rows + r0 + 4 * tx) = v;
+    }
+}
+
 // zero up to 8 float buffers of n floats each (n % 4 == 0) in one launch (recurrent-state resets)
 struct ZeroList { float* p[8]; int count; };
 __global__ __launch_bounds__(256) void zero_bufs_kernel(ZeroList z, size_t n) {
@@ -704,7 +734,7 @@ struct SampleSelArgs {
     // sums them in slab order, adds bias[v] and leaves the finished row in logits_store (the saved logits of backward)
     int ns; size_t slab_stride; const float* bias; float* logits_store;
 };
-constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS, every pass is LDS-bound
+constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS
 __device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
     v = wave_max(v);
     if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = v;
@@ -822,15 +852,25 @@ inline int ss_select_launch(hipStream_t st, int rows, const float* logits_prev, 
     hipLaunchKernelGGL(ss_select_kernel, dim3(rows), dim3(SEL_THREADS), sizeof(float) * V, st, sa);
     return ICZ_OK;
 }
+// One workgroup of 16 waves per row.  Passes: (1) finished logits x = sum of the predict GEMM's split-K slabs + bias -> LDS (and
+// the saved-logits slot of backward), row maximum M; (2) every thread takes a contiguous slice of the row: float64 sum of
+// q_v = exp(x_v - M), block scan -> total and the slice's prefix; (3) the thread whose slice crosses u * total walks it again
+// (q recomputed: the same float expression) and reports the first index above the target.  The distribution is softmax(x) as in
+// the reference; against exp(log_softmax(x)) rounded to float32 first (round 2's form: two more passes over the row) a CDF edge
+// moves by ~1e-7 relative, so a draw differs only when u * total lies that close to an edge (the tests' criterion: within 1e-6).
+// MEASURED (round 3, same box): a two-launch form over the whole chip (rows x 16 slice workgroups for the sums, then one small
+// workgroup per row for the draw: 7.9 + 8.1 us against 15.4 us for round 2's kernel) made the SCST rollouts SLOWER, 2.83 -> 3.09 ms:
+// the sampled chain runs beside the greedy chain, and a launch that fills every CU stalls the other chain's kernels, while this
+// one leaves three quarters of the chip to them.
 __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the row, then its probabilities
+    extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the finished logits of the row
     __shared__ float smf[16];
     __shared__ double smd[16];
     __shared__ int smi[16];
     constexpr int NW = SEL_THREADS / 64;
-    const int row = blockIdx.x, tid = threadIdx.x;
-    const bool dead = (a.t > 0) && (a.n_unfinished[a.t - 1] == 0);
-    if (dead) {
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
+    if (a.t > 0 && a.n_unfinished[a.t - 1] == 0) {          // every row has finished: zeros, as the reference's early break leaves them (:233)
         if (tid == 0) {
             a.seq_out[(size_t)row * a.T + a.t] = 0;
             a.logp_out[(size_t)row * a.T + a.t] = 0.f;
@@ -838,8 +878,7 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
             a.draw_out[row] = -1;
             a.lse_out[row] = 0.f;
         }
-        if (a.emb_next) {           // token 0 (<pad>), as embed_kernel would produce for it_next = 0
-            const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
+        if (a.emb_next)             // token 0 (<pad>), as embed_kernel would produce for it_next = 0
             for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
                 f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + e);
                 const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
@@ -847,11 +886,12 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
                 for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
                 *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
             }
-        }
         return;
     }
     const float* l = a.logits + (size_t)row * a.ldl;
-    // one coalesced pass over HBM/L2; every later pass (any access pattern) runs out of LDS
+    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
+    const bool was_unf = a.unfinished[row] != 0;             // loaded early: the tail below is a chain of dependent accesses
+    // pass 1: one coalesced pass over HBM / L2; every later pass runs out of LDS
     float mx = -INFINITY;
     if (a.ns > 1) {
         float* ls = a.logits_store + (size_t)row * a.ldl;
@@ -876,38 +916,63 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
     }
     mx = block_max_n(mx, smf, NW);
-    float se = 0.f;
-    for (int v = tid; v < a.V; v += SEL_THREADS) se += expf(srow[v] - mx);
-    se = block_sum_n(se, smf, NW);
-    const float lse = logf(se);
-    for (int v = tid; v < a.V; v += SEL_THREADS) srow[v] = expf((srow[v] - mx) - lse);     // p = exp(log_softmax)
-    __syncthreads();
-    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
-    const int drawn = block_inverse_cdf(srow, a.V, u, smd, smi);
-    if (tid == 0) {
-        const int d = drawn;
-        float ld = l[d];
-        if (a.ns > 1) {          // the same sum, in the same order, as the pass above
-            for (int z = 1; z < a.ns; ++z) ld += l[(size_t)z * a.slab_stride + d];
-            ld += a.bias[d];
-        }
-        const float lp = (ld - mx) - lse;
-        bool unf = a.unfinished[row] != 0;
-        unf = unf && (d != 2);
-        a.unfinished[row] = unf ? 1 : 0;
-        const int64_t itv = unf ? (int64_t)d : 0;
-        a.seq_out[(size_t)row * a.T + a.t] = itv;
-        a.logp_out[(size_t)row * a.T + a.t] = lp;
-        a.it_next[row] = itv;
-        a.draw_out[row] = d;
-        a.lse_out[row] = mx + lse;
-        if (unf) atomicAdd(&a.n_unfinished[a.t], 1);
-        smi[0] = (int)itv;
+    // pass 2: contiguous slice per thread -> the first index above the target is the minimum over threads
+    const int per = (a.V + SEL_THREADS - 1) / SEL_THREADS;
+    const int v0 = min(a.V, tid * per), v1 = min(a.V, v0 + per);
+    double loc = 0.0;
+    for (int v = v0; v < v1; ++v) loc += (double)expf(srow[v] - mx);
+    double inc = loc;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const double up = __shfl_up(inc, o, 64);
+        if (lane >= o) inc += up;
     }
-    if (a.emb_next) {
-        __syncthreads();
-        const int tok = smi[0];
-        const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
+    if (lane == 63) smd[wave] = inc;
+    __syncthreads();
+    double wave_off = 0.0, total = 0.0;
+#pragma unroll
+    for (int w = 0; w < NW; ++w) {
+        const double t = smd[w];
+        if (w < wave) wave_off += t;
+        total += t;
+    }
+    const double target = (double)u * total;
+    // pass 3: only the slice that crosses the target is walked again
+    int cand = 0x7fffffff;
+    {
+        double run = wave_off + inc - loc;               // cumulative sum before the slice; run + loc after it (the scan's values)
+        if (run <= target && run + loc > target) {
+            cand = v1 - 1;                               // the slice's last element carries the scan's own cumulative value
+            for (int v = v0; v < v1 - 1; ++v) {
+                run += (double)expf(srow[v] - mx);
+                if (run > target) { cand = v; break; }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+    if (lane == 0) smi[wave] = cand;
+    __syncthreads();
+    int tok = 0;
+    {
+        int d = smi[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) d = min(d, smi[w]);
+        if (d > a.V - 1) d = a.V - 1;                // rounding at u -> 1: the last token
+        const bool unf = was_unf && (d != 2);
+        tok = unf ? d : 0;
+        if (tid == 0) {
+            const float lse = logf((float)total);
+            a.unfinished[row] = unf ? 1 : 0;
+            a.seq_out[(size_t)row * a.T + a.t] = tok;
+            a.logp_out[(size_t)row * a.T + a.t] = (srow[d] - mx) - lse;
+            a.it_next[row] = tok;
+            a.draw_out[row] = d;
+            a.lse_out[row] = mx + lse;
+            if (unf) atomicAdd(&a.n_unfinished[a.t], 1);
+        }
+    }
+    if (a.emb_next)
         for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
             f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + (size_t)tok * a.E + e);
             const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
@@ -915,7 +980,9 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
             for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
             *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
         }
-    }
+}
+inline void launch_sample_select(hipStream_t st, int rows, const SampleSelArgs& a) {
+    hipLaunchKernelGGL(sample_select_kernel, dim3(rows), dim3(SEL_THREADS), sizeof(float) * a.V, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1083,51 +1150,52 @@ __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, Drop
 // time steps, so its gradient is a sum over t: accumulating it step by step would read-modify-write R*A floats per row
 // and step; instead the steps only record ds_t (R floats per row) and the sum over t is formed once, in registers.
 
-// dctx = sum of slabs [ns][rows][ldc] columns 0..D (the LM-LSTM dgrad GEMM output).  Grid (rows, parts), 256 threads.
+// dctx = sum of slabs [ns][rows][ldc] columns 0..D (the LM-LSTM dgrad GEMM output).  Grid (rows, parts = ceil(D / 512)), 256 threads:
+// a workgroup sums the slabs of ITS 512 columns only (with 16 slabs per step the slab sum is as many bytes as the features: every
+// part summing the whole row, as before round 3, quadrupled it) and emits partial dot products dalpha_part[row][part][r] over
+// those columns for all regions; att_bwd_ddec_kernel adds the parts in order.  Wave w takes regions w, w + 4, ...: two 16-byte
+// feature loads per lane and region, all of a wave's loads independent.
+constexpr int DALPHA_COLS = 512;
 __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __restrict__ dctx, int ns, int ldc, int rows,
                                                              const float* __restrict__ feats, int R, int D,
-                                                             float* __restrict__ dalpha) {
-    extern __shared__ __attribute__((aligned(16))) float sd[];      // D floats
+                                                             float* __restrict__ dalpha_part) {
+    __shared__ __attribute__((aligned(16))) float sd[DALPHA_COLS];
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int c0 = part * DALPHA_COLS;
     const size_t ss = (size_t)rows * ldc;
-    for (int c = tid * 4; c < D; c += 1024)
-        *reinterpret_cast<f32x4*>(sd + c) = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+    if (tid < DALPHA_COLS / 4) {
+        const int c = c0 + 4 * tid;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) v = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+        *reinterpret_cast<f32x4*>(sd + 4 * tid) = v;
+    }
+    constexpr int NR = 5;                         // regions per wave and pass (R <= 64: at most 16 per wave)
+    const int ca = c0 + 4 * lane, cb = ca + 256;
+    const bool va = ca < D, vb = cb < D;
+    const float* frow = feats + (size_t)row * R * D;
+    f32x4 xa[NR], xb[NR];
+    auto load_pass = [&](int r0) {                // clamped: a pass past the last region re-reads it and is not stored
+#pragma unroll
+        for (int u = 0; u < NR; ++u) {
+            const int r = min(r0 + 4 * u, R - 1);
+            xa[u] = *reinterpret_cast<const f32x4*>(frow + (size_t)r * D + (va ? ca : 0));
+            xb[u] = *reinterpret_cast<const f32x4*>(frow + (size_t)r * D + (vb ? cb : 0));
+        }
+    };
+    load_pass(wave);                              // in flight behind the slab sum
     __syncthreads();
-    constexpr int NB = 2, NU = 8;          // 2 regions x 8 float4 per lane in flight
-    for (int i0 = wave; part + nparts * i0 < R; i0 += 4 * NB) {
-        int rr[NB];
-        bool ok[NB];
-        const float* f[NB];
-        float acc[NB];
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(sd + 4 * lane), gb = *reinterpret_cast<const f32x4*>(sd + 256 + 4 * lane);
+    for (int r0 = wave; r0 < R; r0 += 4 * NR) {
+        if (r0 != wave) load_pass(r0);
 #pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const int r = part + nparts * (i0 + 4 * b);
-            ok[b] = r < R;
-            rr[b] = ok[b] ? r : part + nparts * i0;
-            f[b] = feats + ((size_t)row * R + rr[b]) * D;
-            acc[b] = 0.f;
-        }
-        for (int c0 = lane * 4; c0 < D; c0 += 256 * NU) {
-            f32x4 x[NB][NU];
-#pragma unroll
-            for (int b = 0; b < NB; ++b)
-#pragma unroll
-                for (int u = 0; u < NU; ++u) x[b][u] = *reinterpret_cast<const f32x4*>(f[b] + min(c0 + 256 * u, D - 4));
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const int c = c0 + 256 * u;
-                if (c < D) {
-                    const f32x4 g = *reinterpret_cast<const f32x4*>(sd + c);
-#pragma unroll
-                    for (int b = 0; b < NB; ++b) acc[b] += x[b][u][0] * g[0] + x[b][u][1] * g[1] + x[b][u][2] * g[2] + x[b][u][3] * g[3];
-                }
-            }
-        }
-#pragma unroll
-        for (int b = 0; b < NB; ++b) {
-            const float v = wave_sum(acc[b]);
-            if (lane == 0 && ok[b]) dalpha[(size_t)row * R + rr[b]] = v;
+        for (int u = 0; u < NR; ++u) {
+            float acc = 0.f;
+            if (va) acc += xa[u][0] * ga[0] + xa[u][1] * ga[1] + xa[u][2] * ga[2] + xa[u][3] * ga[3];
+            if (vb) acc += xb[u][0] * gb[0] + xb[u][1] * gb[1] + xb[u][2] * gb[2] + xb[u][3] * gb[3];
+            acc = wave_sum(acc);
+            const int r = r0 + 4 * u;
+            if (lane == 0 && r < R) dalpha_part[((size_t)row * nparts + part) * R + r] = acc;
         }
     }
 }
@@ -1135,16 +1203,18 @@ __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __rest
 // Grid (rows, A/256), 256 threads: thread (wq = wave, cg) sums regions wq, wq+4, ... for 4 consecutive attention columns;
 // the four waves meet in LDS.  ds_out (block y = 0) keeps ds for att_bwd_denc_kernel.
 struct AttBwdDdecArgs {
-    const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha; const float* dalpha;
+    const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha; const float* dalpha;   // dalpha: [rows][nparts][R] partials
     float* ddec; float* ds_out;
-    int R, A;
+    int R, A, nparts;
 };
 __global__ __launch_bounds__(256) void att_bwd_ddec_kernel(AttBwdDdecArgs a, DropCfg dc) {
     __shared__ float sds[64];
     __shared__ __attribute__((aligned(16))) float spart[3 * 64 * 4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
     const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
-    const float da = lane < a.R ? a.dalpha[(size_t)row * a.R + lane] : 0.f;
+    float da = 0.f;
+    if (lane < a.R)
+        for (int p = 0; p < a.nparts; ++p) da += a.dalpha[((size_t)row * a.nparts + p) * a.R + lane];
     const float dot = wave_sum(al * da);
     const float ds_l = al * (da - dot);
     if (tid < 64) {

@@ -34,6 +34,14 @@ int Butd::ensure_train(int B, int T) {
         tb = TrainBuf();
         mode = 0;
     }
+    if (!wt_lm_ih && wt_possible()) {      // permanent (not re-allocated when the training buffers grow)
+        const size_t G4 = 4 * (size_t)dims.H;
+        ICZ_TRY(alloc((void**)&wt_lm_ih, sizeof(float) * G4 * (dims.D + dims.H)));
+        ICZ_TRY(alloc((void**)&wt_lm_hh, sizeof(float) * G4 * dims.H));
+        ICZ_TRY(alloc((void**)&wt_td_ih_h2, sizeof(float) * G4 * dims.H));
+        ICZ_TRY(alloc((void**)&wt_td_hh, sizeof(float) * G4 * dims.H));
+        wt_fresh = false;
+    }
     struct Scope { bool& f; Scope(bool& x) : f(x) { f = true; } ~Scope() { f = false; } } scope(alloc_train);
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
     const size_t Vp = round4(dims.V);
@@ -69,7 +77,7 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dH2d, sizeof(float) * TB * H));
     ICZ_TRY(zalloc((void**)&tb.dEnc, sizeof(float) * (size_t)B * R * A));
     ICZ_TRY(zalloc((void**)&tb.dwaff, sizeof(float) * (size_t)B * ATT_PARTS * A));
-    ICZ_TRY(zalloc((void**)&tb.dalpha, sizeof(float) * (size_t)B * R));
+    ICZ_TRY(zalloc((void**)&tb.dalpha, sizeof(float) * (size_t)B * R * cdiv((int)D, DALPHA_COLS)));
     ICZ_TRY(zalloc((void**)&tb.dS, sizeof(float) * TB * R));
     ICZ_TRY(zalloc((void**)&tb.dGsum, sizeof(float) * (size_t)B * 4 * H));
     for (int i = 0; i < 2; ++i) {
@@ -216,7 +224,7 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
             a.emb_table = P.embed_weight; a.emb_next = tb.emb + (size_t)(t + 1) * B * dims.E; a.E = dims.E;
             a.emb_drop = make_drop(d_seed, true, rng.emb_mask, (size_t)B * dims.E, RNG_EMB, t + 1);
         }
-        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
+        launch_sample_select(st, B, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
@@ -240,6 +248,7 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     if (mask_sum_global >= 0.f)      // < 0: keep the device value set by icz_butd_set_mask_sum_global
         hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
     mode = 0;   // the saved logits are consumed
+    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));      // outside the captured graph
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
     // the DP hook must fire on every call (a replayed graph would not call it): backward is enqueued eagerly then
     if (explicit_rng || !use_graphs || grad_cb) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
@@ -359,6 +368,7 @@ int Butd::xe_backward_dlogits(const float* dpacked, const icz_butd_params* G, hi
                        tb.scalars_i + T, T, tb.logit);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
     return bptt(*G, st);
 }
 
@@ -377,6 +387,7 @@ int Butd::sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hi
                        tb.draw, tb.lse, tb.coef, B, T);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
     return bptt(*G, st);
 }
 
@@ -398,6 +409,7 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
     return bptt(*G, st);
 }
 
@@ -502,7 +514,17 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             a.rows = bt; a.H = H;
             hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_out);
         }
-        {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
+        // 33 .. 64 rows: the per-step dgrad products as NT products on the transposed weight copies (resident-activation kernel)
+        const bool rdg = wt_lm_ih && wt_fresh && bt > 32 && bt <= 64;
+        if (rdg) {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
+            GemmArgs g = {};
+            g.nseg = 1;
+            g.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_ih, 4 * H, 4 * H, 4 * H, nullptr};
+            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H;
+            g.nsplit = ns1 = gemm_resident_x3_nsplit(g);
+            ICZ_REQUIRE(gemm_slab_floats(bt, D + H, ns1) <= tb.xfloats, "butd: slab buffer too small for the dgrad slabs");
+            ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        } else {
             GemmArgs g = {};
             g.nseg = 1;
             g.seg[0] = {tb.dGlm + slot * 4 * H, P.lm_w_ih, 4 * H, D + H, 4 * H, nullptr};
@@ -510,9 +532,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
         }
         {   // attention backward
-            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, ATT_PARTS), dim3(256), sizeof(float) * D, st, tb.X[0], ns1, D + H, bt, feats, R, D,
-                               tb.dalpha);
-            AttBwdDdecArgs da = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dDec + slot * A, tb.dS + slot * R, R, A};
+            const int dparts = cdiv(D, DALPHA_COLS);
+            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, dparts), dim3(256), 0, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
+            AttBwdDdecArgs da = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dDec + slot * A, tb.dS + slot * R, R, A, dparts};
             hipLaunchKernelGGL(att_bwd_ddec_kernel, dim3(bt, cdiv(A, 256)), dim3(256), 0, st, da, d_att);
             // X2 = dDec . w_dec   [bt, H]
             GemmArgs g = {};
@@ -533,7 +555,19 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
             a.rows = bt; a.H = H;
             hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_off);
         }
-        if (t > 0) {
+        if (t > 0 && rdg) {   // d h2_{t-1} (X3) and d h1_{t-1} (X4) in one launch
+            GemmArgs g3 = {}, g4 = {};
+            g3.nseg = 2;
+            g3.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_hh, 4 * H, 4 * H, 4 * H, nullptr};
+            g3.seg[1] = {tb.dGtd + slot * 4 * H, wt_td_ih_h2, 4 * H, 4 * H, 4 * H, nullptr};
+            g3.M = bt; g3.N = H; g3.out = tb.X[2]; g3.ldo = H;
+            g4.nseg = 1;
+            g4.seg[0] = {tb.dGtd + slot * 4 * H, wt_td_hh, 4 * H, 4 * H, 4 * H, nullptr};
+            g4.M = bt; g4.N = H; g4.out = tb.X[3]; g4.ldo = H;
+            ns3 = gemm_resident_x3_nsplit(g3); ns4 = gemm_resident_x3_nsplit(g4);
+            ICZ_REQUIRE(gemm_slab_floats(bt, H, ns3) <= tb.xfloats, "butd: slab buffer too small for the dgrad slabs");
+            ICZ_TRY(gemm_resident_x3_pair(g3, g4, st));
+        } else if (t > 0) {
             {   // X3 = dG_lm . W_hh_lm + dG_td . W_ih_td[:, :H]   -> d h2_{t-1}
                 GemmArgs g = {};
                 g.nseg = 2;

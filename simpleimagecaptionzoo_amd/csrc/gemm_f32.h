@@ -74,6 +74,10 @@ bool gemm_resident_x3_fits(const GemmArgs& a);
 int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup (4 or 3)
 int gemm_resident_x3_nsplit(const GemmArgs& a);
 int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
+// two independent problems (each in the kernel's four-stage decomposition, N >= 512) as ONE launch; slabs [nsplit][M][N] go to each
+// problem's `out`, nsplit = gemm_resident_x3_nsplit (the two recurrent dgrad products of a BPTT step)
+bool gemm_resident_x3_pair_fits(const GemmArgs& a, const GemmArgs& b);
+int gemm_resident_x3_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stream);
 // Vocabulary projection of a decoder step: logits[rows, V] = x[rows, H] w_pred^T + bias, w_pred stored [Vp, H] with zero pad rows.
 // At 33 - 64 rows the un-split GEMM is V / 64 workgroups that each re-read the whole activation matrix (as many bytes as their
 // weights: 25 us for 41 MB at V = 10102); the resident-activation kernel over the padded vocabulary takes 256 columns and a

@@ -35,8 +35,7 @@
 //     2.7 k: a compute unit's memory pipeline accepts ~14-16 bytes per cycle whatever the bytes are, so activation bytes cost
 //     as much as weight bytes.  Tried in round 3 without gain: whole 128-byte lines per activation load instruction (kept, neutral),
 //     XCD-aware placement of the workgroups that share an activation block (prologue unchanged, K = 4096 main loop slower: L2
-//     channel conflicts), non-temporal weight loads (+-3 %).  Three stages per k range where that fills the chip (TD gates,
-//     K = 3072: 256 workgroups of 192 KB instead of 192 of 256 KB): 33.3 k -> 27.6 k cycles per workgroup;
+//     channel conflicts), non-temporal weight loads (+-3 %), three stages per k range where that fills the chip (see "Decomposition");
 //   * what did not help in round 2 (kept out): 8 waves, 256-column tiles (spills), bf16 planes written by the producers
 //     (6 instead of 4 bytes per element through the same pipeline), weights through LDS.
 #include <stdlib.h>
@@ -82,8 +81,9 @@ constexpr int rs_pb(int nsr) { return 64 * nsr + 16; }
 template <int MT, int NSR>
 constexpr size_t rs_lds_bytes() { return (size_t)3 * (16 * MT) * rs_pb(NSR) * 2 + (size_t)4 * (16 * MT) * 32 * 4; }
 
-template <int MT, int NSR, int TPW, int D, bool STAMPS = false>
-__global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
+// one workgroup's work: pair = its index among the (k range, column group) pairs of the problem `a`
+template <int MT, int NSR, int TPW, int D, bool STAMPS>
+__device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pair) {
     static_assert(NSR >= 2 && NSR <= 4, "two to four 64-deep stages per k range");
     constexpr int RS_PB = rs_pb(NSR);
     unsigned long long* const stamps = STAMPS ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) + 32 * (size_t)blockIdx.x : nullptr;
@@ -106,7 +106,6 @@ __global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
     // all of them) left the prologue unchanged and made the K = 4096 main loop 1.5 - 2x slower per step: with a power-of-two row
     // stride an XCD that streams only two k ranges uses a fraction of its L2 channels.
     const int ncg = (a.N + 128 * TPW - 1) / (128 * TPW);
-    const int pair = blockIdx.x;
     const int z = pair / ncg, n0 = (pair % ncg) * (128 * TPW);
     const int c_begin = z * NSR;
     float* const strip = reinterpret_cast<float*>(sk_smem + 3 * PLANE * 2) + (size_t)wave * ROWS * 32;      // this wave's epilogue staging
@@ -289,32 +288,42 @@ __global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
     stamp(31);
 }
 
+template <int MT, int NSR, int TPW, int D, bool STAMPS = false>
+__global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
+    resident_x3_body<MT, NSR, TPW, D, STAMPS>(a, blockIdx.x);
+}
+// Two independent problems in one launch (the two recurrent dgrad products of a BPTT step, d h2 and d h1: 128 + 64 workgroups --
+// alone neither fills the chip, and every launch pays the same fixed prologue): workgroups [0, first) take `a`, the rest `b`.
+struct GemmPair { GemmArgs a, b; int first; };
+template <int MT, int NSR, int TPW, int D>
+__global__ __launch_bounds__(256) void gemm_resident_x3_pair_kernel(GemmPair g) {
+    if ((int)blockIdx.x < g.first) resident_x3_body<MT, NSR, TPW, D, false>(g.a, blockIdx.x);
+    else resident_x3_body<MT, NSR, TPW, D, false>(g.b, blockIdx.x - g.first);
+}
+
 // ------------------------------------------------------------------------------------------------
-// Decomposition.  tot = K / 64 stages in all; a workgroup takes NSR of them and TPW = 2 column tiles of 128.  NSR is the value
-// in {4, 3} that divides tot and gives the most workgroups not above the 256 CUs (TD gates, K = 3072: 16 ranges of 3 stages x 16
-// column groups = 256; LM gates, K = 4096: 16 ranges of 4; vocabulary projection, K = 1024: 4 ranges of 4 x 40 = 160).
+// Decomposition.  tot = K / 64 stages in all; a workgroup takes NSR = 4 of them (a 256-deep k range) and TPW = 2 column tiles of
+// 128: TD gates (K = 3072) 12 ranges x 16 column groups = 192 workgroups, LM gates (K = 4096) 256, vocabulary projection 160.
+// MEASURED (round 3, same box): three-stage ranges for the TD gates (256 workgroups of 192 KB of weights instead of 192 of 256 KB)
+// take 17 % fewer cycles per workgroup (33.3 k -> 27.6 k) and make the decode SLOWER: greedy 64 x 20 steps 98.9 -> 100.8 us per
+// step, SCST rollouts 3.09 -> 3.13 ms -- four more slabs through the LSTM pointwise kernel, and no idle CUs left for the other
+// chain of the rollout pair.  Not kept; the kernel body stays generic in NSR.
 static int rs_total_stages(const GemmArgs& a) {
     int tot = 0;
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / SK_BK;
     return tot;
 }
-int gemm_resident_x3_stages(const GemmArgs& a) {
-    const int tot = rs_total_stages(a), ncg = cdiv(a.N, 256);
-    int best = 0, best_wgs = 0;
-    for (int nsr = 4; nsr >= 3; --nsr) {
-        if (tot % nsr) continue;
-        const int wgs = ncg * (tot / nsr);
-        if (!best || (wgs <= 256 && (wgs > best_wgs || best_wgs > 256))) { best = nsr; best_wgs = wgs; }
-    }
-    return best;
-}
-// shapes the kernel takes: 33..64 rows, N a multiple of 4 and at least 2048 wide, whole 64-deep stages that split into ranges
-bool gemm_resident_x3_fits(const GemmArgs& a) {
-    if (!gemm_switches().resident_x3 || a.M <= 32 || a.M > 64 || a.N < 2048 || a.N % 4 || a.accumulate) return false;
+int gemm_resident_x3_stages(const GemmArgs& a) { return rs_total_stages(a) % 4 == 0 ? 4 : 0; }
+// shapes the kernel can take: 33..64 rows, N a multiple of 4, whole 64-deep stages that split into ranges
+static bool rs_shape_ok(const GemmArgs& a) {
+    if (!gemm_switches().resident_x3 || a.M <= 32 || a.M > 64 || a.N % 4 || a.accumulate) return false;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % SK_BK || a.seg[s].gather) return false;
     return rs_total_stages(a) >= 8 && gemm_resident_x3_stages(a) > 0;
 }
+// ... and the ones gemm_f32 routes to it by itself: at least 2048 columns (narrower outputs leave most of the chip idle at 256
+// columns per workgroup: dec_att stays on the fp32 kernel)
+bool gemm_resident_x3_fits(const GemmArgs& a) { return a.N >= 2048 && rs_shape_ok(a); }
 int gemm_resident_x3_nsplit(const GemmArgs& a) { return rs_total_stages(a) / gemm_resident_x3_stages(a); }
 
 template <int NSR, bool STAMPS>
@@ -338,17 +347,43 @@ static int rs_dev_env(const char* name) { const char* e = getenv(name); return e
 int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     const int nsr = gemm_resident_x3_stages(a);
-    ICZ_REQUIRE(gemm_resident_x3_fits(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == nsr,
+    ICZ_REQUIRE(rs_shape_ok(a) && a.nsplit == gemm_resident_x3_nsplit(a) && a.chunks_per_split == nsr,
                 "gemm_resident_x3: launch does not match the kernel's fixed decomposition (nsplit %d)", a.nsplit);
     ICZ_REQUIRE(a.nsplit > 1 || a.ldo >= a.N, "gemm_resident_x3: output row stride %d below N = %d", a.ldo, a.N);
 #ifdef ICZ_DEV
     if (rs_dev_env("ICZ_DEV_STAMPS")) {
         if (!g_sk_stamps) ICZ_CHECK_HIP(hipMalloc((void**)&g_sk_stamps, sizeof(unsigned long long) * 32 * 4096));
         a.bias = reinterpret_cast<const float*>(g_sk_stamps);
-        return nsr == 4 ? rs_launch<4, true>(a, stream) : rs_launch<3, true>(a, stream);
+        return rs_launch<4, true>(a, stream);
     }
 #endif
-    return nsr == 4 ? rs_launch<4, false>(a, stream) : rs_launch<3, false>(a, stream);
+    return rs_launch<4, false>(a, stream);
+}
+
+// the pair launch: both problems in the kernel's decomposition with four stages per k range, slabs out (nsplit > 1)
+bool gemm_resident_x3_pair_fits(const GemmArgs& a, const GemmArgs& b) {
+    return rs_shape_ok(a) && rs_shape_ok(b) && gemm_resident_x3_stages(a) == 4 && gemm_resident_x3_stages(b) == 4 && a.N >= 512 && b.N >= 512;
+}
+int gemm_resident_x3_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
+    ICZ_REQUIRE(gemm_resident_x3_pair_fits(a_in, b_in), "gemm_resident_x3_pair: shapes outside the kernel's decomposition");
+    GemmPair g;
+    g.a = a_in; g.b = b_in;
+    for (GemmArgs* p : {&g.a, &g.b}) {
+        p->nsplit = gemm_resident_x3_nsplit(*p);
+        p->chunks_per_split = 4;
+        p->bias = nullptr;
+        ICZ_REQUIRE(p->out && p->nsplit > 1, "gemm_resident_x3_pair: slab output expected");
+    }
+    g.first = cdiv(g.a.N, 256) * g.a.nsplit;
+    constexpr size_t lds = rs_lds_bytes<4, 4>();
+    static bool attr = false;
+    if (!attr) {
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 4, 2, 3>), dim3(g.first + cdiv(g.b.N, 256) * g.b.nsplit), dim3(256), lds, stream, g);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
 }
 
 int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,

@@ -243,7 +243,7 @@ int Nic::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = unf; a.n_unfinished = nunf; a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tok + slot + B; a.draw_out = draw + slot; a.lse_out = lse + slot;
-        hipLaunchKernelGGL(sample_select_kernel, dim3(B), dim3(SEL_THREADS), sizeof(float) * dims.V, st, a);
+        launch_sample_select(st, B, a);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
