@@ -10,8 +10,11 @@ features / references / random-init weights (no network), already resident in HB
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
+    ... bench.py --gpus N --scaling strong     # global batch 64 split over the ranks (64 / N images per GPU) instead of 64 per GPU
+
 Rank 0 prints ONE JSON line (see the keys below).  `roofline` is measured live with HIP events around every launch of
-the dominant kernel (gemm_nt_kernel<4>, the forward GEMMs of the decoder step) during the timed steps;
+the dominant kernel (gemm_resident_x3_kernel<4,4,2,3>: the LSTM-gate and vocabulary-projection GEMMs of every decoder step
+and, on transposed weights, the per-step dgrad GEMMs of BPTT) in an eager re-run of bench steps right after the timed region;
 `cpu_baseline` times the CPU oracle (our port of the reference path, oracle/) on a bounded sample on rank 0.
 """
 import argparse
@@ -135,6 +138,20 @@ def secondary(eng, opt, words, device, B):
         out["beam5_b128"] = {"captions_per_s": 128 / dt, "ms": dt * 1e3, "batch": 128, "steps": 20}
     h.close()
     del h, f128, f64
+    # BASELINE config 3's dominant kernel: the 128 x 128 split-precision NT GEMM on the three big products of a beam step at 640
+    # rows (TD gates K = 3072, LM gates K = 4096 -- both N = 4096 -- and the vocabulary projection 10112 x 1024)
+    out["beam5_b128"]["roofline"] = csv_roofline(
+        "beam5_b128_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
+        "TD gates, LM gates and vocabulary projection of a beam step at 640 rows: 50.8 GFLOP over three launches",
+        flops_per_launch=2.0 * 640 * (4096 * 3072 + 4096 * 4096 + 10112 * 1024) / 3.0)
+    # BASELINE config 2's: the resident split-precision kernel (forward gates / vocabulary projection of the steps with more than 32
+    # active rows, per-step dgrad of BPTT); algorithmic bytes per launch averaged over those five shapes at 64 rows
+    out["xe_step_spatial49"]["roofline"] = csv_roofline(
+        "xe_spatial49_kernel_stats.csv", "gemm_resident_x3_kernel",
+        "TD gates, LM gates, vocabulary projection and the LM-input dgrad of BPTT at up to 64 rows: weights 41 - 67 MB per launch streamed "
+        "once + activations and output (average of the four shapes at 64 rows)",
+        bytes_per_launch=4.0 * (4096 * 3072 + 4096 * 4096 + 10112 * 1024 + 3072 * 4096) / 4.0 + 4.0 * 64 * (3584 + 5300))
+    out["nic_greedy_b16"] = nic_greedy_b16(device)
     out["aoa_scst_step"] = aoa_scst(words, device, B)
     return out
 
@@ -205,7 +222,8 @@ def aoa_roofline(B, steps_in_profile=13):
     six layers of a fused Q/K/V projection 1024 -> 3072 and an AoA linear 2048 -> 2048 over B x 36 rows; two passes per step)."""
     import csv
     try:
-        rows = list(csv.DictReader(open(os.path.join(ROOT, "profiles", "r02_aoa_scst_kernel_stats.csv"))))
+        path = _profile_path("aoa_scst_kernel_stats.csv")
+        rows = list(csv.DictReader(open(path)))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
         k = [r for r in rows if "gemm_tn128_x3_kernel<1, 4, true, true>" in r["Name"]][0]
         M = B * R
@@ -217,8 +235,84 @@ def aoa_roofline(B, steps_in_profile=13):
         return {"kernel": "gemm_tn128_x3_kernel<1,4,true,true> (refiner GEMMs, split precision)", "bound": "mfma", "achieved": tf,
                 "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None, "avg_launch_us": us, "launches_per_step": launches,
                 "share_of_kernel_time": float(k["TotalDurationNs"]) / tot, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS,
-                "source": "profiles/r02_aoa_scst_kernel_stats.csv (rocprofv3 --kernel-trace --stats of tools/perf_aoa_engine.py at the "
-                          "committed code, NOT this run); peak = 2.5 PFLOP/s bf16 / 6 MFMAs per fp32 product"}
+                "source": "profiles/%s (rocprofv3 --kernel-trace --stats of tools/perf_aoa_engine.py at the "
+                          "committed code, NOT this run); peak = 2.5 PFLOP/s bf16 / 6 MFMAs per fp32 product" % os.path.basename(path)}
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def _profile_path(suffix):
+    """profiles/r03_<suffix> if this round committed one, else round 2's."""
+    for rnd in ("r03", "r02"):
+        p = os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix))
+        if os.path.exists(p):
+            return p
+    return os.path.join(ROOT, "profiles", "r03_" + suffix)
+
+
+def csv_roofline(suffix, kernel, what, flops_per_launch=None, bytes_per_launch=None, mfma_peak=2500.0 / 6.0):
+    """Roofline entry of one kernel from a COMMITTED rocprofv3 kernel-stats summary (profiles/), not from this run: average
+    launch duration from the trace, algorithmic flops / bytes per launch from the shapes named in `what`."""
+    import csv
+    try:
+        path = _profile_path(suffix)
+        rows = list(csv.DictReader(open(path)))
+        tot = sum(float(r["TotalDurationNs"]) for r in rows)
+        k = [r for r in rows if kernel in r["Name"]][0]
+        us = float(k["AverageNs"]) / 1e3
+        out = {"kernel": kernel, "what": what, "avg_launch_us": us, "calls_in_profile": int(k["Calls"]),
+               "share_of_kernel_time": float(k["TotalDurationNs"]) / tot,
+               "source": "profiles/%s (rocprofv3 --kernel-trace --stats at the committed code, NOT this run)" % os.path.basename(path)}
+        t_mfma = flops_per_launch / (mfma_peak * 1e12) if flops_per_launch else 0.0
+        t_hbm = bytes_per_launch / (HBM_PEAK_GBS * 1e9) if bytes_per_launch else 0.0
+        if t_mfma >= t_hbm:
+            tf = flops_per_launch / (us * 1e-6) / 1e12
+            out.update({"bound": "mfma", "achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak, "traffic": None,
+                        "peak_note": "2.5 PFLOP/s bf16 / 6 MFMAs per fp32 product (split precision)"})
+        else:
+            gbs = bytes_per_launch / (us * 1e-6) / 1e9
+            out.update({"bound": "hbm", "achieved": gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gbs / HBM_PEAK_GBS, "traffic": None})
+        return out
+    except Exception as e:
+        return {"error": repr(e)}
+
+
+def nic_greedy_b16(device):
+    """BASELINE config 1 at its own size: the NIC decoder's greedy decode (NIC_Model.py:100-119), Flickr8K-size vocabulary 2543,
+    E = H = 512, batch 16, 20 steps, random-init weights -- on the device, with the CPU oracle's time on the same inputs beside it
+    (config 1 is the reference's CPU-runnable plumbing case) and whether the two agree token for token."""
+    import time as _t
+    from oracle import nic as onic
+    from simpleimagecaptionzoo_amd.nic import NicHandle
+    from simpleimagecaptionzoo_amd.synth import random_nic_params
+    try:
+        E_, H_, V_, B_ = 512, 512, 2543, 16
+        params = random_nic_params(E_, H_, V_, device, seed=7)
+        h = NicHandle(E_, H_, V_, B_, 20, device)
+        h.bind(params)
+        g = torch.Generator(device="cpu")
+        g.manual_seed(11)
+        feats = torch.randn(B_, E_, generator=g).to(device)
+        for _ in range(3):
+            ids = h.greedy(feats, 20)
+        torch.cuda.synchronize()
+        t0 = _t.perf_counter()
+        for _ in range(20):
+            ids = h.greedy(feats, 20)
+        torch.cuda.synchronize()
+        dt = (_t.perf_counter() - t0) / 20
+        p = {k: v.cpu() for k, v in params.items()}
+        with torch.no_grad():
+            onic.greedy(feats.cpu(), p, 20)
+            t0 = _t.perf_counter()
+            want, _ = onic.greedy(feats.cpu(), p, 20)
+            cpu_dt = _t.perf_counter() - t0
+        same = int((want.numpy() == ids.cpu().numpy()).all(1).sum())
+        h.close()
+        return {"captions_per_s": B_ / dt, "ms": dt * 1e3, "batch": B_, "steps": 20, "vocab": V_, "embed_dim": E_, "hidden_dim": H_,
+                "cpu_oracle": {"captions_per_s": B_ / cpu_dt, "ms": cpu_dt * 1e3, "cores": torch.get_num_threads(), "kind": "port"},
+                "rows_token_exact_vs_oracle": same,
+                "note": "BASELINE config 1 (NIC greedy decode, Flickr8K vocabulary, batch 16): eager launches, 16 rows take the fp32-MFMA GEMM path"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -281,15 +375,14 @@ def fp32_gemm_child(steps, warmup, batch):
     """The same bench with the split-precision (3 x bf16) GEMM kernels switched off: ICZ_GEMM_*_X3 = 0 selects the fp32-MFMA
     kernels everywhere.  The switches are read once per process, hence a child process (started, not exec'ed into)."""
     import subprocess
-    env = dict(os.environ, ICZ_GEMM_TN_X3="0", ICZ_GEMM_NN_X3="0", ICZ_GEMM_NT_X3BIG="0", ICZ_GEMM_X3="0", ICZ_GEMM_SKINNY_X3="0",
-               ICZ_GEMM_RESIDENT_X3="0")
+    env = dict(os.environ, ICZ_GEMM_TN_X3="0", ICZ_GEMM_NN_X3="0", ICZ_GEMM_NT_X3BIG="0", ICZ_GEMM_RESIDENT_X3="0")
     try:
         out = subprocess.run([sys.executable, os.path.abspath(__file__), "--steps", str(steps), "--warmup", str(warmup), "--batch", str(batch),
                               "--headline-only"], env=env, capture_output=True, text=True, timeout=600)
         line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
         j = json.loads(line)
         return {"value": j["value"], "ms_per_step": j["ms_per_step"], "note": "ICZ_GEMM_TN_X3=0 ICZ_GEMM_NN_X3=0 ICZ_GEMM_NT_X3BIG=0 "
-                "ICZ_GEMM_SKINNY_X3=0 ICZ_GEMM_RESIDENT_X3=0: every GEMM on v_mfma_f32_16x16x4_f32"}
+                "ICZ_GEMM_RESIDENT_X3=0: every GEMM on v_mfma_f32_16x16x4_f32"}
     except Exception as e:
         return {"error": repr(e)}
 
@@ -299,7 +392,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="images per GPU per step (BASELINE config: 64)")
+    ap.add_argument("--batch", type=int, default=64, help="images per step: per GPU (weak scaling, BASELINE config: 64) or in all (strong)")
+    ap.add_argument("--scaling", choices=("weak", "strong"), default="weak",
+                    help="weak: --batch images per GPU (per-GPU work fixed); strong: --batch images split over the ranks (total work fixed)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive / cold-cache / secondary measurements")
     ap.add_argument("--headline-only", action="store_true", help="timed region + JSON line, nothing else (used by the fp32-GEMM child run)")
@@ -322,6 +417,10 @@ def main():
     device = "cuda:%d" % local
     torch.cuda.set_device(local)
     B = args.batch
+    if args.scaling == "strong":
+        if args.batch % world:
+            raise SystemExit("--scaling strong: the global batch %d does not split over %d ranks" % (args.batch, world))
+        B = args.batch // world
     eng, opt, vocab, words = build_engine(device, B)
     df = eng._cider_df
     # Every step sees a batch it has never seen: new image ids, new features, new references (a shuffled loader never repeats
@@ -407,7 +506,7 @@ def main():
     out = {
         "metric": "captions/sec (SCST step), BUTDDetection COCO14-size vocab",
         "value": value, "unit": "captions/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
         "dtype": "f32", "data": "synthetic",
         "arithmetic": "fp32 storage and fp32 accumulation throughout (float64 CIDEr-D).  The LSTM-gate and vocabulary-projection GEMMs of "
                       "the decoder steps (64 rows) and the 128 x 128-tile GEMMs (weight gradients, the dgrad over all time steps, forward "
@@ -451,11 +550,12 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
     t_hbm, t_mfma = bytes_pl / (HBM_PEAK_GBS * 1e9), flops_pl / (mfma_peak * 1e12)
     traffic, src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_pmc_traffic.json")))
+        pmc_path = _profile_path("pmc_traffic.json")
+        pmc = json.load(open(pmc_path))
         want = "gemm_resident_x3_kernel" if x3 else "gemm_nt_kernel"
         nt = [v for k, v in pmc["kernels"].items() if want in k]
         traffic = max(nt, key=lambda v: v["launches"])["hbm_bytes_per_launch"]
-        src = ("profiles/r02_pmc_traffic.json: rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters "
+        src = ("profiles/" + os.path.basename(pmc_path) + ": rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters "
                "cannot be read in-process); above the algorithmic bytes by the split-K slabs the kernel writes (12 - 16 slabs of "
                "rows x N floats per gate GEMM, 4 per vocabulary projection), which its consumers sum")
     except Exception:

@@ -101,9 +101,11 @@ def inverse_cdf_draw(prob, u):
     return torch.searchsorted(c, tgt, right=True).clamp_(max=prob.shape[1] - 1).squeeze(1)
 
 
-def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, early_exit=True):
+def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, early_exit=True, trace=None):
     """DecoderRNN.sample_rl, BUTD_Model.py:191-234 with explicit uniforms/masks.
-    Returns seq (B,T) int64 (0 at and after a sampled <end>), logprobs (B,T) (autograd-capable), logits."""
+    Returns seq (B,T) int64 (0 at and after a sampled <end>), logprobs (B,T) (autograd-capable), logits.
+    trace: optional dict; receives "h1" = the attention LSTM's hidden state of every step (detached), for tests that look at
+    the attention pre-activations behind a gradient."""
     B = feats.shape[0]
     H = p["TD_atten.weight_hh"].shape[1]
     mean, st = feats.mean(1), zero_state(B, H)
@@ -117,6 +119,8 @@ def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, e
              None if att_masks is None else torch.as_tensor(att_masks[t]),
              None if out_masks is None else torch.as_tensor(out_masks[t]))
         logits, _, st = step(feats, mean, it, st, p, m)
+        if trace is not None:
+            trace.setdefault("h1", []).append(st[0].detach())
         logp = torch.log_softmax(logits, dim=1)
         draw = inverse_cdf_draw(torch.exp(logp.detach()), uniforms[t])
         lps[t] = logp.gather(1, draw.unsqueeze(1)).squeeze(1)
@@ -186,8 +190,9 @@ def scheduled_tokens(captions, t, bt, prev_logits, ss_prob, ss_gate, ss_draw):
 
 
 def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_masks=None, ss_prob=0.0, ss_gate=None,
-               ss_draw=None, tokens_out=None):
-    """DecoderRNN.forward, BUTD_Model.py:97-151.  Returns packed logits (sum(lengths), V).
+               ss_draw=None, tokens_out=None, trace=None):
+    """DecoderRNN.forward, BUTD_Model.py:97-151.  Returns packed logits (sum(lengths), V).  trace: as in sample_rl ("h1" per step,
+    rows past a step's active count zero-padded to the batch).
     Scheduled sampling (:120-132, ss_prob > 0): from time step 2 on, row b feeds a draw from softmax(previous logits)
     instead of its caption token when ss_gate[t][b] < ss_prob; the draw is inverse_cdf_draw with ss_draw[t][b] (no
     gradient flows through it).  tokens_out, if a list, receives the tokens fed at every step."""
@@ -205,6 +210,10 @@ def forward_xe(feats, captions, lengths, p, emb_masks=None, att_masks=None, out_
         if tokens_out is not None:
             tokens_out.append(it.clone())
         logits, _, st = step(feats[:bt], mean[:bt], it, tuple(s[:bt] for s in st), p, m)
+        if trace is not None:
+            h1 = torch.zeros(B, H, dtype=st[0].dtype)
+            h1[:bt] = st[0].detach()
+            trace.setdefault("h1", []).append(h1)
         rows.append(logits)
     return torch.cat(rows, 0)
 

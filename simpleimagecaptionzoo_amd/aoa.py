@@ -315,6 +315,18 @@ class AoADetection_Captioner(nn.Module, ScheduledSamplingState):
         self._ss_push(self._h, fresh)
         return self._h
 
+    def _replay_handle(self):
+        """One-image handle for the teacher-forced replay behind eval_test_image's attention maps (as BUTDDetection_Captioner's):
+        the training handle keeps its stored pass, graphs and buffers, and scheduled sampling is off on a fresh handle."""
+        named = self._named()
+        dev = next(iter(named.values())).device
+        rh = getattr(self, "_rh", None)
+        if rh is None or rh.device != dev:
+            R, D, Hd, E, V, NH = self.dims
+            rh = self._rh = AoaHandle(R, D, Hd, E, V, NH, 1, 52, dev)
+        rh.bind({k: p.data for k, p in named.items()})
+        return rh
+
     @staticmethod
     def _feats(visual_inputs):
         """bu_feats (+ the region counts behind bu_masks: `bu_counts` when the Engine supplies them, else read back from the
@@ -369,8 +381,9 @@ class AoADetection_Captioner(nn.Module, ScheduledSamplingState):
             replay = torch.cat([torch.ones(1, 1, dtype=torch.int64, device=ids.device), ids], 1)
         steps = replay.shape[1] - 1
         if steps > 0:
-            h.xe_forward(feats, replay, [steps], None, train=False)
-            alphas = h.saved_alphas(1, steps, raw.shape[1])
+            rh = self._replay_handle()
+            rh.xe_forward(feats, replay, [steps], None, train=False)
+            alphas = rh.saved_alphas(1, steps, raw.shape[1])
         else:
             alphas = torch.zeros(1, 0, raw.shape[1], device=raw.device)
         caption = []

@@ -193,6 +193,19 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
         out = [seqs[i:i + 1, :lens[i]] for i in range(len(lens))]
         return out[0] if len(out) == 1 else out
 
+    def _replay_handle(self):
+        """One-row handle for the teacher-forced replay behind eval_test_image's beam-search attention maps: the training handle
+        keeps its stored forward pass, its captured graphs and its buffers (a beam sentence of up to 50 steps would re-allocate
+        them), and the replay never sees scheduled sampling (a fresh handle has it switched off)."""
+        named = self._named()
+        dev = next(iter(named.values())).device
+        rh = getattr(self, "_rh", None)
+        if rh is None or rh.device != dev:
+            d = self.dims
+            rh = self._rh = ButdHandle(d["R"], d["D"], d["H"], d["E"], d["A"], d["V"], 1, 52, dev)
+        rh.bind({k: v.data for k, v in named.items()})          # binds and refreshes the weight-norm weights (parameters may have moved on)
+        return rh
+
     def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):
         """BUTD_Model.py:519-544 -> (caption words, [alphas (1, steps, R)]).  Greedy: the attention maps come out of the decode
         itself.  Beam search: the decoder state of a beam is a function of its token prefix, so the maps of the returned
@@ -209,8 +222,9 @@ class BUTDDetection_Captioner(nn.Module, ScheduledSamplingState):
             ids = seqs[:, :n]
             steps = n - 1                                   # one map per generated token (the leading <sta> has none, :316)
             if steps > 0:
-                h.xe_forward(feats, ids.long(), [steps], None, train=False)
-                alphas = h.saved_alphas(1, steps)
+                rh = self._replay_handle()
+                rh.xe_forward(feats, ids.long(), [steps], None, train=False)
+                alphas = rh.saved_alphas(1, steps)
             else:
                 alphas = torch.zeros(1, 0, self.dims["R"], device=feats.device)
         else:

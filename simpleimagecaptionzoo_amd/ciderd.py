@@ -11,6 +11,8 @@ they still count in the reference norms and can never match a hypothesis n-gram 
 vocabulary ids).  Scoring itself runs in libicz (csrc/ciderd.hip) in float64.
 """
 import ctypes as C
+import threading
+import time
 
 import numpy as np
 import torch
@@ -135,9 +137,11 @@ class ReferenceCooker:
         return (np.asarray(ent_ptr, np.int32), np.asarray(keys, np.int32).reshape(-1, 4), np.asarray(order, np.int32),
                 np.asarray(ws, np.float64), np.asarray(norms, np.float64).reshape(-1, 4), np.asarray(lens, np.int32))
 
-    def cook_images(self, refs_per_image):
+    def cook_images(self, refs_per_image, as_block=False):
         """[[reference strings of image 0], ...] -> one (ent_ptr, keys, order, w, norm, length) tuple per image, through the
-        library's host cooker (one call for all of them, outside the GIL)."""
+        library's host cooker (one call for all of them, outside the GIL).  as_block: the arrays of all the images as ONE block
+        instead ({"nref": references per image, "ep": entry pointer per reference (+1), "key", "ord", "w", "norm", "len"}): what
+        the device store appends, without cutting the arrays per image and joining them again."""
         tok, tptr, nref = [], [0], []
         get, wid = self.word2ix.get, self._word_id
         for refs in refs_per_image:
@@ -159,6 +163,9 @@ class ReferenceCooker:
         P = lambda a: a.ctypes.data_as(C.c_void_p)
         check(lib().icz_ciderd_cook_host(P(self.keys_host), P(self.idf_host), self.cap, self.log_ref_len, P(tok), P(tptr), n_refs, max_ent,
                                          P(K), P(O), P(W), P(EP), P(N), P(L), C.byref(ne)))
+        if as_block:
+            e = int(ne.value)
+            return {"nref": np.asarray(nref, np.int32), "ep": EP, "key": K[:e], "ord": O[:e], "w": W[:e], "norm": N[:n_refs], "len": L[:n_refs]}
         out, r0 = [], 0
         for nr in nref:
             e0, e1 = int(EP[r0]), int(EP[r0 + nr])
@@ -184,7 +191,11 @@ class CiderDReward:
                                       C.byref(self._h)))
         self.persistent = False
         self._out = {}
-        self._cooked = {}                    # image id -> cooked reference arrays (host), until they are in the store
+        self._blocks = []                    # cooked reference blocks (host) waiting for their upload, in cooking order
+        self._pending = {}                   # image id -> its block, until the block is in the store
+        self._cooking = set()                # image ids being cooked right now (by the loader's worker thread or the main thread)
+        self._lock = threading.Lock()        # guards _slot / _blocks / _pending / _cooking: prepare() runs on a loader thread beside _append()
+        self._up_ring, self._up_i = [(None, None, None)] * 4, 0       # pinned / device staging of the block uploads
         self._store_init()
 
     def close(self):
@@ -229,11 +240,23 @@ class CiderDReward:
 
     def prepare(self, img_ids, gts):
         """Cook the references of images not seen before (host only, thread-safe: a loader's worker thread calls this for
-        batch i+1 while batch i is on the device, features.DevicePrefetcher(on_batch=...); the cooker runs outside the GIL)."""
-        new = [i for i in dict.fromkeys(img_ids) if i not in self._slot and i not in self._cooked]
-        if new:
-            for i, c in zip(new, self.cooker.cook_images([gts[i] for i in new])):
-                self._cooked[i] = c
+        batch i+1 while batch i is on the device, features.DevicePrefetcher(on_batch=...); the cooker runs outside the GIL).
+        The new images of one call form one block, which _append uploads as a unit."""
+        with self._lock:
+            new = [i for i in dict.fromkeys(img_ids) if i not in self._slot and i not in self._pending and i not in self._cooking]
+            self._cooking.update(new)
+        if not new:
+            return
+        try:
+            blk = self.cooker.cook_images([gts[i] for i in new], as_block=True)       # outside the lock (and, in C++, outside the GIL)
+            blk["ids"] = new
+            with self._lock:
+                self._blocks.append(blk)
+                for i in new:
+                    self._pending[i] = blk
+        finally:
+            with self._lock:
+                self._cooking.difference_update(new)
 
     def preload(self, gts):
         """Cook and upload the references of a whole dataset split ({image id: [reference strings]}) ahead of training."""
@@ -242,39 +265,65 @@ class CiderDReward:
             self._append(ids[lo:lo + 1024], gts)
 
     def _append(self, img_ids, gts):
-        new = [i for i in dict.fromkeys(img_ids) if i not in self._slot]
-        if not new:
-            return
-        self.prepare(new, gts)
-        irp, rep, K, O, W, N, L = [], [], [], [], [], [], []
-        nref, nent = self._n_ref, self._n_ent
-        for i in new:
-            ep, k, o, w, nrm, ln = self._cooked.pop(i)
-            rep.extend((nent + ep[1:]).tolist())
-            nent += int(ep[-1])
-            nref += len(ln)
-            irp.append(nref)
-            K.append(k); O.append(o); W.append(w); N.append(nrm); L.append(ln)
-        n_new = len(new)
+        """Make sure every image of `img_ids` is in the device store: cook what nobody has cooked, wait for what the loader's worker
+        thread is cooking right now, then upload the pending blocks that hold any of them."""
+        while True:
+            self.prepare(img_ids, gts)
+            with self._lock:
+                missing = [i for i in img_ids if i not in self._slot and i not in self._pending]
+                if not missing:
+                    need = {id(self._pending[i]) for i in img_ids if i in self._pending}
+                    blocks = [b for b in self._blocks if id(b) in need]
+                    self._blocks = [b for b in self._blocks if id(b) not in need]
+                    break
+            time.sleep(0.0002)
+        for blk in blocks:
+            self._upload(blk)
+
+    def _upload(self, blk):
+        """One block of cooked references -> the device store: the seven arrays go through ONE pinned staging buffer and one
+        asynchronous H2D copy, then device-side copies into the (growing) store arrays -- nothing here waits for the device."""
+        ids, nref = blk["ids"], blk["nref"]
+        n_new, n_ref, n_ent = len(ids), int(blk["len"].shape[0]), int(blk["ord"].shape[0])
+        irp = self._n_ref + np.cumsum(nref, dtype=np.int64).astype(np.int32)           # reference end per image
+        rep = (self._n_ent + blk["ep"][1:n_ref + 1].astype(np.int64)).astype(np.int32)   # entry end per reference
+        parts = (("irp", irp, self._n_img + 1), ("rep", rep, self._n_ref + 1), ("key", blk["key"], self._n_ent), ("ord", blk["ord"], self._n_ent),
+                 ("w", blk["w"], self._n_ent), ("norm", blk["norm"], self._n_ref), ("len", blk["len"], self._n_ref))
         self._grow("irp", self._n_img + n_new + 1)
-        self._grow("rep", nref + 1)
+        self._grow("rep", self._n_ref + n_ref + 1)
         for name in ("norm", "len"):
-            self._grow(name, nref)
+            self._grow(name, self._n_ref + n_ref)
         for name in ("key", "ord", "w"):
-            self._grow(name, nent)
-        st = self._st
-        up = lambda arr, dt: torch.from_numpy(np.ascontiguousarray(arr)).to(dt)      # small pageable copies: cold path only
-        st["irp"][self._n_img + 1:self._n_img + 1 + n_new].copy_(up(np.asarray(irp), torch.int32))
-        st["rep"][self._n_ref + 1:nref + 1].copy_(up(np.asarray(rep), torch.int32))
-        st["key"][self._n_ent:nent].copy_(up(np.concatenate(K).reshape(-1, 4), torch.int32))
-        st["ord"][self._n_ent:nent].copy_(up(np.concatenate(O), torch.int32))
-        st["w"][self._n_ent:nent].copy_(up(np.concatenate(W), torch.float64))
-        st["norm"][self._n_ref:nref].copy_(up(np.concatenate(N).reshape(-1, 4), torch.float64))
-        st["len"][self._n_ref:nref].copy_(up(np.concatenate(L), torch.int32))
-        for j, i in enumerate(new):
-            self._slot[i] = self._n_img + j
+            self._grow(name, self._n_ent + n_ent)
+        total = sum((a.nbytes + 15) // 16 * 16 for _, a, _ in parts)
+        k = self._up_i = (self._up_i + 1) % len(self._up_ring)
+        host, dev, ev = self._up_ring[k]
+        if host is None or host.numel() < total:
+            cap = max(1 << 20, 1 << (total - 1).bit_length())
+            host, dev, ev = torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device), None
+        if ev is not None:
+            ev.synchronize()                                        # the copy issued len(ring) blocks ago has left this buffer
+        hv, off, views = host.numpy(), 0, []
+        for name, a, at in parts:
+            a = np.ascontiguousarray(a)
+            hv[off:off + a.nbytes] = a.view(np.uint8).reshape(-1)
+            views.append((name, off, a.nbytes, at, a.shape))
+            off += (a.nbytes + 15) // 16 * 16
+        dev[:off].copy_(host[:off], non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        self._up_ring[k] = (host, dev, ev)
+        for name, o, nb, at, shape in views:
+            dst = self._st[name]
+            src = dev[o:o + nb].view(dst.dtype).view(shape)
+            dst[at:at + shape[0]].copy_(src, non_blocking=True)
+        with self._lock:
+            for j, i in enumerate(ids):
+                self._slot[i] = self._n_img + j
+                self._pending.pop(i, None)
         self._n_img += n_new
-        self._n_ref, self._n_ent = nref, nent
+        self._n_ref += n_ref
+        self._n_ent += n_ent
 
     def _slots(self, img_ids, gts):
         """Store rows of the batch as a device int32 tensor (uploading first whatever the store does not hold yet)."""

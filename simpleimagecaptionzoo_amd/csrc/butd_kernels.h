@@ -853,11 +853,10 @@ inline int ss_select_launch(hipStream_t st, int rows, const float* logits_prev, 
     return ICZ_OK;
 }
 // One workgroup of 16 waves per row.  Passes: (1) finished logits x = sum of the predict GEMM's split-K slabs + bias -> LDS (and
-// the saved-logits slot of backward), row maximum M; (2) every thread takes a contiguous slice of the row: float64 sum of
-// q_v = exp(x_v - M), block scan -> total and the slice's prefix; (3) the thread whose slice crosses u * total walks it again
-// (q recomputed: the same float expression) and reports the first index above the target.  The distribution is softmax(x) as in
-// the reference; against exp(log_softmax(x)) rounded to float32 first (round 2's form: two more passes over the row) a CDF edge
-// moves by ~1e-7 relative, so a draw differs only when u * total lies that close to an edge (the tests' criterion: within 1e-6).
+// the saved-logits slot of backward), row maximum M; (2) every thread takes a contiguous slice of the row: float32 sum of
+// exp(x - M) -> lse, then the float64 sum of p_v = expf((x_v - M) - lse) over its slice and a block scan -> total and the slice's
+// prefix; (3) the thread whose slice crosses u * total walks it again (p recomputed: the same float expression) and reports the
+// first index above the target.  Round 2's kernel made two more passes over the row (p written back to LDS, strided re-reads).
 // MEASURED (round 3, same box): a two-launch form over the whole chip (rows x 16 slice workgroups for the sums, then one small
 // workgroup per row for the draw: 7.9 + 8.1 us against 15.4 us for round 2's kernel) made the SCST rollouts SLOWER, 2.83 -> 3.09 ms:
 // the sampled chain runs beside the greedy chain, and a launch that fills every CU stalls the other chain's kernels, while this
@@ -916,11 +915,17 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
     }
     mx = block_max_n(mx, smf, NW);
-    // pass 2: contiguous slice per thread -> the first index above the target is the minimum over threads
+    // pass 2: contiguous slice per thread -> the first index above the target is the minimum over threads.
+    // p_v = exp(log_softmax(x)_v) = expf((x_v - M) - lse) with lse = logf(sum expf(x - M)) in float32 -- the reference's own
+    // float expression (:221-223), so that the float64 CDF below agrees with the oracle's to the last bit in all but a few draws in 10^5
     const int per = (a.V + SEL_THREADS - 1) / SEL_THREADS;
     const int v0 = min(a.V, tid * per), v1 = min(a.V, v0 + per);
+    float se = 0.f;
+    for (int v = v0; v < v1; ++v) se += expf(srow[v] - mx);
+    se = block_sum_n(se, smf, NW);
+    const float lse = logf(se);
     double loc = 0.0;
-    for (int v = v0; v < v1; ++v) loc += (double)expf(srow[v] - mx);
+    for (int v = v0; v < v1; ++v) loc += (double)expf((srow[v] - mx) - lse);
     double inc = loc;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -944,7 +949,7 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         if (run <= target && run + loc > target) {
             cand = v1 - 1;                               // the slice's last element carries the scan's own cumulative value
             for (int v = v0; v < v1 - 1; ++v) {
-                run += (double)expf(srow[v] - mx);
+                run += (double)expf((srow[v] - mx) - lse);
                 if (run > target) { cand = v; break; }
             }
         }
@@ -962,7 +967,6 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         const bool unf = was_unf && (d != 2);
         tok = unf ? d : 0;
         if (tid == 0) {
-            const float lse = logf((float)total);
             a.unfinished[row] = unf ? 1 : 0;
             a.seq_out[(size_t)row * a.T + a.t] = tok;
             a.logp_out[(size_t)row * a.T + a.t] = (srow[d] - mx) - lse;
@@ -1052,7 +1056,8 @@ __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict_
     __shared__ float smf[4];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
     if (b >= rows.n[t]) return;
-    const float inv_n = n_dev ? 1.0f / n_dev[0] : inv_n_host;      // data-parallel: the all-reduced token count, a device scalar
+    // data-parallel: the all-reduced token count, a device scalar (0 = never handed over: the local count, as the SCST path does)
+    const float inv_n = (n_dev && n_dev[0] > 0.f) ? 1.0f / n_dev[0] : inv_n_host;
     const int row = t * B + b;
     float* l = logits + (size_t)row * ldl;
     float mx = -INFINITY;
@@ -1084,7 +1089,7 @@ __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict_
 __global__ __launch_bounds__(256) void sum_scale_kernel(const float* __restrict__ x, int n, float scale_host, const float* __restrict__ n_dev,
                                                         float* __restrict__ out) {
     __shared__ float smf[4];
-    const float scale = n_dev ? 1.0f / n_dev[0] : scale_host;
+    const float scale = (n_dev && n_dev[0] > 0.f) ? 1.0f / n_dev[0] : scale_host;
     float s = 0.f;
     for (int i = threadIdx.x; i < n; i += 256) s += x[i];
     s = block_sum_256(s, smf);

@@ -199,12 +199,18 @@ class BUTDDetection_Eng(Engine):
             # extension: a batch already resident in HBM (prefetching loaders, bench.py); padded batches carry their counts
             feats, counts = supp_info_datas["bu_feats"], supp_info_datas.get("bu_counts")
             if self.use_graphs and counts is None and feats.is_cuda:
-                # captured graphs are keyed by the feature tensor's address: a loader's ring of a few buffers replays them,
-                # any other tensor is copied (device to device, ~7 us for 19 MB) into ONE persistent buffer first
-                seen = self.__dict__.setdefault("_feat_addrs", [])
+                # captured graphs are keyed by the feature tensor's address: a prefetching loader's ring of `depth` buffers replays
+                # them, any other tensor is copied (device to device, ~7 us for 19 MB) into ONE persistent buffer first.  The
+                # address set belongs to one loader instance: a new one (e.g. per epoch) starts it afresh
+                ring = supp_info_datas.get("bu_ring")
+                token, depth = ring if isinstance(ring, tuple) else (None, 0)
+                cache = self.__dict__.setdefault("_feat_ring", {"token": None, "addrs": set()})
+                if token is not None and cache["token"] != token:
+                    cache["token"], cache["addrs"] = token, set()
+                seen = cache["addrs"] if token is not None else ()
                 if feats.data_ptr() not in seen:
-                    if len(seen) < 3 and supp_info_datas.get("bu_ring"):
-                        seen.append(feats.data_ptr())
+                    if token is not None and len(seen) < depth:
+                        seen.add(feats.data_ptr())
                     else:
                         buf = getattr(self, "_dev_batch", None)
                         if buf is None or buf.shape != feats.shape:
@@ -396,9 +402,20 @@ class BUTDDetection_Eng(Engine):
         """Engine.py:251-272: greedy baseline (eval mode) + multinomial rollout (train mode) + CIDEr-D reward +
         REINFORCE + clamp 0.25 + Adam, all on the device; `criterion` (RewardCriterion) is implied."""
         self.model.train()
-        monitor = _monitor(dataloader, "Training Process", tqdm_visible)
         scorer = self.scorer()
+        # References of images the scorer has not seen yet (the whole first epoch) are cooked on a loader thread one batch ahead
+        # of the step that needs them (Utils.py:319-367 cooks them inside the step, for every batch of every epoch); a loader
+        # that is not a prefetcher already is wrapped in one, which also stages host-side features through pinned buffers
+        dataloader, restore = _cook_ahead(dataloader, scorer, self.device, getattr(self, "cook_ahead", True))
+        monitor = _monitor(dataloader, "Training Process", tqdm_visible)
         losses = []
+        try:
+            self._scst_steps(monitor, scorer, optimizer, rngs, tqdm_visible, losses)
+        finally:
+            restore()
+        return losses
+
+    def _scst_steps(self, monitor, scorer, optimizer, rngs, tqdm_visible, losses):
         for batch_i, (img_ids, img_tensors, img_gts, supp_info_datas) in enumerate(monitor):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
             feats = self._features(visual_inputs)
@@ -424,7 +441,6 @@ class BUTDDetection_Eng(Engine):
             losses.append(loss.clone())      # with graphs the handle returns one persistent buffer, overwritten by the next step
             if tqdm_visible:
                 monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))
-        return losses
 
     # ---- E3 -------------------------------------------------------------------------------------------------
     def eval_captions_json_generation(self, dataloader, eval_beam_size=-1, tqdm_visible=True):
@@ -433,31 +449,32 @@ class BUTDDetection_Eng(Engine):
 
     def _eval_captions_json_generation(self, dataloader, eval_beam_size=-1, tqdm_visible=True):
         """Engine.py:274-300.  Beam search accepts any batch size here (the reference's loader uses 1).
-        Data-parallel (torch.distributed initialised): every rank walks the same loader and decodes the
-        batches i with i % world == rank; the (image id, token ids) rows are all-gathered and every rank returns the
+        Data-parallel (torch.distributed initialised): rank r decodes the batches i with i % world == r (and
+        loads only those where the loader allows, _rank_batches); the (image id, token ids) rows are all-gathered and every rank returns the
         complete list in loader order -- what the corpus-level scorer after it (COCO_Eval_Utils.py:15-35) needs in one
         place; rank 0 is the one that should write / score it."""
         self.model.eval()
         print("Generating captions json for evaluation. Beam Search: %s" % (eval_beam_size != -1))
-        monitor = _monitor(dataloader, "Generating Process", tqdm_visible)
         dp = icz_dist.is_distributed()
         rank, world = icz_dist.rank(), icz_dist.world_size()
-        ids_out, rows_out, keys_out, n_seen = [], [], [], 0
-        for batch_i, (image_ids, img_tensors, supp_info_datas) in enumerate(monitor):
+        # data-parallel: this rank's batches only.  An indexable loader (list, Dataset-like: __len__ + __getitem__) or one with a
+        # shard(rank, world) method is never asked for the other ranks' batches (no feature I/O for them); any other iterable is
+        # walked in full and the foreign batches dropped
+        monitor = _monitor(_rank_batches(dataloader, rank, world) if dp else enumerate(dataloader), "Generating Process", tqdm_visible)
+        ids_out, rows_out, keys_out = [], [], []
+        for batch_i, (image_ids, img_tensors, supp_info_datas) in monitor:
             nb = len(image_ids)
-            if not dp or batch_i % world == rank:
-                visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
-                h = self._hot_handle()
-                if eval_beam_size != -1:
-                    seqs, lens = h.beam_search(self._features(visual_inputs), eval_beam_size, 50)
-                    seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
-                    rows = [seqs[i, :lens[i]] for i in range(len(lens))]
-                else:
-                    rows = list(h.greedy(self._features(visual_inputs), 20).cpu().numpy())
-                ids_out += [int(i) for i in image_ids]
-                rows_out += rows
-                keys_out += list(range(n_seen, n_seen + nb))
-            n_seen += nb
+            visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
+            h = self._hot_handle()
+            if eval_beam_size != -1:
+                seqs, lens = h.beam_search(self._features(visual_inputs), eval_beam_size, 50)
+                seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+                rows = [seqs[i, :lens[i]] for i in range(len(lens))]
+            else:
+                rows = list(h.greedy(self._features(visual_inputs), 20).cpu().numpy())
+            ids_out += [int(i) for i in image_ids]
+            rows_out += rows
+            keys_out += [(batch_i << 20) + j for j in range(nb)]      # loader order: batch index, then row
         if dp:
             ids_out, rows_out = icz_dist.gather_caption_rows(keys_out, ids_out, rows_out, self.device)
         result = []
@@ -538,6 +555,37 @@ class _on_stream:
         self.ctx.__exit__(*exc)
         self.outer.wait_stream(self.eng.stream)
         return False
+
+
+def _rank_batches(loader, rank, world):
+    """(batch index, batch) of the batches i with i % world == rank, loading as little else as the loader allows."""
+    if hasattr(loader, "shard"):
+        for i, b in loader.shard(rank, world):
+            yield i, b
+    elif hasattr(loader, "__getitem__") and hasattr(loader, "__len__"):
+        for i in range(rank, len(loader), world):
+            yield i, loader[i]
+    else:
+        for i, b in enumerate(loader):
+            if i % world == rank:
+                yield i, b
+
+
+def _cook_ahead(loader, scorer, device, enabled):
+    """-> (loader whose worker thread cooks unseen references one batch ahead, restore())."""
+    from .features import DevicePrefetcher
+    cook = lambda batch: scorer.prepare(batch[0], batch[2])
+    if not enabled:
+        return loader, lambda: None
+    if isinstance(loader, DevicePrefetcher):
+        if loader.on_batch is not None:
+            return loader, lambda: None
+        loader.on_batch = cook
+
+        def restore():
+            loader.on_batch = None
+        return loader, restore
+    return DevicePrefetcher(loader, device, on_batch=cook), lambda: None
 
 
 def _monitor(dataloader, desc, visible):

@@ -144,6 +144,9 @@ class DevicePrefetcher:
 
     def _stage(self, slot, batch):
         img_ids, supp = batch[0], batch[-1]
+        if self.store is None and isinstance(supp, dict):      # features already on the device (or not this loader's business): pass through
+            self._ready[slot] = None
+            return batch
         if self.store is not None:
             counts = self.store.counts(img_ids)
             D = self.store.D
@@ -179,7 +182,7 @@ class DevicePrefetcher:
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[slot] = ev
-        out = {"bu_feats": dev, "bu_bboxes": boxes, "bu_ring": True}      # bu_ring: one of a few reused device buffers
+        out = {"bu_feats": dev, "bu_bboxes": boxes, "bu_ring": (id(self), self.depth)}      # bu_ring: one of this loader's `depth` reused device buffers
         if min(counts) < R:
             out["bu_counts"] = counts
         return batch[:-1] + (out,)
@@ -223,12 +226,14 @@ class DevicePrefetcher:
                     raise err
                 if out is None:
                     break
-                torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
+                if self._ready[slot] is not None:
+                    torch.cuda.current_stream(self.device).wait_event(self._ready[slot])
                 yield out
-                # everything the consumer queued on its stream so far must finish before the slot is overwritten
-                done = torch.cuda.Event()
-                done.record(torch.cuda.current_stream(self.device))
-                self._free[slot] = done
+                if self._ready[slot] is not None:
+                    # everything the consumer queued on its stream so far must finish before the slot is overwritten
+                    done = torch.cuda.Event()
+                    done.record(torch.cuda.current_stream(self.device))
+                    self._free[slot] = done
                 released[slot].set()
         finally:
             stop.set()
@@ -241,3 +246,25 @@ class DevicePrefetcher:
 
     def __len__(self):
         return len(self.loader)
+
+    def shard(self, rank, world):
+        """(batch index, staged batch) for the batches i with i % world == rank (data-parallel evaluation): an indexable inner
+        loader is only asked for those, any other iterable is walked in full with the foreign batches dropped before staging."""
+        inner = self.loader
+        if hasattr(inner, "__getitem__") and hasattr(inner, "__len__"):
+            idx = list(range(rank, len(inner), world))
+            mine = (inner[i] for i in idx)
+        else:
+            idx, pairs = [], ((i, b) for i, b in enumerate(inner) if i % world == rank)
+
+            def own():
+                for i, b in pairs:
+                    idx.append(i)
+                    yield b
+            mine = own()
+        self.loader = mine
+        try:
+            for n, b in enumerate(iter(self)):
+                yield idx[n], b
+        finally:
+            self.loader = inner

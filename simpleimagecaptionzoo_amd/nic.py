@@ -229,10 +229,9 @@ class NICDecoder_Captioner(nn.Module, ScheduledSamplingState):
 
     def forward(self, visual_inputs, captions, lengths, rng=None):
         """NIC_Model.py:246-260: [0] of the result = packed logits (no autograd graph on this path)."""
-        self._seed += 1
         train = self.training
         logits = self._handle().xe_forward(self._features(visual_inputs).detach(), captions, list(lengths),
-                                           (rng or make_rng(self._seed)) if train else None, train=train, want_logits=True)
+                                           (rng or self._next_rng()) if train else None, train=train, want_logits=True)
         return (logits, None)
 
     def eval_test_image(self, visual_inputs, caption_vocab, max_len=20, eval_beam_size=-1):

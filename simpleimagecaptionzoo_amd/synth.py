@@ -39,6 +39,20 @@ def random_butd_params(R, D, H, E, A, V, device, seed=1234):
     return {k_: t.to(device=device, dtype=torch.float32).contiguous() for k_, t in p.items()}
 
 
+def random_nic_params(E, H, V, device, seed=1234):
+    """NIC decoder tensors by the reference's state_dict names, torch defaults as Models/NIC_Model.py:39-50 leaves them:
+    Embedding N(0, 1); LSTMCell and Linear U(-1/sqrt(H), 1/sqrt(H)); weight_norm g = ||v|| per row."""
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    k = 1.0 / math.sqrt(H)
+    U = lambda shape: (torch.rand(shape, generator=g) * 2 - 1) * k
+    p = {"embed.weight": torch.randn((V, E), generator=g), "lstm.weight_ih": U((4 * H, E)), "lstm.weight_hh": U((4 * H, H)),
+         "lstm.bias_ih": U((4 * H,)), "lstm.bias_hh": U((4 * H,))}
+    v = U((V, H))
+    p["predict.weight_v"], p["predict.weight_g"], p["predict.bias"] = v, v.norm(dim=1, keepdim=True), U((V,))
+    return {k_: t.to(device=device, dtype=torch.float32).contiguous() for k_, t in p.items()}
+
+
 def synthetic_references(n_img, vocab_words, seed=0, min_len=8, max_len=12):
     """5 references per image, length U{8..12}, Zipf(1.3) tokens over the vocabulary."""
     import numpy as np
