@@ -622,11 +622,19 @@ def test_fullsize_aoa_scst_step_64x20_matches_oracle():
     greedy, seq, lp = h.rollouts(feats, T, rng)
     greedy, seq, lp = greedy.cpu().numpy(), seq.cpu().numpy(), lp.cpu().numpy()
 
-    # ---- oracle (gradients only for the decoder: the only parameters in the reference's optimizer, AoA_Model.py:669-674)
-    p = {k: v.detach().cpu().clone().requires_grad_(k.startswith("decoder.")) for k, v in cap.state_dict().items()}
+    # ---- oracle (gradients only for the decoder: the only parameters in the reference's optimizer, AoA_Model.py:669-674), once in
+    #      fp32 (the reference's arithmetic: ids, log-probs, loss) and once in float64 (the truth the gradients are held to)
+    runs = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)
+        try:
+            pp = {k: v.detach().cpu().to(dt).requires_grad_(k.startswith("decoder.")) for k, v in cap.state_dict().items()}
+            runs[name] = (pp,) + tuple(oa.sample_rl(feats_c.to(dt), pp, u.astype(np.float64), masks, T, early_exit=False))
+        finally:
+            torch.set_default_dtype(torch.float32)
+    p, w_seq, w_lp = runs["f32"]
     with torch.no_grad():
         w_greedy, w_glog = oa.greedy(feats_c, p, T)
-    w_seq, w_lp = oa.sample_rl(feats_c, p, u.astype(np.float64), masks, T, early_exit=False)
     div = _first_divergence(greedy, w_greedy.numpy())
     excused = 0
     for b in np.nonzero(div >= 0)[0]:
@@ -638,7 +646,8 @@ def test_fullsize_aoa_scst_step_64x20_matches_oracle():
     assert (sdiv >= 0).sum() <= 2, "sampled: %d rows differ" % int((sdiv >= 0).sum())
     for b in np.nonzero(sdiv >= 0)[0]:              # a draw within fp32 rounding of a CDF boundary lands on the neighbouring token
         assert abs(int(seq[b, sdiv[b]]) - int(w_seq[b, sdiv[b]])) <= 2, (b, seq[b], w_seq[b])
-    ok = sdiv < 0
+    ok = (sdiv < 0) & (runs["f64"][1].numpy() == seq).all(1)
+    assert ok.sum() >= B - 4
     np.testing.assert_allclose(lp[ok], w_lp.detach().numpy()[ok], atol=1e-4)
 
     # ---- reward: bit-exact on the ids the device produced
@@ -650,23 +659,27 @@ def test_fullsize_aoa_scst_step_64x20_matches_oracle():
                                        oc.DocFreq(dfd["document_frequency"], dfd["ref_len"]))
     assert np.array_equal(reward.cpu().numpy(), w_reward)
 
-    # ---- REINFORCE loss and decoder gradients
+    # ---- REINFORCE loss and decoder gradients: |HIP - f64| <= 2 |torch32 - f64| + 2e-4 max per unit (tests/test_gpu_round3.py)
+    from test_gpu_round3 import check_grads_against_float64
     rw = w_reward.copy()
     rw[~ok] = 0.0
     rw = rw + rs.randn(B, 1).astype(np.float32) * ok[:, None].astype(np.float32)
     grads = h.new_grads()
     loss, msum = h.sample_backward(torch.tensor(rw, device=dev), grads)
-    w_seq_m = torch.from_numpy(np.where(ok[:, None], w_seq.numpy(), seq))
-    w_loss = ob.reward_criterion(w_lp, w_seq_m, torch.from_numpy(rw))
-    w_loss.backward()
-    assert abs(loss.item() - w_loss.item()) < 1e-4, (loss.item(), w_loss.item())
-    for k, gt in grads.items():
-        if k == "decoder.aoa_block.linear_K.bias":
-            continue                                   # identically zero (softmax shift invariance)
-        want = p[k].grad.numpy()
-        scale = max(1e-6, float(np.abs(want).max()))
-        err = float(np.abs(gt.cpu().numpy() - want).max())
-        assert err <= 3e-4 * scale + 1e-7, (k, err, scale)
+    gsets = {}
+    for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
+        torch.set_default_dtype(dt)
+        try:
+            pp, ws, wl = runs[name]
+            w_seq_m = torch.from_numpy(np.where(ok[:, None], ws.numpy(), seq))
+            w_loss = ob.reward_criterion(wl, w_seq_m, torch.from_numpy(rw).to(dt))
+            w_loss.backward()
+            gsets[name] = {k: v.grad.numpy() for k, v in pp.items() if v.grad is not None}
+            if name == "f32":
+                assert abs(loss.item() - w_loss.item()) < 1e-4, (loss.item(), w_loss.item())
+        finally:
+            torch.set_default_dtype(torch.float32)
+    check_grads_against_float64(grads, gsets["f32"], gsets["f64"], None, skip=("decoder.aoa_block.linear_K.bias",))
 
 
 @pytest.mark.parametrize("regime", ["nat", "end_biased"])
