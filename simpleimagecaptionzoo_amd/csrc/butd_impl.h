@@ -129,7 +129,9 @@ struct Butd {
     hipStream_t low_st = nullptr;        // lowest-priority stream for work overlapped with the BPTT chain
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     icz_grad_ready_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // DP overlap hook (icz_butd_set_grad_callback)
-    int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st);
+    int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st,
+                             int phases = 0xF, bool fire_cb = true);
+    bool bptt_joined = false;            // the predict-gradient branch has been joined (bptt phases)
 
     // beam search (butd_beam.hip)
     BeamBuf bm;
@@ -159,7 +161,7 @@ struct Butd {
     int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
     int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);
     int colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st);
-    int bptt(const icz_butd_params& G, hipStream_t st);
+    int bptt(const icz_butd_params& G, hipStream_t st, int phases = 0xF, bool fire_cb = true);
 };
 
 void gemm_set_capturing(bool on);

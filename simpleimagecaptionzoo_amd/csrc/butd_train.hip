@@ -250,25 +250,37 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     mode = 0;   // the saved logits are consumed
     if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));      // outside the captured graph
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
-    // the DP hook must fire on every call (a replayed graph would not call it): backward is enqueued eagerly then
-    if (explicit_rng || !use_graphs || grad_cb) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
+    if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
     std::vector<uintptr_t> key = {3, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)mask_sum_out, (uintptr_t)cur_B, (uintptr_t)cur_T,
                                   (uintptr_t)cur_feats, (uintptr_t)cur_seq, (uintptr_t)cur_logp};
     const float* const* gp = reinterpret_cast<const float* const*>(G);
     for (size_t i = 0; i < sizeof(icz_butd_params) / sizeof(float*); ++i) key.push_back((uintptr_t)gp[i]);
     const icz_butd_params Gc = *G;
-    return run_cached(key, st, [&](hipStream_t s) { return sample_backward_impl(reward, Gc, loss_out, mask_sum_out, s); });
+    if (!grad_cb) return run_cached(key, st, [&](hipStream_t s) { return sample_backward_impl(reward, Gc, loss_out, mask_sum_out, s); });
+    // The DP hook must fire on every call (a replayed graph would not call it): the backward is cut at the three points where a
+    // gradient group is complete, every piece is its own captured graph, and the hook is called between the replays -- the
+    // all-reduce of a group then starts beside the remaining pieces exactly as in the eager form.
+    for (int ph = 0; ph < 4; ++ph) {
+        std::vector<uintptr_t> k2 = key;
+        k2.push_back(0x100 + ph);
+        ICZ_TRY(run_cached(k2, st, [&](hipStream_t s) { return sample_backward_impl(reward, Gc, loss_out, mask_sum_out, s, 1 << ph, false); }));
+        if (ph < 3) grad_cb(grad_cb_user, ph);
+    }
+    return ICZ_OK;
 }
 
-int Butd::sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st) {
+int Butd::sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st,
+                               int phases, bool fire_cb) {
     const int B = cur_B, T = cur_T;
     const int Vp = round4(dims.V);
-    hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum_global,
-                       tb.coef, loss_out, mask_sum_out);
-    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
-                       tb.draw, tb.lse, tb.coef, B, T);
-    ICZ_CHECK_HIP(hipGetLastError());
-    return bptt(G, st);
+    if (phases & 1) {
+        hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum_global,
+                           tb.coef, loss_out, mask_sum_out);
+        hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
+                           tb.draw, tb.lse, tb.coef, B, T);
+        ICZ_CHECK_HIP(hipGetLastError());
+    }
+    return bptt(G, st, phases, fire_cb);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -440,7 +452,11 @@ int Butd::colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t 
     return ICZ_OK;
 }
 
-int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
+// phases: bit 0 = predict layer + reverse-time loop, bit 1 = embedding and TD-LSTM weight gradients, bit 2 = LM-LSTM weight
+// gradients, bit 3 = attention block, biases, joins.  After each of the first three the corresponding gradient group is complete
+// in stream order (icz_butd_set_grad_callback); fire_cb = false leaves the callbacks to the caller, which replays every phase
+// as its own captured graph and calls them in between.
+int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_cb) {
     const int B = cur_B, T = cur_T;
     const int H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
     const int Vp = round4(V);
@@ -459,6 +475,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
     }
     hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
+    if (phases & 1) {
+    bptt_joined = false;
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
     {
@@ -588,12 +606,14 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         cur ^= 1;
     }
 
-    bool joined = false;
     if (grad_cb) {      // the predict branch has long finished beside the loop: join it now so that its gradients can be reduced
         ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
-        joined = true;
-        grad_cb(grad_cb_user, 0);
+        bptt_joined = true;
     }
+    }   // phase 0
+    if ((phases & 1) && grad_cb && fire_cb) grad_cb(grad_cb_user, 0);
+    const int ldtd = H + D + E, ldlm = D + H;
+    if (phases & 2) {
     // ---- embedding gradient: dEmb = dG_td . W_ih_td[:, H+D:] for all steps, then ordered scatter
     {
         GemmArgs g = {};
@@ -610,17 +630,20 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
-    const int ldtd = H + D + E, ldlm = D + H;
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st));                 // h2_{t-1}
     hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)B * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)B * 4 * H, tb.dGsum);
     ICZ_TRY(wgrad(tb.dGsum, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));               // mean features
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st));         // embedding
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st));                     // h1_{t-1}
-    if (grad_cb) grad_cb(grad_cb_user, 1);
+    }   // phase 1
+    if ((phases & 2) && grad_cb && fire_cb) grad_cb(grad_cb_user, 1);
+    if (phases & 4) {
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st));                 // ctx_t
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st));         // h1_t
     ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
-    if (grad_cb) grad_cb(grad_cb_user, 2);
+    }   // phase 2
+    if ((phases & 4) && grad_cb && fire_cb) grad_cb(grad_cb_user, 2);
+    if (phases & 8) {
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
     {   // d enc_ctx (sum over time) and the affine-weight partials, from the ds_t recorded by the loop
         AttBwdDencArgs ea = {enc_ctx, tb.dec, tb.dS, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
@@ -655,7 +678,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st) {
         add(tb.dWaff, A, P.affine_v, P.affine_g, n_aff, G.affine_v, G.affine_g, 1, A);
         hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
     }
-    if (!joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
+    if (!bptt_joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
+    }   // phase 3
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
