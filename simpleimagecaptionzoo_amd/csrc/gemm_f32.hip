@@ -933,7 +933,12 @@ static bool nt_x3big(const GemmArgs& a) {
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return false;
     const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);
-    if (a.nseg == 1) return tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128;
+    if (a.nseg == 1) {
+        if (tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128) return true;
+        // few tiles but many rows (dec_att of a beam step: 640 x 1024 x 1024 = 40 tiles): 256-deep splits still fill most of the chip,
+        // and the fp32 kernel needs 25 us for it (round 2's beam profile)
+        return a.M >= 256 && tiles * (a.seg[0].K / 256) >= 128;
+    }
     int tot = 0;                                   // several segments: their concatenation is split as well (gemm_pick_split)
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / 128;
     return tiles * (tot / 8 > 0 ? tot / 8 : 1) >= 128;
@@ -960,6 +965,7 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
         const int tot = a.seg[0].K / 128;
         int s = 896 / tiles;
         if (s > tot / 5) s = tot / 5;
+        if (tiles < 128 && tot >= 4) s = (tot / 2 < 320 / tiles) ? tot / 2 : 320 / tiles;      // few tiles: splits of two chunks and more
         if (s < 1) s = 1;
         return cdiv(tot, cdiv(tot, s));
     }
