@@ -1,7 +1,7 @@
 #!/bin/bash
-# rocprofv3 summaries of the bench command -> gpurun_out/prof_r02/ (copy what is to be judged into profiles/)
+# rocprofv3 summaries of the bench command -> gpurun_out/prof_r03/ (copy what is to be judged into profiles/)
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
-OUT=$ROOT/gpurun_out/prof_r02
+OUT=$ROOT/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/p_stats /tmp/p_fetch /tmp/p_write
