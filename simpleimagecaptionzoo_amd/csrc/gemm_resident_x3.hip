@@ -35,7 +35,10 @@
 //     2.7 k: a compute unit's memory pipeline accepts ~14-16 bytes per cycle whatever the bytes are, so activation bytes cost
 //     as much as weight bytes.  Tried in round 3 without gain: whole 128-byte lines per activation load instruction (kept, neutral),
 //     XCD-aware placement of the workgroups that share an activation block (prologue unchanged, K = 4096 main loop slower: L2
-//     channel conflicts), non-temporal weight loads (+-3 %), three stages per k range where that fills the chip (see "Decomposition");
+//     channel conflicts), non-temporal weight loads (+-3 %), three stages per k range where that fills the chip (see "Decomposition"),
+//     and staging the activations one 64-deep stage at a time beside the MFMAs of the first column tile (only 16 KB + the first
+//     step's weights before the first MFMA: the barrier came 3.5 k cycles earlier, the first tile's steps took 4.4 k longer -- the
+//     bytes a CU has to pull are the same, and ~4 k cycles pass between kernel entry and the 16th load instruction whatever is loaded);
 //   * what did not help in round 2 (kept out): 8 waves, 256-column tiles (spills), bf16 planes written by the producers
 //     (6 instead of 4 bytes per element through the same pipeline), weights through LDS.
 #include <stdlib.h>
@@ -167,15 +170,15 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
             });
         });
         if constexpr (STAMPS) { __builtin_amdgcn_sched_barrier(0); stamp(20); __builtin_amdgcn_sched_barrier(0); }
-        // the weights of the first D - 1 pipeline steps go out now: their HBM latency passes behind the split below
-        sk_static_for<0, D - 1>([&](auto ic) {
-            point_w(ic);
-            sk_static_for<0, LW>([&](auto lc) { load_w1(ic, lc); });
-        });
+        // the first step's weights go out now: their HBM latency passes behind the split below.  The second step's follow AFTER the
+        // split (round 3: with both up front, 128 KB of loads stood between kernel entry and the first MFMA; deferring 32 KB of them
+        // took ~0.5 us off every launch: greedy step 96.9 -> 95.4 us, SCST rollouts and backward -1 % each, same box)
+        point_w(std::integral_constant<int, 0>{});
+        sk_static_for<0, LW>([&](auto lc) { load_w1(std::integral_constant<int, 0>{}, lc); });
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (STAMPS) {
             stamp(21);
-            asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+            asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
             stamp(22);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -196,6 +199,12 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
         });
     }
 
+    __builtin_amdgcn_sched_barrier(0);
+    sk_static_for<1, D - 1>([&](auto ic) {
+        point_w(ic);
+        sk_static_for<0, LW>([&](auto lc) { load_w1(ic, lc); });
+    });
+    __builtin_amdgcn_sched_barrier(0);
     stamp(1);
     __syncthreads();                        // the planes are complete (the only barrier of the kernel)
     stamp(2);
