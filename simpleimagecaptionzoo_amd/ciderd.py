@@ -18,6 +18,7 @@ import numpy as np
 import torch
 
 from ._lib import check, lib, ptr, stream_ptr
+from .features import wait_event as _wait
 
 _FNV_OFF, _FNV_PRIME = np.uint32(2166136261), np.uint32(16777619)
 
@@ -222,9 +223,11 @@ class CiderDReward:
         self._n_img = self._n_ref = self._n_ent = 0
         self._slot = {}                      # image id -> store row
         z = lambda n, dt, *rest: torch.zeros((n,) + rest, dtype=dt, device=dev)
-        self._st = {"irp": z(1025, torch.int32), "rep": z(8193, torch.int32), "key": z(1 << 17, torch.int32, 4),
-                    "ord": z(1 << 17, torch.int32), "w": z(1 << 17, torch.float64), "norm": z(8192, torch.float64, 4),
-                    "len": z(8192, torch.int32)}
+        # sized for ~20 k images up front (5 references of ~40 n-gram entries each: 130 MB of a 288 GB device); a growth step
+        # re-allocates and copies three to seven arrays (tens of ms through hipMalloc), so they are made rare: x4 per step
+        self._st = {"irp": z((1 << 15) + 1, torch.int32), "rep": z((1 << 17) + 1, torch.int32), "key": z(1 << 22, torch.int32, 4),
+                    "ord": z(1 << 22, torch.int32), "w": z(1 << 22, torch.float64), "norm": z(1 << 17, torch.float64, 4),
+                    "len": z(1 << 17, torch.int32)}
         self._idx_ring, self._idx_ev, self._idx_i, self._idx_dev = [], [], 0, {}
 
     def _grow(self, name, need):
@@ -233,7 +236,7 @@ class CiderDReward:
             return
         cap = t.shape[0]
         while cap < need:
-            cap *= 2
+            cap *= 4
         new = torch.zeros((cap,) + tuple(t.shape[1:]), dtype=t.dtype, device=t.device)
         new[:t.shape[0]] = t
         self._st[name] = new
@@ -302,7 +305,7 @@ class CiderDReward:
             cap = max(1 << 20, 1 << (total - 1).bit_length())
             host, dev, ev = torch.empty(cap, dtype=torch.uint8).pin_memory(), torch.empty(cap, dtype=torch.uint8, device=self.device), None
         if ev is not None:
-            ev.synchronize()                                        # the copy issued len(ring) blocks ago has left this buffer
+            _wait(ev)                                               # the copy issued len(ring) blocks ago has left this buffer
         hv, off, views = host.numpy(), 0, []
         for name, a, at in parts:
             a = np.ascontiguousarray(a)
@@ -339,7 +342,7 @@ class CiderDReward:
             self._idx_ev = [None] * 8
         k = self._idx_i = (self._idx_i + 1) % 8
         if self._idx_ev[k] is not None:
-            self._idx_ev[k].synchronize()                           # the copy issued 8 batches ago has left this buffer
+            _wait(self._idx_ev[k])                                  # the copy issued 8 batches ago has left this buffer
         host = self._idx_ring[k]
         host.numpy()[:B] = rows
         dev = self._idx_dev.get(B)

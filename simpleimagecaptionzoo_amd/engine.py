@@ -20,6 +20,7 @@ from ._lib import BUTD_PARAM_KEYS, check, lib, ptr, stream_ptr
 from .captioner import BUTDDetection_Captioner
 from .ciderd import CiderDReward
 from . import dist as icz_dist
+from .features import wait_event
 
 
 class FusedAdam:
@@ -233,7 +234,7 @@ class BUTDDetection_Eng(Engine):
             self._pinned = torch.zeros(need, dtype=torch.float32).pin_memory()
             self._dev_feats = torch.empty(need, dtype=torch.float32, device=self.device)
         if getattr(self, "_h2d_done", None) is not None:
-            self._h2d_done.synchronize()         # the previous batch's copy has left the pinned buffer
+            wait_event(self._h2d_done)           # the previous batch's copy has left the pinned buffer
         host = self._pinned[:need].view(B, max_len, D)
         hv = host.numpy()
         for i, f in enumerate(bu_feats):
@@ -406,7 +407,8 @@ class BUTDDetection_Eng(Engine):
         # References of images the scorer has not seen yet (the whole first epoch) are cooked on a loader thread one batch ahead
         # of the step that needs them (Utils.py:319-367 cooks them inside the step, for every batch of every epoch); a loader
         # that is not a prefetcher already is wrapped in one, which also stages host-side features through pinned buffers
-        dataloader, restore = _cook_ahead(dataloader, scorer, self.device, getattr(self, "cook_ahead", True))
+        dataloader, restore = _cook_ahead(dataloader, scorer, self.device, getattr(self, "cook_ahead", True),
+                                          self.__dict__.setdefault("_cook_cache", {}))
         monitor = _monitor(dataloader, "Training Process", tqdm_visible)
         losses = []
         try:
@@ -571,8 +573,9 @@ def _rank_batches(loader, rank, world):
                 yield i, b
 
 
-def _cook_ahead(loader, scorer, device, enabled):
-    """-> (loader whose worker thread cooks unseen references one batch ahead, restore())."""
+def _cook_ahead(loader, scorer, device, enabled, cache=None):
+    """-> (loader whose worker thread cooks unseen references one batch ahead, restore()).  `cache` (a dict the Engine keeps) holds
+    the wrapping prefetcher across epochs: its pinned ring, copy stream and thread pool are set up once."""
     from .features import DevicePrefetcher
     cook = lambda batch: scorer.prepare(batch[0], batch[2])
     if not enabled:
@@ -585,7 +588,16 @@ def _cook_ahead(loader, scorer, device, enabled):
         def restore():
             loader.on_batch = None
         return loader, restore
-    return DevicePrefetcher(loader, device, on_batch=cook), lambda: None
+    pf = cache.get("pf") if cache is not None else None
+    if pf is None:
+        pf = DevicePrefetcher(loader, device, on_batch=cook)
+        if cache is not None:
+            cache["pf"] = pf
+    pf.loader, pf.on_batch = loader, cook
+
+    def release():
+        pf.loader = None            # do not keep the caller's loader alive between epochs
+    return pf, release
 
 
 def _monitor(dataloader, desc, visible):
