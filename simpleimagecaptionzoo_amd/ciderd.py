@@ -179,8 +179,10 @@ class ReferenceCooker:
 class CiderDReward:
     """Device-resident CIDEr-D scorer for SCST (arguments as ReferenceCooker's)."""
 
-    def __init__(self, document_frequency, ref_len, word2ix, device="cuda:0", sigma=6.0):
+    def __init__(self, document_frequency, ref_len, word2ix, device="cuda:0", sigma=6.0, store_images=1 << 15):
+        """store_images: images the device-resident reference store holds before its first growth step."""
         self.device = torch.device(device)
+        self._store_images = max(16, int(store_images))
         self.cooker = ReferenceCooker(document_frequency, ref_len, word2ix)
         self.V = self.cooker.V
         self._keys = torch.from_numpy(self.cooker.keys_host).to(self.device)
@@ -223,11 +225,13 @@ class CiderDReward:
         self._n_img = self._n_ref = self._n_ent = 0
         self._slot = {}                      # image id -> store row
         z = lambda n, dt, *rest: torch.zeros((n,) + rest, dtype=dt, device=dev)
-        # sized for ~20 k images up front (5 references of ~40 n-gram entries each: 130 MB of a 288 GB device); a growth step
-        # re-allocates and copies three to seven arrays (tens of ms through hipMalloc), so they are made rare: x4 per step
-        self._st = {"irp": z((1 << 15) + 1, torch.int32), "rep": z((1 << 17) + 1, torch.int32), "key": z(1 << 22, torch.int32, 4),
-                    "ord": z(1 << 22, torch.int32), "w": z(1 << 22, torch.float64), "norm": z(1 << 17, torch.float64, 4),
-                    "len": z(1 << 17, torch.int32)}
+        # sized for `store_images` images up front (default 32 k: 5 references of ~25 n-gram entries each, 130 MB of a 288 GB
+        # device); a growth step re-allocates and copies three to seven arrays (tens of ms through hipMalloc), so they are made
+        # rare: x4 per step
+        n = self._store_images
+        self._st = {"irp": z(n + 1, torch.int32), "rep": z(4 * n + 1, torch.int32), "key": z(128 * n, torch.int32, 4),
+                    "ord": z(128 * n, torch.int32), "w": z(128 * n, torch.float64), "norm": z(4 * n, torch.float64, 4),
+                    "len": z(4 * n, torch.int32)}
         self._idx_ring, self._idx_ev, self._idx_i, self._idx_dev = [], [], 0, {}
 
     def _grow(self, name, need):

@@ -103,3 +103,60 @@ def test_coco_eval_end_to_end(tmp_path):
     gts = tokenize(load_annotations(str(p)))
     want, _ = corpus_cider({i: gts[i] for i in (11, 12, 13)}, {r["image_id"]: [r["caption"]] for r in results})
     assert got == want and got > 0
+
+
+def test_reference_store_growth_and_loader_thread_cooking():
+    """The device-resident reference store under what the Engine does in a first epoch: a loader thread cooks the references of
+    batch i + 1 (CiderDReward.prepare) while the main thread scores batch i, the store starts tiny (16 images) and grows x4
+    several times, batches repeat images and arrive in another order -- scores stay bit-exact against the oracle throughout."""
+    import threading
+    from oracle import ciderd as oc
+    from simpleimagecaptionzoo_amd.ciderd import CiderDReward
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    V, B, T, NB = 503, 24, 20, 12
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    dfd = document_frequency(synthetic_references(300, words, seed=0))
+    scorer = CiderDReward(dfd["document_frequency"], dfd["ref_len"], vocab.word2ix, "cuda", store_images=16)
+    docfreq = oc.DocFreq(dfd["document_frequency"], dfd["ref_len"])
+    ix2word = dict(enumerate(words))
+    rs = np.random.RandomState(1)
+    batches = []
+    for i in range(NB):
+        refs = synthetic_references(B, words, seed=100 + i)
+        ids = [1000 * i + j for j in range(B)]
+        gts = {ids[j]: refs[j] for j in range(B)}
+        if i >= 2:                                   # a few images of an earlier batch again, in another position
+            old_ids, old_gts = batches[i - 2][0], batches[i - 2][1]
+            for j in (3, 11):
+                ids[j] = old_ids[j + 1]
+                gts[ids[j]] = old_gts[ids[j]]
+            gts = {k: gts[k] for k in ids}
+        gen = rs.randint(0, V, size=(B, T)).astype(np.int64)
+        gre = rs.randint(0, V, size=(B, T)).astype(np.int64)
+        for b in range(B):                           # some hypotheses close to a reference
+            if b % 3 == 0:
+                row = [vocab.word2ix[w] for w in gts[ids[b]][0].split()][:T]
+                gen[b, :len(row)] = row
+                gen[b, len(row):] = 0
+        batches.append((ids, gts, gen, gre))
+    err = []
+
+    def loader():
+        try:
+            for ids, gts, _, _ in batches:
+                scorer.prepare(ids, gts)
+        except BaseException as e:      # surfaced below
+            err.append(e)
+    th = threading.Thread(target=loader)
+    th.start()
+    for ids, gts, gen, gre in batches:
+        r = scorer.reward(torch.tensor(gen), torch.tensor(gre), gts, ids).cpu().numpy()
+        want = oc.self_critical_reward(gen, gre, gts, ids, ix2word, docfreq)
+        assert np.array_equal(r, want)
+    th.join()
+    assert not err, err
+    assert scorer._n_img == len({i for b in batches for i in b[0]}) and scorer._st["irp"].shape[0] > 17      # it did grow
+    assert not scorer._blocks and not scorer._pending
+    scorer.close()
