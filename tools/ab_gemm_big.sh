@@ -1,6 +1,6 @@
 #!/bin/bash
 # same-box A/B of the 128 x 128 split-precision GEMM shapes: tools/ab_gemm_big.sh "VAR=val" "VAR=val" ...
-ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd $ROOT
 for v in "$@"; do
   echo "== $v"

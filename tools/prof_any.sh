@@ -1,13 +1,13 @@
 #!/bin/bash
-# usage: tools/prof_any.sh <tag> <python script and args...>  -> gpurun_out/prof_r02/<tag>_kernel_stats.csv + top kernels on stdout
+# usage: tools/prof_any.sh <tag> <python script and args...>  -> gpurun_out/prof_r03/<tag>_kernel_stats.csv + top kernels on stdout
 tag=$1; shift
-ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_r03
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rm -rf /tmp/p_$tag
-script=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/p_$tag -- python3 $ROOT/$script "$@" > $OUT/${tag}.log 2> $OUT/${tag}.err
-cp $(find /tmp/p_$tag -name '*kernel_stats.csv' | head -1) $OUT/${tag}_kernel_stats.csv
+PD=$(mktemp -d /tmp/prof_XXXXXX)
+script=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d $PD -- python3 $ROOT/$script "$@" > $OUT/${tag}.log 2> $OUT/${tag}.err
+cp $(find $PD -name '*kernel_stats.csv' | head -1) $OUT/${tag}_kernel_stats.csv
 tail -3 $OUT/${tag}.log
 python3 - $OUT/${tag}_kernel_stats.csv <<'PY'
 import csv, sys

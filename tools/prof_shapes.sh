@@ -1,11 +1,10 @@
 #!/bin/bash
 # usage: tools/prof_shapes.sh <tag> "M N K ns" ...   -> prints avg kernel duration of the GEMM kernels per shape
 tag=$1; shift
-ROOT=${GRAFT_REPO_ROOT:-/root/repo}
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 cd /tmp && export TMPDIR=/tmp
 for shape in "$@"; do
-  d=/tmp/prof_${tag}_$(echo $shape | tr ' ' '_')
-  rm -rf $d
+  d=$(mktemp -d /tmp/prof_XXXXXX)
   rocprofv3 --kernel-trace --stats --output-format csv -d $d -- python3 $ROOT/tools/perf_skinny_one.py $shape > /dev/null 2>&1
   f=$(find $d -name '*kernel_stats.csv' | head -1)
   echo "== $tag shape $shape"
