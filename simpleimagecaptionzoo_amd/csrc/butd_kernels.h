@@ -624,6 +624,56 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
     *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
+// Greedy token choice of a decoder step in ONE launch (round 3), one 1024-thread workgroup per row like the multinomial kernel:
+// logits = sum of the predict GEMM's split-K slabs + bias (never written back: greedy decoding keeps no logits), argmax with ties to
+// the lowest index (torch.max, :183), the id recorded, and the next step's input embedding (Embedding -> ReLU, eval mode) gathered
+// by the same workgroup.  Replaces argmax_part_kernel + embed_argmax_kernel (5.6 + 4.8 us) at 33 - 64 rows; 64 workgroups leave
+// the other three quarters of the chip to the sampled chain that runs beside the greedy one in an SCST step.
+__global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, int V, int ldl, int ns, size_t slab_stride,
+                                                            const float* __restrict__ bias, const float* __restrict__ table, int E,
+                                                            float* __restrict__ emb, int64_t* __restrict__ it_next,
+                                                            int64_t* __restrict__ ids_out, int ids_stride, int t) {
+    __shared__ float sv[16];
+    __shared__ int si[16];
+    const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* l = logits + (size_t)row * ldl;
+    float best = -INFINITY;
+    int bi = 0x7fffffff;
+    const bool vec = ((ldl | (int)(slab_stride & 3)) & 3) == 0 && (((uintptr_t)logits | (uintptr_t)bias) & 15) == 0;
+    const int Vv = vec ? (V & ~3) : 0;
+    for (int v = tid * 4; v < Vv; v += 4096) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(l + v);
+        for (int z = 1; z < ns; ++z) x += *reinterpret_cast<const f32x4*>(l + (size_t)z * slab_stride + v);
+        if (bias) x += *reinterpret_cast<const f32x4*>(bias + v);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (x[j] > best) { best = x[j]; bi = v + j; }
+    }
+    for (int v = Vv + tid; v < V; v += 1024) {
+        float x = l[v];
+        for (int z = 1; z < ns; ++z) x += l[(size_t)z * slab_stride + v];
+        if (bias) x += bias[v];
+        if (x > best || (x == best && v < bi)) { best = x; bi = v; }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) argmax_combine(best, bi, __shfl_xor(best, o, 64), __shfl_xor(bi, o, 64));
+    if (lane == 0) { sv[wave] = best; si[wave] = bi; }
+    __syncthreads();
+    best = sv[0]; bi = si[0];
+#pragma unroll
+    for (int w = 1; w < 16; ++w) argmax_combine(best, bi, sv[w], si[w]);
+    if (tid == 0) {
+        it_next[row] = bi;
+        if (ids_out) ids_out[(size_t)row * ids_stride + t] = bi;
+    }
+    for (int e = tid * 4; e < E; e += 4096) {
+        f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)bi * E + e);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+        *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
+    }
+}
+
 __global__ void set_scalars_kernel(uint64_t* seed_p, uint64_t seed, float* f_p, float f) {
     if (seed_p) *seed_p = seed;
     if (f_p) *f_p = f;
