@@ -198,7 +198,11 @@ class CiderDReward:
         self._pending = {}                   # image id -> its block, until the block is in the store
         self._cooking = set()                # image ids being cooked right now (by the loader's worker thread or the main thread)
         self._lock = threading.Lock()        # guards _slot / _blocks / _pending / _cooking: prepare() runs on a loader thread beside _append()
-        self._up_ring, self._up_i = [(None, None, None)] * 4, 0       # pinned / device staging of the block uploads
+        # pinned / device staging of the block uploads, allocated here (a pinned allocation costs milliseconds and synchronises the
+        # device: not something for the first training steps)
+        self._up_ring, self._up_i = [], 0
+        for _ in range(4):
+            self._up_ring.append((torch.empty(1 << 20, dtype=torch.uint8).pin_memory(), torch.empty(1 << 20, dtype=torch.uint8, device=self.device), None))
         self._store_init()
 
     def close(self):
