@@ -252,3 +252,64 @@ def test_host_reference_cooker_matches_the_python_statement():
         for x, y in zip(a, b):
             assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
     assert any((a[1] >= 300).any() for a in want)          # private ids of out-of-vocabulary words are in play
+
+
+def test_rank_batches_shards_without_touching_foreign_batches():
+    """Data-parallel evaluation (engine._rank_batches): rank r gets the batches i with i % world == r -- an indexable loader
+    is only asked for those (no feature I/O for the others), a loader with shard() is delegated to, any other iterable is
+    walked.  Together the ranks cover every batch exactly once, with the loader's own indices (the all-gather sorts by them)."""
+    from simpleimagecaptionzoo_amd.engine import _rank_batches
+
+    class Indexable:
+        def __init__(self, n):
+            self.n, self.touched = n, []
+
+        def __len__(self):
+            return self.n
+
+        def __getitem__(self, i):
+            self.touched.append(i)
+            return ("batch", i)
+
+    class Sharded:
+        def shard(self, rank, world):
+            return iter([(rank, "mine")])
+
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            ld = Indexable(11)
+            got = list(_rank_batches(ld, r, world))
+            assert [i for i, _ in got] == list(range(r, 11, world)) and all(b == ("batch", i) for i, b in got)
+            assert ld.touched == list(range(r, 11, world))            # nothing else was loaded
+            seen += [i for i, _ in got]
+        assert sorted(seen) == list(range(11))
+    assert list(_rank_batches(Sharded(), 1, 2)) == [(1, "mine")]
+    gen = (("g", i) for i in range(7))                                # a plain iterable: walked in full, foreign batches dropped
+    assert list(_rank_batches(gen, 1, 3)) == [(1, ("g", 1)), (4, ("g", 4))]
+
+
+def test_cooked_reference_blocks_equal_the_per_image_form():
+    """ReferenceCooker.cook_images(as_block=True) -- what the device store appends since round 3 -- holds exactly the per-image
+    arrays of the classic form, concatenated, with reference-level entry pointers."""
+    from simpleimagecaptionzoo_amd.ciderd import ReferenceCooker
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    vocab = synthetic_vocab(211)
+    words = [vocab.ix2word[i] for i in range(211)]
+    dfd = document_frequency(synthetic_references(60, words, seed=3))
+    ck = ReferenceCooker(dfd["document_frequency"], dfd["ref_len"], vocab.word2ix)
+    refs = synthetic_references(9, words, seed=4)
+    refs = [list(refs[i]) for i in range(9)]
+    refs[2] = refs[2][:2] + ["zzz unknown words here"]               # out-of-vocabulary words, fewer references
+    per = ck.cook_images(refs)
+    blk = ck.cook_images(refs, as_block=True)
+    assert blk["nref"].tolist() == [len(r) for r in refs]
+    assert np.array_equal(blk["key"], np.concatenate([p[1] for p in per])) and np.array_equal(blk["ord"], np.concatenate([p[2] for p in per]))
+    assert np.array_equal(blk["w"], np.concatenate([p[3] for p in per])) and np.array_equal(blk["norm"], np.concatenate([p[4] for p in per]))
+    assert np.array_equal(blk["len"], np.concatenate([p[5] for p in per]))
+    ends, e0 = [], 0
+    for p in per:
+        ends += (e0 + p[0][1:]).tolist()
+        e0 += int(p[0][-1])
+    assert blk["ep"][0] == 0 and blk["ep"][1:len(ends) + 1].tolist() == ends
