@@ -632,7 +632,7 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
 __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, int V, int ldl, int ns, size_t slab_stride,
                                                             const float* __restrict__ bias, const float* __restrict__ table, int E,
                                                             float* __restrict__ emb, int64_t* __restrict__ it_next,
-                                                            int64_t* __restrict__ ids_out, int ids_stride, int t) {
+                                                            int64_t* __restrict__ ids_out, int ids_stride, int t, int relu = 1) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -669,7 +669,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
     for (int e = tid * 4; e < E; e += 4096) {
         f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)bi * E + e);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+        for (int j = 0; j < 4; ++j) x[j] = relu ? fmaxf(x[j], 0.f) : x[j];      // NIC embeds without the ReLU (NIC_Model.py:112)
         *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
     }
 }

@@ -152,12 +152,13 @@ int Nic::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
         int pns = 1;
         ICZ_TRY(token_step(B, it, t > 0, h[cur], c[cur], h[cur ^ 1], c[cur ^ 1], emb, nullptr, hdrop, logits, off, st, &pns));
         if (pns > 1)
-            hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, (const float*)ws, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx,
-                               pns, (size_t)B * Vp, (const float*)P.predict_b);
-        else
+            hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, (const float*)ws, dims.V, Vp, pns, (size_t)B * Vp,
+                               (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, T, t, 0);
+        else {
             hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
-        hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
-                           P.embed_weight, dims.E, emb, it, ids_out, T, t, 0);
+            hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
+                               P.embed_weight, dims.E, emb, it, ids_out, T, t, 0);
+        }
         cur ^= 1;
     }
     ICZ_CHECK_HIP(hipGetLastError());
