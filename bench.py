@@ -589,10 +589,19 @@ def extra_rates(eng, opt, words, device, B, steps):
     out = {}
     scorer = eng.scorer()
 
+    hot = make_batches(6, B, words, device, 0, id_base=40_000_000)
+    for bt in hot:
+        scorer.preload(bt[2])
+
     def timed(loader_fn, n):
+        # six warm steps right in front of the timed epoch, then only a synchronize: the legs below are prepared on the host for
+        # hundreds of ms (random features, pinned copies) while the GPU idles and drops its clocks; a 10-step epoch started from
+        # there took 64 or 108 ms at random (tools/perf_cold2.py), 62 - 66 ms every time without the idle gap
+        loader = loader_fn()
+        eng.SCST_training_epoch(hot, opt, None, tqdm_visible=False)
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        eng.SCST_training_epoch(loader_fn(), opt, None, tqdm_visible=False)
+        eng.SCST_training_epoch(loader, opt, None, tqdm_visible=False)
         torch.cuda.synchronize()
         return (time.perf_counter() - t1) / n
 

@@ -201,7 +201,7 @@ class CiderDReward:
         # pinned / device staging of the block uploads, allocated here (a pinned allocation costs milliseconds and synchronises the
         # device: not something for the first training steps)
         self._up_ring, self._up_i = [], 0
-        for _ in range(4):
+        for _ in range(8):
             self._up_ring.append((torch.empty(1 << 20, dtype=torch.uint8).pin_memory(), torch.empty(1 << 20, dtype=torch.uint8, device=self.device), None))
         self._store_init()
 

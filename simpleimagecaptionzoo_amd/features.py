@@ -127,9 +127,12 @@ class PackedFeatureStore:
 def wait_event(ev):
     """Host-side wait for a recorded event.  Almost always the event has long completed (it guards a buffer last used several
     batches ago): a query answers that without entering hipEventSynchronize, whose wake-up path cost 1 - 2 ms per call on
-    ROCm 7.2 even for finished events (measured round 3: it made the cold first epoch host-bound)."""
-    if not ev.query():
-        ev.synchronize()
+    ROCm 7.2 even for finished events (measured round 3: it made the cold first epoch host-bound) and, when the event is NOT
+    finished, wakes tens of milliseconds late every now and then (a 10-step cold epoch took 108 instead of 64 ms once in four).
+    Unfinished events are therefore polled with short sleeps."""
+    import time
+    while not ev.query():
+        time.sleep(5e-5)
 
 
 class DevicePrefetcher:
