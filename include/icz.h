@@ -317,6 +317,21 @@ int icz_ciderd_cook_host(const int32_t* df_keys_host, const double* df_idf_host,
                          const int32_t* tokens, const int32_t* ref_tok_ptr, int32_t n_refs, int64_t max_ent,
                          int32_t* ent_key_out, int32_t* ent_order_out, double* ent_w_out, int32_t* ref_ent_ptr_out,
                          double* ref_norm_out, int32_t* ref_len_out, int64_t* n_ent_out);
+/* Host-side word -> id map of the scorer: the caption vocabulary (Caption_Vocabulary.word2ix, ClassRepository/CaptionVocabClass.py:1-19)
+ * plus private ids >= V, in order of first appearance, for words outside it (references and the document-frequency table contain
+ * them; ciderD_scorer.py keys n-grams by the word strings themselves).  words: n_words strings back to back, word i =
+ * words[word_off[i] .. word_off[i+1]) with id word_id[i].  Thread-safe. */
+typedef struct icz_ciderd_vocab icz_ciderd_vocab_t;
+int icz_ciderd_vocab_create(const char* words, const int64_t* word_off, const int32_t* word_id, int32_t n_words, int32_t V,
+                            icz_ciderd_vocab_t** out);
+int icz_ciderd_vocab_destroy(icz_ciderd_vocab_t* v);
+int icz_ciderd_vocab_oov_id(icz_ciderd_vocab_t* v, const char* word, int32_t len, int32_t* id_out);
+/* icz_ciderd_cook_host with `precook`'s tokenisation (ciderD_scorer.py:17-32: s.split()) in front of it: text = n_refs ASCII
+ * references separated by '\n', words by runs of blanks.  Outputs as icz_ciderd_cook_host (at most 4 * words entries). */
+int icz_ciderd_cook_text(icz_ciderd_vocab_t* vocab, const int32_t* df_keys_host, const double* df_idf_host, int64_t cap, double default_idf,
+                         const char* text, int64_t text_len, int32_t n_refs, int64_t max_ent,
+                         int32_t* ent_key_out, int32_t* ent_order_out, double* ent_w_out, int32_t* ref_ent_ptr_out,
+                         double* ref_norm_out, int32_t* ref_len_out, int64_t* n_ent_out);
 /* The same against a device-resident STORE of cooked references (every image of the dataset cooked once, instead of the
  * reference's re-cooking of the batch's references on every call, ciderD.py:41-52): the seven arrays are the store's, laid
  * out as above with one CSR row per stored image, and img_slot [B] int32 (device) names the store row of image b of the

@@ -164,6 +164,10 @@ def lib():
         "icz_ciderd_destroy": (C.c_int, [vp]),
         "icz_ciderd_reward": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_ciderd_cook_host": (C.c_int, [vp, vp, i64, C.c_double, vp, vp, i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
+        "icz_ciderd_vocab_create": (C.c_int, [C.c_char_p, vp, vp, i32, i32, C.POINTER(vp)]),
+        "icz_ciderd_vocab_destroy": (C.c_int, [vp]),
+        "icz_ciderd_vocab_oov_id": (C.c_int, [vp, C.c_char_p, i32, C.POINTER(i32)]),
+        "icz_ciderd_cook_text": (C.c_int, [vp, vp, vp, i64, C.c_double, C.c_char_p, i64, i32, i64, vp, vp, vp, vp, vp, vp, C.POINTER(i64)]),
         "icz_ciderd_reward_indexed": (C.c_int, [vp, vp, vp, i32, i32, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp, vp]),
         "icz_prof_begin": (C.c_int, []),
         "icz_prof_select": (C.c_int, [i32]),

@@ -55,8 +55,18 @@ class ReferenceCooker:
         import threading
         self.word2ix = dict(word2ix)
         self.V = len(self.word2ix)
-        self._ext = {}                       # out-of-vocabulary reference words -> private ids >= V
+        self._ext = {}                       # out-of-vocabulary reference words -> private ids >= V (cache of the library's map)
         self._ext_lock = threading.Lock()
+        # the library's word -> id map: it tokenises whole batches of references outside the interpreter lock (cook_images) and
+        # owns the private ids of out-of-vocabulary words (one owner: _word_id below asks it)
+        ws = list(self.word2ix.items())
+        blob = [w.encode("utf-8") for w, _ in ws]
+        off = np.zeros(len(ws) + 1, dtype=np.int64)
+        np.cumsum([len(b) for b in blob], out=off[1:])
+        ids = np.asarray([i for _, i in ws], dtype=np.int32)
+        self._vocab = C.c_void_p()
+        check(lib().icz_ciderd_vocab_create(b"".join(blob), off.ctypes.data_as(C.c_void_p), ids.ctypes.data_as(C.c_void_p), len(ws), self.V,
+                                            C.byref(self._vocab)))
         self.log_ref_len = float(np.log(float(ref_len)))
         self._df = document_frequency
         self._log_cache = {}
@@ -105,13 +115,20 @@ class ReferenceCooker:
         i = self.word2ix.get(w)
         if i is None:
             i = self._ext.get(w)
-            if i is None:
-                with self._ext_lock:         # a loader's worker thread cooks too (CiderDReward.prepare)
-                    i = self._ext.get(w)
-                    if i is None:
-                        i = self.V + len(self._ext)
-                        self._ext[w] = i
+            if i is None:                    # the library hands out the private ids (thread-safe); cached here
+                b = w.encode("utf-8")
+                out = C.c_int32()
+                check(lib().icz_ciderd_vocab_oov_id(self._vocab, b, len(b), C.byref(out)))
+                i = self._ext[w] = int(out.value)
         return i
+
+    def __del__(self):
+        try:
+            if self._vocab:
+                lib().icz_ciderd_vocab_destroy(self._vocab)
+                self._vocab = C.c_void_p()
+        except Exception:
+            pass
 
     def cook_image(self, refs):
         """refs: list of reference strings of one image -> (ent_ptr, keys, order, w, norm, length).  The Python statement of
@@ -143,27 +160,35 @@ class ReferenceCooker:
         library's host cooker (one call for all of them, outside the GIL).  as_block: the arrays of all the images as ONE block
         instead ({"nref": references per image, "ep": entry pointer per reference (+1), "key", "ord", "w", "norm", "len"}): what
         the device store appends, without cutting the arrays per image and joining them again."""
-        tok, tptr, nref = [], [0], []
-        get, wid = self.word2ix.get, self._word_id
-        for refs in refs_per_image:
-            nref.append(len(refs))
-            for ref in refs:
-                ids = [get(w) for w in ref.split()]
-                if None in ids:              # out-of-vocabulary words: private ids
-                    ids = [wid(w) for w in ref.split()]
-                tok += ids
-                tptr.append(len(tok))
-        n_refs = len(tptr) - 1
-        tok = np.asarray(tok, dtype=np.int32)
-        tptr = np.asarray(tptr, dtype=np.int32)
-        max_ent = 4 * max(1, tok.size)
-        K, O = np.empty((max_ent, 4), np.int32), np.empty(max_ent, np.int32)
-        W, EP = np.empty(max_ent, np.float64), np.empty(n_refs + 1, np.int32)
-        N, L = np.empty((max(1, n_refs), 4), np.float64), np.empty(max(1, n_refs), np.int32)
-        ne = C.c_int64()
+        flat = [ref for refs in refs_per_image for ref in refs]
+        nref = [len(refs) for refs in refs_per_image]
+        n_refs = len(flat)
+        text = "\n".join(flat)
         P = lambda a: a.ctypes.data_as(C.c_void_p)
-        check(lib().icz_ciderd_cook_host(P(self.keys_host), P(self.idf_host), self.cap, self.log_ref_len, P(tok), P(tptr), n_refs, max_ent,
-                                         P(K), P(O), P(W), P(EP), P(N), P(L), C.byref(ne)))
+        ne = C.c_int64()
+        if n_refs and text.isascii() and text.count("\n") == n_refs - 1:
+            # the whole batch in one library call, tokenisation included: the interpreter lock is held for the join above only
+            raw = text.encode("ascii")
+            max_ent = 4 * (len(raw) // 2 + n_refs + 1)
+            K, O = np.empty((max_ent, 4), np.int32), np.empty(max_ent, np.int32)
+            W, EP = np.empty(max_ent, np.float64), np.empty(n_refs + 1, np.int32)
+            N, L = np.empty((n_refs, 4), np.float64), np.empty(n_refs, np.int32)
+            check(lib().icz_ciderd_cook_text(self._vocab, P(self.keys_host), P(self.idf_host), self.cap, self.log_ref_len, raw, len(raw), n_refs,
+                                             max_ent, P(K), P(O), P(W), P(EP), P(N), P(L), C.byref(ne)))
+        else:       # non-ASCII text or a newline inside a reference: str.split() here, ids to the library
+            tok, tptr = [], [0]
+            wid = self._word_id
+            for ref in flat:
+                tok += [wid(w) for w in ref.split()]
+                tptr.append(len(tok))
+            tok = np.asarray(tok if tok else [0], dtype=np.int32)
+            tptr = np.asarray(tptr, dtype=np.int32)
+            max_ent = 4 * max(1, tok.size)
+            K, O = np.empty((max_ent, 4), np.int32), np.empty(max_ent, np.int32)
+            W, EP = np.empty(max_ent, np.float64), np.empty(n_refs + 1, np.int32)
+            N, L = np.empty((max(1, n_refs), 4), np.float64), np.empty(max(1, n_refs), np.int32)
+            check(lib().icz_ciderd_cook_host(P(self.keys_host), P(self.idf_host), self.cap, self.log_ref_len, P(tok), P(tptr), n_refs, max_ent,
+                                             P(K), P(O), P(W), P(EP), P(N), P(L), C.byref(ne)))
         if as_block:
             e = int(ne.value)
             return {"nref": np.asarray(nref, np.int32), "ep": EP, "key": K[:e], "ord": O[:e], "w": W[:e], "norm": N[:n_refs], "len": L[:n_refs]}

@@ -8,6 +8,9 @@
 // by thread 0 in reference order), which makes the scores bit-identical to the reference's float64 results.
 #include <math.h>
 
+#include <mutex>
+#include <string>
+#include <unordered_map>
 #include <vector>
 
 #include "icz_common.h"
@@ -296,6 +299,81 @@ int icz_ciderd_cook_host(const int32_t* df_keys_host, const double* df_idf_host,
     }
     *n_ent_out = ne;
     return ICZ_OK;
+}
+
+// Word -> id map of the scorer on the host side of the library: the caption vocabulary plus private ids (>= V, in order of first
+// appearance) for words outside it, which the references and the document-frequency table may contain (they count in the
+// reference norms and never match a hypothesis).  One owner for those private ids: the Python cooker asks here too
+// (icz_ciderd_vocab_oov_id), so that references tokenised in C++ (icz_ciderd_cook_text) and n-grams keyed in Python agree.
+struct CiderVocab {
+    std::unordered_map<std::string, int32_t> base, ext;
+    int32_t V = 0;
+    std::mutex mu;
+    int32_t id_of(const std::string& w) {
+        auto it = base.find(w);
+        if (it != base.end()) return it->second;
+        std::lock_guard<std::mutex> lk(mu);
+        auto e = ext.find(w);
+        if (e != ext.end()) return e->second;
+        const int32_t id = V + (int32_t)ext.size();
+        ext.emplace(w, id);
+        return id;
+    }
+};
+
+int icz_ciderd_vocab_create(const char* words, const int64_t* word_off, const int32_t* word_id, int32_t n_words, int32_t V,
+                            icz_ciderd_vocab_t** out) {
+    ICZ_REQUIRE(words && word_off && word_id && n_words >= 0 && V > 0 && out, "icz_ciderd_vocab_create: bad arguments");
+    CiderVocab* v = new CiderVocab();
+    v->V = V;
+    v->base.reserve((size_t)n_words * 2);
+    for (int32_t i = 0; i < n_words; ++i) v->base.emplace(std::string(words + word_off[i], (size_t)(word_off[i + 1] - word_off[i])), word_id[i]);
+    *out = reinterpret_cast<icz_ciderd_vocab_t*>(v);
+    return ICZ_OK;
+}
+int icz_ciderd_vocab_destroy(icz_ciderd_vocab_t* v) {
+    delete reinterpret_cast<CiderVocab*>(v);
+    return ICZ_OK;
+}
+int icz_ciderd_vocab_oov_id(icz_ciderd_vocab_t* v, const char* word, int32_t len, int32_t* id_out) {
+    ICZ_REQUIRE(v && word && len >= 0 && id_out, "icz_ciderd_vocab_oov_id: bad arguments");
+    *id_out = reinterpret_cast<CiderVocab*>(v)->id_of(std::string(word, (size_t)len));
+    return ICZ_OK;
+}
+
+// icz_ciderd_cook_host with the tokenisation in front of it: `text` holds n_refs references separated by '\n', words separated
+// by runs of ASCII whitespace (str.split() of an ASCII string: the caller checks that the text is ASCII and has exactly
+// n_refs - 1 newlines).  Everything between the caller's join() and the flat arrays happens here, outside the interpreter lock:
+// the loader thread that cooks the next batch's references no longer competes with the training thread's kernel launches.
+int icz_ciderd_cook_text(icz_ciderd_vocab_t* vocab, const int32_t* df_keys_host, const double* df_idf_host, int64_t cap, double default_idf,
+                         const char* text, int64_t text_len, int32_t n_refs, int64_t max_ent,
+                         int32_t* ent_key_out, int32_t* ent_order_out, double* ent_w_out, int32_t* ref_ent_ptr_out,
+                         double* ref_norm_out, int32_t* ref_len_out, int64_t* n_ent_out) {
+    ICZ_REQUIRE(vocab && text && text_len >= 0 && n_refs >= 0, "icz_ciderd_cook_text: bad arguments");
+    CiderVocab* v = reinterpret_cast<CiderVocab*>(vocab);
+    std::vector<int32_t> tok, ptr;
+    tok.reserve((size_t)text_len / 2 + 8);
+    ptr.reserve((size_t)n_refs + 1);
+    ptr.push_back(0);
+    std::string w;
+    int64_t i = 0;
+    int32_t refs = 0;
+    auto is_space = [](char c) { return c == ' ' || c == '\t' || c == '\r' || c == '\v' || c == '\f' || (c >= 0x1c && c <= 0x1f); };    // str.split()'s ASCII whitespace minus '\n'
+    while (refs < n_refs) {
+        while (i < text_len && text[i] != '\n') {
+            while (i < text_len && is_space(text[i])) ++i;
+            const int64_t b = i;
+            while (i < text_len && text[i] != '\n' && !is_space(text[i])) ++i;
+            if (i > b) { w.assign(text + b, (size_t)(i - b)); tok.push_back(v->id_of(w)); }
+        }
+        ++i;                                     // the newline (or one past the end after the last reference)
+        ptr.push_back((int32_t)tok.size());
+        ++refs;
+    }
+    ICZ_REQUIRE(i >= text_len, "icz_ciderd_cook_text: text holds more than %d references", n_refs);
+    if (tok.empty()) tok.push_back(0);           // keep the pointer valid
+    return icz_ciderd_cook_host(df_keys_host, df_idf_host, cap, default_idf, tok.data(), ptr.data(), n_refs, max_ent, ent_key_out, ent_order_out,
+                                ent_w_out, ref_ent_ptr_out, ref_norm_out, ref_len_out, n_ent_out);
 }
 
 int icz_ciderd_reward(icz_ciderd_t* h, const int64_t* gen, const int64_t* greedy, int32_t B, int32_t T,

@@ -313,3 +313,28 @@ def test_cooked_reference_blocks_equal_the_per_image_form():
         ends += (e0 + p[0][1:]).tolist()
         e0 += int(p[0][-1])
     assert blk["ep"][0] == 0 and blk["ep"][1:len(ends) + 1].tolist() == ends
+
+
+def test_library_tokeniser_equals_str_split_and_falls_back_for_non_ascii():
+    """icz_ciderd_cook_text tokenises like str.split() on ASCII text (runs of blanks, tabs, leading / trailing blanks, empty
+    references) and shares the private ids of out-of-vocabulary words with the Python side; references with non-ASCII
+    characters or an embedded newline take the Python tokeniser -- every array equal to the Python statement either way."""
+    from simpleimagecaptionzoo_amd.ciderd import ReferenceCooker
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    v = synthetic_vocab(120)
+    words = [v.ix2word[i] for i in range(120)]
+    df = document_frequency(synthetic_references(80, words + ["oovA", "oovB"], seed=1))
+    ck = ReferenceCooker(df["document_frequency"], df["ref_len"], v.word2ix)
+    ascii_refs = [["  w5   w6\tw7 ", "", "w5 w5 w5", "newword w5 newword", "   "], ["w9"], ["oovA oovB w1 zzz"]]
+    other_refs = [["w5 café w6", "w7 w8"], ["w1\nw2 w3"]]          # non-ASCII word, non-breaking space (a str.split() blank), newline
+    for refs in (ascii_refs, other_refs, ascii_refs + other_refs):
+        want = [ck.cook_image(r) for r in refs]
+        got = ck.cook_images(refs)
+        for a, b in zip(want, got):
+            for x, y in zip(a, b):
+                assert x.dtype == y.dtype and x.shape == y.shape and np.array_equal(x, y)
+    # the same out-of-vocabulary word has one id on both sides
+    assert ck._word_id("newword") == ck._word_id("newword") >= 120
+    k = ck.cook_images([["newword"]])[0][1]
+    assert k[0, 0] == ck._word_id("newword")
