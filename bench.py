@@ -611,8 +611,8 @@ def extra_rates(eng, opt, words, device, B, steps):
             f = supp["bu_feats"].cpu().numpy()
             hs.append((ids, None, gts, tuple({"bu_feat": f[j], "bu_bbox": None} for j in range(f.shape[0]))))
         return hs
-    # ---- cold first epoch: images the scorer has never seen; references cooked (a) inline on the training thread,
-    #      (b) on the loader's worker thread one batch ahead (DevicePrefetcher(on_batch=scorer.prepare))
+    # ---- cold first epoch: images the scorer has never seen; references cooked on a loader thread one batch ahead (the Engine
+    #      wraps any loader in a DevicePrefetcher(on_batch=scorer.prepare)): (a) features resident, (b) features from host memory
     # one prefetcher for all host-fed runs (a training run keeps its loader: pinned ring, copy stream and worker pool are set
     # up once), warmed on references the scorer already holds
     warm = host_side(make_batches(steps + 3, B, words, device, 0, id_base=30_000_000))
@@ -620,14 +620,18 @@ def extra_rates(eng, opt, words, device, B, steps):
         scorer.preload(bt[2])
     pf = DevicePrefetcher(warm[:3], device)
     eng.SCST_training_epoch(pf, opt, None, tqdm_visible=False)
-    cold_a = make_batches(steps, B, words, device, 0, id_base=10_000_000)
-    dta = timed(lambda: cold_a, steps)
-    pf.loader, pf.on_batch = host_side(make_batches(steps, B, words, device, 0, id_base=20_000_000)), lambda bt: scorer.prepare(bt[0], bt[2])
-    dtb = timed(lambda: pf, steps)
+    # 3 x `steps` batches per cold leg: the first batch of an epoch is cooked with nothing to hide behind (a real epoch has thousands)
+    nc = 3 * steps
+    cold_a = make_batches(nc, B, words, device, 0, id_base=10_000_000)
+    dta = timed(lambda: cold_a, nc)
+    pf.loader, pf.on_batch = host_side(make_batches(nc, B, words, device, 0, id_base=20_000_000)), lambda bt: scorer.prepare(bt[0], bt[2])
+    dtb = timed(lambda: pf, nc)
     out["cold_first_epoch"] = {"value": B / dta, "ms_per_step": dta * 1e3, "prefetched": {"value": B / dtb, "ms_per_step": dtb * 1e3},
                                "note": "every image unseen: its references are cooked on the host (n-gram tf-idf vectors, once per image "
-                                       "for the whole run) and appended to the device store; `value`: inline on the training thread, features "
-                                       "resident; `prefetched`: on the loader's worker thread one batch ahead, features from host memory"}
+                                       "for the whole run) on a loader thread one batch ahead (the Engine's default since round 3) and appended "
+                                       "to the device store; `value`: features resident in HBM; `prefetched`: features from host memory through "
+                                       "a DevicePrefetcher whose worker thread stages them as well; "
+                                       "both legs: %d steps, six warm steps in front (no idle gap)" % nc}
     # ---- PCIe-inclusive (never `value`): features start in host memory as the reference boundary hands them over
     #      (BUTD_Engine.py:45), pinned triple-buffered prefetcher; references warm (second epoch on)
     pf.loader, pf.on_batch = warm[3:], None
