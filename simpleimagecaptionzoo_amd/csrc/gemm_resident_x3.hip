@@ -316,7 +316,11 @@ __global__ __launch_bounds__(256) void gemm_resident_x3_pair_kernel(GemmPair g) 
 // MEASURED (round 3, same box): three-stage ranges for the TD gates (256 workgroups of 192 KB of weights instead of 192 of 256 KB)
 // take 17 % fewer cycles per workgroup (33.3 k -> 27.6 k) and make the decode SLOWER: greedy 64 x 20 steps 98.9 -> 100.8 us per
 // step, SCST rollouts 3.09 -> 3.13 ms -- four more slabs through the LSTM pointwise kernel, and no idle CUs left for the other
-// chain of the rollout pair.  Not kept; the kernel body stays generic in NSR.
+// chain of the rollout pair.  Not kept; the kernel body stays generic in NSR.  The other direction -- TPW = 4 column tiles per
+// workgroup (half the workgroups: 96 / 128 / 80, every launch on at most half of the CUs, the activation block amortised over twice
+// the weights) -- is worse by more: rollouts 2.75 -> 3.25 ms, greedy 95.5 -> 127 us per step with all three GEMMs on it, 2.98 ms /
+// 109 us with the vocabulary projection alone (same box, bitwise the same results): two half-chip GEMMs of the two chains side by
+// side do not make up for a launch that takes 1.7x as long.
 static int rs_total_stages(const GemmArgs& a) {
     int tot = 0;
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / SK_BK;
