@@ -45,3 +45,6 @@ for j, n in enumerate(names):
     tot += ms
     print("%-12s %.3f ms" % (n, ms))
 print("%-12s %.3f ms (sum of phases; the step also pays host gaps between them)" % ("total", tot))
+span = ev[2][0].elapsed_time(ev[N - 1][4]) / (N - 2)
+gaps = sum(ev[i][4].elapsed_time(ev[i + 1][0]) for i in range(2, N - 1)) / (N - 3)
+print("%-12s %.3f ms per step on the device timeline; between two steps (features, handle, host) %.3f ms" % ("span", span, gaps))
