@@ -320,7 +320,10 @@ __global__ __launch_bounds__(256) void gemm_resident_x3_pair_kernel(GemmPair g) 
 // workgroup (half the workgroups: 96 / 128 / 80, every launch on at most half of the CUs, the activation block amortised over twice
 // the weights) -- is worse by more: rollouts 2.75 -> 3.25 ms, greedy 95.5 -> 127 us per step with all three GEMMs on it, 2.98 ms /
 // 109 us with the vocabulary projection alone (same box, bitwise the same results): two half-chip GEMMs of the two chains side by
-// side do not make up for a launch that takes 1.7x as long.
+// side do not make up for a launch that takes 1.7x as long.  And TWO workgroups per CU (so that one chain's GEMM can stream while the
+// other's is in its prologue / epilogue): NSR = 2 x TPW = 4 -- 128-deep ranges of 512 columns, the same 256 KB of weights per
+// workgroup, 55 KB of planes + half-width epilogue strips = 72 KB of LDS, 200 VGPRs -- doubles the slabs (24 - 32 per gate GEMM)
+// and loses everywhere: rollouts 2.79 -> 3.55 ms, greedy 96 -> 110 us per step (same box, suite green with it).
 static int rs_total_stages(const GemmArgs& a) {
     int tot = 0;
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / SK_BK;
