@@ -308,15 +308,18 @@ int Aoa::beam_search(const float* feats, int n_img, int kb, int max_steps, float
     ICZ_TRY(zero_state(*this, rows, st));
     int sb = 0, steps_done = 0;
     for (int stp = 1; stp <= max_steps; ++stp) {
-        AoaStepIO s = scratch_io(*this, rows, bm.img_of_row, 0);
+        // step 1: the kb rows of an image are identical and only row 0 is scored -> one decoder row per image (butd_beam.hip)
+        const bool compact = stp == 1 && kb > 1;
+        AoaStepIO s = compact ? scratch_io(*this, n_img, nullptr, 0) : scratch_io(*this, rows, bm.img_of_row, 0);
         s.emb_ready = false;
         ICZ_TRY(step(s, st));
         BeamArgs a = {logits, dims.V, Vp, kb, stp, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + stp};
-        launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx);
+        launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx,
+                            compact ? 1 : 0);
         hipLaunchKernelGGL(beam_merge_kernel, dim3(n_img), dim3(64), 0, st, a, (const float*)bm.cand_val, (const int*)bm.cand_idx);
         hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(Hd, 1024), rows), dim3(256), 0, st, bm.src_row, Hd, h[1], m[1], ctx[1], h[1],
-                           h[0], m[0], ctx[0], u);
+                           h[0], m[0], ctx[0], u, compact ? kb : 1);
         sb ^= 1;
         steps_done = stp;
         if (stp >= 6 && (stp % 3) == 0 && stp < max_steps) {

@@ -26,7 +26,7 @@ struct BeamArgs {
 // The global top-n_act are contained in the union of the per-row top-n_act, so the result equals a search over all k*V.
 __global__ __launch_bounds__(256) void beam_rowtopk_kernel(const float* __restrict__ logits, int V, int ldl, int k, int step,
                                                            const int* __restrict__ n_act, const float* __restrict__ run,
-                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+                                                           float* __restrict__ cand_val, int* __restrict__ cand_idx, int compact) {
     __shared__ float smf[4];
     __shared__ float s_val[4];
     __shared__ int s_idx[4], s_who[4];
@@ -34,7 +34,7 @@ __global__ __launch_bounds__(256) void beam_rowtopk_kernel(const float* __restri
     const int na = n_act[img];
     const int nr = (step == 1) ? 1 : na;          // step 1 scores row 0 only (:273-274)
     if (r >= nr) return;
-    const float* l = logits + (size_t)row * ldl;
+    const float* l = logits + (size_t)(compact ? img : row) * ldl;      // compact (step 1 only): one decoder row per image
     // Every sweep fetches the thread's strided slice (40 logits at V = 10102) in batches of U independent loads: one memory
     // latency per batch instead of one per element.  (All 40 in registers across the three sweeps: the unrolled kernel
     // outgrows the instruction cache; the row staged in LDS for the second and third sweep: no faster, 36 -> 37 us.)
@@ -134,7 +134,7 @@ constexpr int BEAM_CAND_CAP = 128;
 template <int NV4>
 __global__ __launch_bounds__(256) void beam_rowtopk_reg_kernel(const float* __restrict__ logits, int V, int ldl, int k, int step,
                                                                const int* __restrict__ n_act, const float* __restrict__ run,
-                                                               float* __restrict__ cand_val, int* __restrict__ cand_idx) {
+                                                               float* __restrict__ cand_val, int* __restrict__ cand_idx, int compact) {
     __shared__ float smf[4];
     __shared__ float s_val[4];
     __shared__ int s_idx[4], s_who[4];
@@ -146,7 +146,7 @@ __global__ __launch_bounds__(256) void beam_rowtopk_reg_kernel(const float* __re
     const int na = n_act[img];
     const int nr = (step == 1) ? 1 : na;          // step 1 scores row 0 only (:273-274)
     if (r >= nr) return;
-    const float* l = logits + (size_t)row * ldl;
+    const float* l = logits + (size_t)(compact ? img : row) * ldl;      // compact (step 1 only): one decoder row per image
     f32x4 x[NV4];
 #pragma unroll
     for (int u = 0; u < NV4; ++u) {
@@ -278,11 +278,11 @@ __global__ __launch_bounds__(256) void beam_rowtopk_reg_kernel(const float* __re
 
 // per-row candidates of one beam step: the register kernel where the vocabulary fits it, else the sweep kernel
 inline void launch_beam_rowtopk(hipStream_t st, int rows, const float* logits, int V, int ldl, int k, int step, const int* n_act,
-                                const float* run, float* cand_val, int* cand_idx) {
+                                const float* run, float* cand_val, int* cand_idx, int compact = 0) {
     const bool ok = ldl % 4 == 0 && ((uintptr_t)logits & 15) == 0;
-    if (ok && V <= 1024 * 3) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<3>), dim3(rows), dim3(256), sizeof(float) * 1024 * 3, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
-    else if (ok && V <= 1024 * 10) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<10>), dim3(rows), dim3(256), sizeof(float) * 1024 * 10, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
-    else hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx);
+    if (ok && V <= 1024 * 3) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<3>), dim3(rows), dim3(256), sizeof(float) * 1024 * 3, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx, compact);
+    else if (ok && V <= 1024 * 10) hipLaunchKernelGGL((beam_rowtopk_reg_kernel<10>), dim3(rows), dim3(256), sizeof(float) * 1024 * 10, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx, compact);
+    else hipLaunchKernelGGL(beam_rowtopk_kernel, dim3(rows), dim3(256), 0, st, logits, V, ldl, k, step, n_act, run, cand_val, cand_idx, compact);
 }
 
 __global__ __launch_bounds__(64) void beam_merge_kernel(BeamArgs a, const float* __restrict__ cand_val, const int* __restrict__ cand_idx) {
@@ -369,11 +369,12 @@ __global__ __launch_bounds__(256) void beam_gather_kernel(const int32_t* __restr
                                                           const float* __restrict__ a0, const float* __restrict__ a1,
                                                           const float* __restrict__ a2, const float* __restrict__ a3,
                                                           float* __restrict__ o0, float* __restrict__ o1,
-                                                          float* __restrict__ o2, float* __restrict__ o3) {
+                                                          float* __restrict__ o2, float* __restrict__ o3, int src_div) {
     const int row = blockIdx.y;
     const int j = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (j >= H) return;
-    const size_t s = (size_t)src_row[row] * H + j, d = (size_t)row * H + j;
+    // src_div = k after a compact first step (the state of image img sits in row img, src_row says img k + 0), else 1
+    const size_t s = (size_t)(src_row[row] / src_div) * H + j, d = (size_t)row * H + j;
     *reinterpret_cast<f32x4*>(o0 + d) = *reinterpret_cast<const f32x4*>(a0 + s);
     *reinterpret_cast<f32x4*>(o1 + d) = *reinterpret_cast<const f32x4*>(a1 + s);
     *reinterpret_cast<f32x4*>(o2 + d) = *reinterpret_cast<const f32x4*>(a2 + s);

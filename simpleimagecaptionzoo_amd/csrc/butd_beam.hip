@@ -42,18 +42,23 @@ int Butd::beam_search(const float* feats, int n_img, int k, int max_steps, float
                        bm.has_complete, bm.best_score);
     int sb = 0, steps_done = 0;
     for (int step = 1; step <= max_steps; ++step) {
+        // Step 1: the k rows of an image are identical (<sta>, zero state) and only row 0 is scored (:273-274), so the decoder runs
+        // ONE row per image (row img of the buffers); the top-k kernel reads image img's logits from row img and the state gather
+        // fans row img out to the image's k rows.
+        const bool compact = step == 1 && k > 1;
         StepIO s = {};
-        s.rows = rows; s.feats = feats; s.img_of_row = bm.img_of_row; s.it = it;
-        s.rows_per_img = k;
+        s.rows = compact ? n_img : rows; s.feats = feats; s.img_of_row = compact ? nullptr : bm.img_of_row; s.it = it;
+        s.rows_per_img = compact ? 1 : k;
         s.h1_in = h1[0]; s.c1_in = c1[0]; s.h2_in = h2[0]; s.c2_in = c2[0];
         s.h1_out = h1[1]; s.c1_out = c1[1]; s.h2_out = h2[1]; s.c2_out = c2[1];
         ICZ_TRY(this->step(s, st));
         BeamArgs a = {logits, dims.V, pad_vocab(dims.V), k, step, L, bm.n_act, bm.run, bm.seqs[sb], bm.seqs[sb ^ 1], bm.src_row, it,
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + step};
-        launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx);
+        launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx,
+                            compact ? 1 : 0);
         hipLaunchKernelGGL(beam_merge_kernel, dim3(n_img), dim3(64), 0, st, a, (const float*)bm.cand_val, (const int*)bm.cand_idx);
         hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h1[1], c1[1], h2[1], c2[1],
-                           h1[0], c1[0], h2[0], c2[0]);
+                           h1[0], c1[0], h2[0], c2[0], compact ? k : 1);
         sb ^= 1;
         steps_done = step;
         // every few steps ask the device whether any image still has live beams (one 4-byte read-back)

@@ -466,7 +466,7 @@ int Nic::beam_search(const float* feats, int n_img, int k, int max_steps, float*
                       bm.best_score, bm.best_len, bm.best_seq, bm.has_complete, bm.n_live + step};
         launch_beam_rowtopk(st, rows, a.logits, a.V, a.ldl, a.k, a.step, (const int*)bm.n_act, (const float*)bm.run, bm.cand_val, bm.cand_idx);
         hipLaunchKernelGGL(beam_merge_kernel, dim3(n_img), dim3(64), 0, st, a, (const float*)bm.cand_val, (const int*)bm.cand_idx);
-        hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h[1], c[1], h[1], c[1], h[0], c[0], h[0], c[0]);
+        hipLaunchKernelGGL(beam_gather_kernel, dim3(cdiv(H, 1024), rows), dim3(256), 0, st, bm.src_row, H, h[1], c[1], h[1], c[1], h[0], c[0], h[0], c[0], 1);
         sb ^= 1;
         steps_done = step;
         if (step >= 6 && (step % 3) == 0 && step < max_steps) {
