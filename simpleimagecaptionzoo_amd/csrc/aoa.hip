@@ -217,7 +217,7 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
     hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out,
                        (const float*)meanf, s.img_of_row, s.u_next, s.d_ctx_next);
-    ICZ_TRY(gemm_predict(s.ctxdrop, Hd, w_pred, P.predict_b, rows, dims.V, Vp, s.logits, Vp, ws, ws_floats, s.pred_nsplit, st));
+    if (!s.skip_predict) ICZ_TRY(gemm_predict(s.ctxdrop, Hd, w_pred, P.predict_b, rows, dims.V, Vp, s.logits, Vp, ws, ws_floats, s.pred_nsplit, st));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }

@@ -32,6 +32,7 @@ struct AoaStepIO {
     float* u_next;                   // where this step's GLU kernel leaves the next step's u (null: it does not)
     DropP d_ctx_next;                // the next step's ctx dropout
     int* pred_nsplit;                // non-null: the caller's consumer sums split-K slabs of the predict GEMM (gemm_predict)
+    bool skip_predict;               // teacher-forced XE forward: the vocabulary projection of all time steps is one GEMM after the loop
 };
 
 struct Aoa {

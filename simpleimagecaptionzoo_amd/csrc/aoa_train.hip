@@ -238,6 +238,7 @@ int Aoa::ensure_train(int Bq, int Tq) {
     ICZ_TRY(alloc((void**)&temb, sizeof(float) * TB * E));
     float** sth[] = {&tu, &tqn, &tQp, &txatt, &tcd, &dCd, &dQp, &dQn, &prod, &tdX};
     for (float** p : sth) ICZ_TRY(alloc((void**)p, sizeof(float) * TB * Hd));
+    ICZ_CHECK_HIP(hipMemset(tcd, 0, sizeof(float) * TB * Hd));      // the batched vocabulary projection of xe_forward reads every (t, b) row
     ICZ_TRY(alloc((void**)&tg, sizeof(float) * TB * 4 * Hd));
     ICZ_TRY(alloc((void**)&dG, sizeof(float) * TB * 4 * Hd));
     ICZ_TRY(alloc((void**)&tz, sizeof(float) * TB * 2 * Hd));
@@ -391,6 +392,9 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
     ICZ_CHECK_HIP(hipMemsetAsync(tctx, 0, sizeof(float) * sH, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tlogit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(aoa_captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tok);
+    // teacher forcing: one vocabulary projection over all (t, b) rows after the loop unless scheduled sampling needs the previous
+    // step's logits (butd_train.hip: xe_forward); rows b >= rows_t[t] are zeroed by xe_loss_dlogits_kernel / the scatter kernel
+    const bool batched_predict = ss_prob <= 0.f && T * B >= 128;
     for (int t = 0; t < T; ++t) {
         if (t >= 2 && ss_prob > 0.f)          // scheduled sampling (AoA_Model.py:258-270): this step's tokens, mixed with draws from the previous logits
             ICZ_TRY(ss_select_launch(st, rows_t[t], tlogit + (size_t)(t - 1) * B * Vp, (int)Vp, dims.V, t, B, ss_prob, ss_gate, ss_draw, d_seed,
@@ -398,7 +402,15 @@ int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, c
         AoaStepIO io = train_io(rows_t[t], t, cur_train);
         io.u_ready = t > 0;             // the next step's rows are a prefix of this step's: its u comes from this step's GLU kernel
         if (t + 1 < T) { const AoaStepIO nx = train_io(rows_t[t + 1], t + 1, cur_train); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
+        io.skip_predict = batched_predict;
         ICZ_TRY(step(io, st));
+    }
+    if (batched_predict) {
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {tcd, w_pred, dims.Hd, dims.Hd, dims.Hd, nullptr};
+        g.M = T * B; g.N = dims.V; g.out = tlogit; g.ldo = Vp; g.bias = P.predict_b; g.nsplit = 1;
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     }
     if (packed_out) {
         std::vector<int> hostv(2 * T);

@@ -257,7 +257,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
                            s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
         launch_lstm_point(a, s.drop_out, st);
     }
-    {   // predict: logits = drop(h2) w_pred^T + b  (finished logits, or split-K slabs in the chain's workspace for a consumer that sums them)
+    if (!s.skip_predict) {   // predict: logits = drop(h2) w_pred^T + b  (finished logits, or split-K slabs in the chain's workspace for a consumer that sums them)
         const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
         ICZ_TRY(gemm_predict(s.h2drop_out ? s.h2drop_out : h2drop, H, w_pred, P.predict_b, rows, V, Vp, s.logits_out ? s.logits_out : logits,
                              s.logits_ld ? s.logits_ld : Vp, ws, ws_cap, s.pred_nsplit, st));

@@ -34,6 +34,7 @@ struct StepIO {
     float* ws_alt;                   // split-K slab workspace / attention scores of this chain (null = the handle's):
     float* scores_alt;               // two decode chains running concurrently must not share them
     DropCfg drop_emb, drop_att, drop_out;
+    bool skip_predict;               // teacher-forced XE forward: the vocabulary projection of ALL time steps is one GEMM after the loop
 };
 
 // Activations kept by a training-mode forward (slot t = time step, slot stride = B rows) and backward scratch.
@@ -147,7 +148,8 @@ struct Butd {
     const int64_t* cur_seq = nullptr; const float* cur_logp = nullptr; const int64_t* cur_captions = nullptr;
     std::vector<int> rows_t;
     int ensure_train(int B, int T);
-    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false, int* pred_nsplit = nullptr);
+    int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false, int* pred_nsplit = nullptr,
+                   bool skip_predict = false);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_mask_sum(float* out, hipStream_t st);
     int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,

@@ -109,6 +109,26 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
     *reinterpret_cast<f32x4*>(emb + (size_t)row * E + e) = x;
 }
 
+// The same for every time step of a teacher-forced forward pass at once (the tokens are all known up front): block (x, t B + b),
+// active while b < rows_t[t]; dropout of step t = the per-step configuration (Philox step t / mask slice t of [T][B][E]).
+constexpr int EMB_MAX_T = 128;
+struct EmbRows { int n[EMB_MAX_T]; };
+__global__ __launch_bounds__(256) void embed_steps_kernel(const float* __restrict__ table, const int64_t* __restrict__ tok,
+                                                          float* __restrict__ emb, int B, int E, EmbRows rows, DropCfg dc) {
+    const int t = blockIdx.y / B, b = blockIdx.y % B;
+    if (b >= rows.n[t]) return;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= E) return;
+    dc.step = (uint32_t)t;
+    if (dc.mode == 1) dc.mask += (size_t)t * B * E;
+    f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)tok[blockIdx.y] * E + e);
+    uint32_t k = dc.mode ? dc.keep4((uint64_t)b * E + e) : 0xFu;
+    const float sc = dc.mode ? 2.0f : 1.0f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
+    *reinterpret_cast<f32x4*>(emb + (size_t)blockIdx.y * E + e) = x;
+}
+
 // ---------------------------------------------------------------------------------------------------------
 // LSTMCell pointwise part (:82-83; gate order i,f,g,o):
 //   gates[row, :] = sum_z slab[z,row,:] + pre[pre_row,:] (optional) + b_ih + b_hh
@@ -1105,7 +1125,11 @@ __global__ __launch_bounds__(256) void xe_loss_dlogits_kernel(float* __restrict_
                                                               float* __restrict__ loss_rows) {
     __shared__ float smf[4];
     const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
-    if (b >= rows.n[t]) return;
+    if (b >= rows.n[t]) {          // inactive (t, b): its gradient row must be zero for the batched GEMMs of the backward pass (the batched
+        float* z = logits + (size_t)(t * B + b) * ldl;      // vocabulary projection of the forward pass fills every row)
+        for (int v = tid; v < ldl; v += 256) z[v] = 0.f;
+        return;
+    }
     // data-parallel: the all-reduced token count, a device scalar (0 = never handed over: the local count, as the SCST path does)
     const float inv_n = (n_dev && n_dev[0] > 0.f) ? 1.0f / n_dev[0] : inv_n_host;
     const int row = t * B + b;

@@ -109,7 +109,7 @@ static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base
 
 // ------------------------------------------------------------------------------------------------
 // forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
-int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit) {
+int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit, bool skip_predict) {
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
     const size_t Vp = round4(dims.V);
     const size_t slot = (size_t)t * Bs;
@@ -130,6 +130,7 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     s.drop_att = make_drop(d_seed, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
     s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
     s.pred_nsplit = pred_nsplit;
+    s.skip_predict = skip_predict;
     return step(s, st);
 }
 
@@ -332,11 +333,31 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     ICZ_CHECK_HIP(hipMemsetAsync(tb.logit, 0, sizeof(float) * (size_t)T * B * Vp, st));
     hipLaunchKernelGGL(captions_to_tok_kernel, dim3(cdiv(T * B, 256)), dim3(256), 0, st, captions, B, L, T, tb.tok);
     cur_captions = captions; cur_L = L;
+    // Teacher forcing: no step needs the previous step's logits unless scheduled sampling draws from them -> one vocabulary projection
+    // over all time steps after the loop (T B >= 128 rows: a single GEMM on the big-tile kernel instead of T decoder-step GEMMs)
+    const bool batched_predict = ss_prob <= 0.f && T * B >= 128;
+    const bool batched_embed = ss_prob <= 0.f && T <= EMB_MAX_T && dims.E % 4 == 0;       // likewise the embeddings of all steps: one launch
+    if (batched_embed) {
+        EmbRows er = {};
+        for (int t = 0; t < T; ++t) er.n[t] = rows_t[t];
+        hipLaunchKernelGGL(embed_steps_kernel, dim3(cdiv(dims.E, 1024), T * B), dim3(256), 0, st, P.embed_weight, tb.tok, tb.emb, B, dims.E, er,
+                           make_drop(d_seed, train != 0, rng.emb_mask, (size_t)B * dims.E, RNG_EMB, 0));
+    }
     for (int t = 0; t < T; ++t) {
         if (t >= 2 && ss_prob > 0.f)          // BUTD_Model.py:120-130: this step's tokens, mixed with draws from the previous step's logits
             ICZ_TRY(ss_select_launch(st, rows_t[t], tb.logit + (size_t)(t - 1) * B * Vp, (int)Vp, dims.V, t, B, ss_prob, ss_gate, ss_draw,
                                      d_seed, tb.tok + (size_t)t * B));
-        ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st));
+        ICZ_TRY(train_step(feats, rows_t[t], B, t, train != 0, st, batched_embed, nullptr, batched_predict));
+    }
+    if (batched_predict) {
+        // logits of all (t, b) rows at once: [T B, H] x w_pred^T + b through the 128 x 128 split-precision kernel (one pass over the
+        // vocabulary matrix instead of T).  Rows b >= rows_t[t] hold whatever their h2 slots held: nothing reads them before
+        // xe_loss_dlogits_kernel / scatter_packed_kernel overwrite them with zeros.
+        GemmArgs g = {};
+        g.nseg = 1;
+        g.seg[0] = {tb.h2d, w_pred, (int)H, (int)H, (int)H, nullptr};
+        g.M = T * B; g.N = dims.V; g.out = tb.logit; g.ldo = (int)Vp; g.bias = P.predict_b; g.nsplit = 1;
+        ICZ_TRY(gemm_f32(GEMM_NT, g, st));
     }
     if (packed_out) {
         ICZ_TRY(upload_pack_index(st));
