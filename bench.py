@@ -144,13 +144,14 @@ def secondary(eng, opt, words, device, B):
         "beam5_b128_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
         "TD gates, LM gates and vocabulary projection of a beam step at 640 rows: 50.8 GFLOP over three launches",
         flops_per_launch=2.0 * 640 * (4096 * 3072 + 4096 * 4096 + 10112 * 1024) / 3.0)
-    # BASELINE config 2's: the resident split-precision kernel (forward gates / vocabulary projection of the steps with more than 32
-    # active rows, per-step dgrad of BPTT); algorithmic bytes per launch averaged over those five shapes at 64 rows
+    # BASELINE config 2's: the resident split-precision kernel (forward LSTM gates of the steps with more than 32 active rows, LM-input
+    # dgrad of BPTT; the vocabulary projection of a teacher-forced pass is ONE big-tile GEMM after the time loop and not on this
+    # kernel); algorithmic bytes per launch averaged over those three shapes at 64 rows
     out["xe_step_spatial49"]["roofline"] = csv_roofline(
         "xe_spatial49_kernel_stats.csv", "gemm_resident_x3_kernel",
-        "TD gates, LM gates, vocabulary projection and the LM-input dgrad of BPTT at up to 64 rows: weights 41 - 67 MB per launch streamed "
-        "once + activations and output (average of the four shapes at 64 rows)",
-        bytes_per_launch=4.0 * (4096 * 3072 + 4096 * 4096 + 10112 * 1024 + 3072 * 4096) / 4.0 + 4.0 * 64 * (3584 + 5300))
+        "TD gates, LM gates and the LM-input dgrad of BPTT at up to 64 rows: weights 50 - 67 MB per launch streamed "
+        "once + activations and output (average of the three shapes at 64 rows)",
+        bytes_per_launch=4.0 * (4096 * 3072 + 4096 * 4096 + 3072 * 4096) / 3.0 + 4.0 * 64 * (3072 + 4096 + 4096 + 4096 + 4096 + 3072) / 3.0)
     out["nic_greedy_b16"] = nic_greedy_b16(device)
     out["aoa_scst_step"] = aoa_scst(words, device, B)
     return out
