@@ -69,6 +69,11 @@ int Butd::init(const icz_butd_dims& d) {
     if (A > nmax) nmax = A;
     if (V > nmax) nmax = V;
     ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    {   // the resident decoder-step GEMMs leave one slab per 256-deep k range: (2H + max(E, D)) / 256 slabs of rows x 4H at up to 128 rows
+        const size_t kmax = 2 * H + (E > D ? E : D), r128 = rows < 128 ? rows : 128;
+        const size_t need = (kmax / 256 + 1) * r128 * 4 * H;
+        if (need > ws_floats) ws_floats = need;
+    }
     ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
     return ICZ_OK;
 }
@@ -416,7 +421,12 @@ int icz_butd_step(icz_butd_t* h, const float* feats, int32_t B, const int64_t* i
     return ICZ_OK;
 }
 
-size_t icz_gemm_workspace_floats(int32_t M, int32_t N) { return (size_t)Butd::TARGET_WGS * 4096 * 2 + (size_t)M * N; }
+size_t icz_gemm_workspace_floats(int32_t M, int32_t N) {
+    const size_t base = (size_t)Butd::TARGET_WGS * 4096 * 2 + (size_t)M * N;
+    // 65..128 rows: the 128-row resident kernel leaves up to 32 slabs of M x N (one per 256-deep k range of K <= 8192)
+    const size_t m128 = (M > 64 && M <= 128) ? (size_t)32 * M * N : 0;
+    return base > m128 ? base : m128;
+}
 
 int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, int32_t ldw, const float* bias,
                  float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,

@@ -194,7 +194,7 @@ __global__ __launch_bounds__(256) void lstm_point_kernel(LstmPointArgs a, DropCf
 
 // Gate-per-wave form, grid (H / 256, rows), 256 threads: wave q sums gate q of the workgroup's 256 hidden units (16 bytes per
 // lane and slab, the loads of up to eight slabs independent), the four gates meet in LDS and thread j finishes unit j.  The
-// resident-activation gate GEMM (gemm_skinny_x3.hip) leaves 12 - 16 split-K slabs (16.8 MB at 64 rows): the one-unit kernel
+// resident-activation gate GEMM (gemm_resident_x3.hip) leaves 12 - 16 split-K slabs (16.8 MB at 64 rows): the one-unit kernel
 // above then issues 64 four-byte wave loads per thread (8.3 us), a four-units-per-thread form with one wave per workgroup
 // has ONE wave per compute unit waiting on 64 KB (9.5 us in the SCST trace); here four waves per compute unit wait on 16 KB
 // each (5.1 us).  Same summation order per element (slabs ascending, pre, b_ih, b_hh): bit-identical to the kernel above.
@@ -577,7 +577,7 @@ __device__ __forceinline__ void argmax_combine(float& best, int& bi, float ob, i
     if (ob > best || (ob == best && oi < bi)) { best = ob; bi = oi; }
 }
 // ns > 1: `logits` holds the ns split-K slabs of the predict GEMM (slab z at + z * slab_stride, no bias yet): the logit is their
-// sum in slab order + bias[v] (the resident-activation GEMM of gemm_skinny_x3.hip leaves four slabs at 33 - 64 rows).
+// sum in slab order + bias[v] (the resident-activation GEMM of gemm_resident_x3.hip leaves four slabs at 33 - 64 rows).
 __global__ __launch_bounds__(256) void argmax_part_kernel(const float* __restrict__ logits, int V, int ldl, int P,
                                                           float* __restrict__ part_val, int* __restrict__ part_idx,
                                                           int ns = 1, size_t slab_stride = 0, const float* __restrict__ bias = nullptr) {

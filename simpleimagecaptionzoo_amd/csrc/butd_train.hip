@@ -85,6 +85,11 @@ int Butd::ensure_train(int B, int T) {
         ICZ_TRY(zalloc((void**)&tb.dc2[i], sizeof(float) * (size_t)B * H));
     }
     tb.xfloats = (size_t)TARGET_WGS * 4096 * 2 + (size_t)B * (D + H);
+    {   // X[0] is the sampled chain's slab workspace (train_step): same rule as Butd::init's ws_floats
+        const size_t kmax = 2 * H + (E > D ? E : D), r128 = B < 128 ? B : 128;
+        const size_t need = (kmax / 256 + 1) * r128 * 4 * H;
+        if (need > tb.xfloats) tb.xfloats = need;
+    }
     for (int i = 0; i < 4; ++i) ICZ_TRY(zalloc((void**)&tb.X[i], sizeof(float) * tb.xfloats));
     ICZ_TRY(zalloc((void**)&tb.dWp, sizeof(float) * Vp * H));
     ICZ_TRY(zalloc((void**)&tb.dWenc, sizeof(float) * A * D));
@@ -554,7 +559,10 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_out);
         }
         // 33 .. 64 rows: the per-step dgrad products as NT products on the transposed weight copies (resident-activation kernel)
-        const bool rdg = wt_lm_ih && wt_fresh && bt > 32 && bt <= 64;
+        // (capacity: 4H / 256 slabs of bt x (D + H) resp. (2 x) 4H / 256 slabs of bt x H must fit tb.X[*]; larger models -- H = 1536
+        // with D = 2048 already -- take the NN path below, whose split is fitted to the buffer)
+        const bool rdg = wt_lm_ih && wt_fresh && bt > 32 && bt <= 64 && gemm_slab_floats(bt, D + H, 4 * H / 256) <= tb.xfloats &&
+                         gemm_slab_floats(bt, H, 2 * (4 * H / 256)) <= tb.xfloats;
         if (rdg) {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
             GemmArgs g = {};
             g.nseg = 1;

@@ -68,10 +68,10 @@ int gemm_normalize_split(GemmLayout layout, const GemmArgs& a, int nsplit);
 // the largest split <= nsplit whose slabs fit the given capacity
 int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capacity_floats);
 
-// gemm_resident_x3.hip: NT at 33..64 rows with split-precision operands and the activations of a workgroup's k range resident in
+// gemm_resident_x3.hip: NT at 33..64 rows (and, as one merged decode chain, 65..128 rows) with split-precision operands and the activations of a workgroup's k range resident in
 // LDS (LSTM gates, vocabulary projection, per-step dgrad on transposed weights): fixed decomposition, nsplit = stages / stages per range
 bool gemm_resident_x3_fits(const GemmArgs& a);
-int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup (4 or 3)
+int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup: 4 (a 256-deep k range), 0 = shape not taken
 int gemm_resident_x3_nsplit(const GemmArgs& a);
 int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
 // two independent problems (each in the kernel's four-stage decomposition, N >= 512) as ONE launch; slabs [nsplit][M][N] go to each
@@ -90,8 +90,9 @@ int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, 
 
 // Library switches, read from the environment once at first use (defaults = the product configuration): ICZ_GEMM_TN_X3,
 // ICZ_GEMM_NN_X3, ICZ_GEMM_NT_X3BIG, ICZ_GEMM_RESIDENT_X3 (0: the fp32-input MFMA kernels -- bench.py's fp32_mfma_gemms leg),
+// ICZ_GEMM_RESIDENT_M128 (0: 65..128 rows go to the 128 x 128-tile kernel instead of the 128-row resident kernel),
 // ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch).
-struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, predict_slabs; unsigned prof_every; };
+struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs; unsigned prof_every; };
 const GemmSwitches& gemm_switches();
 
 }  // namespace icz

@@ -326,7 +326,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
 // in memory (same bytes as before) and are split in registers on their way to the matrix pipe (VALU work in the shadow of
 // the MFMAs); the activation tile is split once per stage when it is staged into LDS.  Operands must be finite.
 // Used by the 128 x 128-tile kernels below (operand reuse: gemm_tn128_x3_kernel) and, in its own translation unit, by the
-// resident-activation decoder-step kernel (gemm_skinny_x3.hip).
+// resident-activation decoder-step kernel (gemm_resident_x3.hip).
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(16))) float f32x16;
 typedef __attribute__((ext_vector_type(4))) uint32_t u32x4;
@@ -891,7 +891,7 @@ const GemmSwitches& gemm_switches() {
         auto on = [](const char* name) { const char* e = getenv(name); return e ? atoi(e) != 0 : true; };
         GemmSwitches s;
         s.tn_x3 = on("ICZ_GEMM_TN_X3"); s.nn_x3 = on("ICZ_GEMM_NN_X3"); s.nt_x3big = on("ICZ_GEMM_NT_X3BIG");
-        s.resident_x3 = on("ICZ_GEMM_RESIDENT_X3"); s.predict_slabs = on("ICZ_PREDICT_SLABS");
+        s.resident_x3 = on("ICZ_GEMM_RESIDENT_X3"); s.resident_m128 = on("ICZ_GEMM_RESIDENT_M128"); s.predict_slabs = on("ICZ_PREDICT_SLABS");
         const char* e = getenv("ICZ_PROF_EVERY");
         s.prof_every = e && atoi(e) > 1 ? (unsigned)atoi(e) : 1u;
         return s;
@@ -929,7 +929,7 @@ static bool nt_spread(const GemmArgs& a) { return a.M <= 64 || a.M >= 1024; }
 // NT shapes with many rows (AoA refiner, beam-search steps, prologue hoists) that go to the split-precision 128 x 128-tile
 // kernel: whole 128-deep chunks, enough tiles to fill at least half of the CUs (one K segment may also be split)
 static bool nt_x3big(const GemmArgs& a) {
-    if (!gemm_switches().nt_x3big || a.M < 128 || a.N < 128) return false;
+    if (!gemm_switches().nt_x3big || a.M < 128 || a.N < 128 || gemm_resident_x3_fits(a)) return false;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % 128) return false;
     const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128);

@@ -311,6 +311,251 @@ __global__ __launch_bounds__(256) void gemm_resident_x3_pair_kernel(GemmPair g) 
 }
 
 // ------------------------------------------------------------------------------------------------
+// 65..128 rows (round 4): the greedy baseline and the sampled rollout of an SCST step as ONE chain of 2 x 64 decoder rows, so that
+// the weights are streamed once per step pair instead of once per chain.  Same decomposition as above (a workgroup owns a 256-deep
+// k range x two 128-column tiles = 256 KB of weights, 256 / 192 / 160 workgroups), same fragment-shaped weight loads, same slabs.
+// What changes with 128 rows: the three bf16 planes of a 256-deep range would need 196 KB of LDS, so the planes hold HALF a range
+// (128 deep: 108 KB) at a time and BOTH column tiles keep their accumulators live (128 VGPRs): pipeline steps run (half, tile,
+// stage) = (0,0,0) (0,0,1) (0,1,0) (0,1,1) | re-split | (1,0,2) (1,0,3) (1,1,2) (1,1,3).  The second half's activations are loaded
+// into registers beside the first two steps' MFMAs and wait there; the re-split costs two barriers.  The MFMA operands are swapped
+// (A = weights, B = activations) so that a lane holds four consecutive columns of a row and a tile leaves straight from the
+// accumulators as 16-byte stores, tile 0 beside tile 1's last two steps.
+// Bytes through a compute unit per workgroup: 256 KB weights + 128 KB activations + 128 KB slab tile = 512 KB for 128 rows against
+// 2 x 384 KB for two 64-row launches; matrix time 8 steps x 192 MFMAs x 16 cycles = 24.6 k cycles per wave -- at 128 rows the main
+// loop is paced by the matrix pipe (the weight split of a k block, ~90 VALU instructions, now hides behind 96 MFMAs instead of 48).
+// pipeline step i of the 128-row kernel -> column tile, stage of the k range (two tiles x two stages per resident half)
+constexpr int m128_tile_of(int i) { return (i % 4) / 2; }
+constexpr int m128_stage_of(int i) { return (i / 4) * 2 + i % 2; }
+template <int D, bool STAMPS>
+__device__ __forceinline__ void resident_x3_m128_body(const GemmArgs& a, const int pair) {
+    constexpr int MT = 8, NSR = 4, HS = 2, TPW = 2, NCT = 2, ROWS = 16 * MT, NT = TPW * NSR;
+    constexpr int RS_PB = rs_pb(HS);
+    constexpr size_t PLANE = (size_t)ROWS * RS_PB;
+    constexpr int XL = ROWS * 16 / 256;                        // activation float4 per thread and 64-deep stage
+    unsigned long long* const stamps = STAMPS ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) + 32 * (size_t)blockIdx.x : nullptr;
+    auto stamp = [&](int i) __attribute__((always_inline)) {
+        if constexpr (STAMPS) {
+            const unsigned long long t = __builtin_amdgcn_s_memtime();
+            if (threadIdx.x == 0 && i < 32) stamps[i] = t;
+        }
+    };
+    stamp(0);
+    extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
+    unsigned short* const planes = reinterpret_cast<unsigned short*>(sk_smem);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lq = lane >> 4;
+    const int ncg = (a.N + 128 * TPW - 1) / (128 * TPW);
+    const int z = pair / ncg, n0 = (pair % ncg) * (128 * TPW);
+    const int c_begin = z * NSR;
+
+    struct Cur { int seg, k0; };
+    auto seek = [&](int stage) __attribute__((always_inline)) {
+        Cur c = {0, 0};
+        int q = stage;
+#pragma unroll
+        for (int sg = 0; sg < GEMM_MAX_SEG - 1; ++sg) {
+            if (c.seg == sg && sg < a.nseg - 1) {
+                const int nst = a.seg[sg].K / SK_BK;
+                if (q >= nst) { q -= nst; c.seg = sg + 1; }
+            }
+        }
+        c.k0 = q * SK_BK;
+        return c;
+    };
+
+    f32x4 acc[MT][TPW * NCT];
+    f32x4 w[D][2][NCT][2];
+    sk_u32x4 bq[2][NCT][3];
+    const float* wp[NCT];
+    auto point_w = [&](auto stepc) __attribute__((always_inline)) {
+        constexpr int i = decltype(stepc)::value;
+        const Cur c = seek(c_begin + m128_stage_of(i));
+        const GemmSeg& g = a.seg[c.seg];
+#pragma unroll
+        for (int cc = 0; cc < NCT; ++cc) {
+            const int col = n0 + 128 * m128_tile_of(i) + (wave * NCT + cc) * 16 + li;
+            wp[cc] = g.B + (size_t)(col < a.N ? col : a.N - 1) * g.ldb + c.k0 + 4 * lq;
+        }
+    };
+    constexpr int LW = 2 * NCT * 2, WP = 4 * NCT, G = 2 * MT;
+    auto load_w1 = [&](auto slot, auto idx) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value, i = decltype(idx)::value, b = i / (2 * NCT), c = (i / 2) % NCT, h = i & 1;
+        w[S][b][c][h] = *reinterpret_cast<const f32x4*>(wp[c] + 32 * b + 16 * h);
+    };
+    auto w_piece = [&](auto slot, auto blk, auto piece, auto which) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot)::value, B_ = decltype(blk)::value, P = decltype(piece)::value, Wh = decltype(which)::value;
+        constexpr int c = P >> 2, i = P & 3;
+        uint32_t p0, p1, p2;
+        sk_split3(w[S][B_][c][i >> 1][2 * (i & 1)], w[S][B_][c][i >> 1][2 * (i & 1) + 1], p0, p1, p2);
+        bq[Wh][c][0][i] = p0; bq[Wh][c][1][i] = p1; bq[Wh][c][2][i] = p2;
+    };
+    // activations of one half (HS stages from `first`): global -> registers, registers -> the three planes
+    auto load_x = [&](f32x4 (&xr)[HS][XL], int first) __attribute__((always_inline)) {
+        sk_static_for<0, HS>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            const Cur c = seek(c_begin + first + st);
+            const GemmSeg& g = a.seg[c.seg];
+            sk_static_for<0, XL>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int f = tid + 256 * j, row = f >> 4, c4 = f & 15;
+                xr[st][j] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(row < a.M ? row : a.M - 1) * g.lda + c.k0 + 4 * c4);
+            });
+        });
+    };
+    auto load_x1 = [&](f32x4 (&xr)[HS][XL], int first, auto idx) __attribute__((always_inline)) {      // one float4 of load_x
+        constexpr int st = decltype(idx)::value / XL, j = decltype(idx)::value % XL;
+        const Cur c = seek(c_begin + first + st);
+        const GemmSeg& g = a.seg[c.seg];
+        const int f = tid + 256 * j, row = f >> 4, c4 = f & 15;
+        xr[st][j] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(row < a.M ? row : a.M - 1) * g.lda + c.k0 + 4 * c4);
+    };
+    auto split_x = [&](f32x4 (&xr)[HS][XL]) __attribute__((always_inline)) {
+        sk_static_for<0, HS>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            sk_static_for<0, XL>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int f = tid + 256 * j, row = f >> 4, c4 = f & 15, kq = c4 & 7;
+                unsigned short* o = planes + (size_t)row * RS_PB + 64 * st + 32 * (c4 >> 3) + 8 * (kq & 3) + 4 * (kq >> 2);
+                uint32_t a0, a1, a2, b0, b1, b2;
+                sk_split3(xr[st][j][0], xr[st][j][1], a0, a1, a2);
+                sk_split3(xr[st][j][2], xr[st][j][3], b0, b1, b2);
+                *reinterpret_cast<sk_u32x2*>(o) = (sk_u32x2){a0, b0};
+                *reinterpret_cast<sk_u32x2*>(o + PLANE) = (sk_u32x2){a1, b1};
+                *reinterpret_cast<sk_u32x2*>(o + 2 * PLANE) = (sk_u32x2){a2, b2};
+            });
+        });
+    };
+
+    // the second half's activations: loaded beside the MFMAs of steps 0 and 1 (one float4 per even row-tile group; the weight loads
+    // take the odd ones), they wait in registers until the re-split.  (First version: all 16 loads in front of the barrier --
+    // entry -> barrier 12.2 k cycles at K = 4096 with 192 KB of loads queued in front of the first MFMA.)
+    f32x4 xr2[HS][XL];
+    {
+        f32x4 xr[HS][XL];
+        load_x(xr, 0);
+        point_w(std::integral_constant<int, 0>{});
+        sk_static_for<0, LW>([&](auto lc) { load_w1(std::integral_constant<int, 0>{}, lc); });
+        __builtin_amdgcn_sched_barrier(0);
+        split_x(xr);
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    sk_static_for<1, D - 1>([&](auto ic) {
+        point_w(ic);
+        sk_static_for<0, LW>([&](auto lc) { load_w1(ic, lc); });
+    });
+    __builtin_amdgcn_sched_barrier(0);
+    stamp(1);
+    __syncthreads();
+    stamp(2);
+    sk_static_for<0, WP>([&](auto pc) { w_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 0>{}); });
+#pragma unroll
+    for (int t = 0; t < MT; ++t)
+#pragma unroll
+        for (int c = 0; c < TPW * NCT; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool direct = a.nsplit == 1;
+    float* const outp = direct ? a.out : a.out + (size_t)z * a.M * a.N;
+    const int ldo = direct ? a.ldo : a.N;
+    auto store_tile = [&](auto tc) __attribute__((always_inline)) {
+        constexpr int tile = decltype(tc)::value;
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+            const int colb = n0 + 128 * tile + (wave * NCT + c) * 16 + 4 * lq;
+#pragma unroll
+            for (int t = 0; t < MT; ++t) {
+                const int m = 16 * t + li;
+                f32x4 v = acc[t][tile * NCT + c];
+                if (m < a.M && colb + 3 < a.N) {
+                    if (direct && a.bias && !STAMPS) v += *reinterpret_cast<const f32x4*>(a.bias + colb);
+                    *reinterpret_cast<f32x4*>(outp + (size_t)m * ldo + colb) = v;
+                } else if (m < a.M) {
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (colb + e < a.N) outp[(size_t)m * ldo + colb + e] = v[e] + ((direct && a.bias) ? a.bias[colb + e] : 0.f);
+                }
+            }
+        }
+    };
+
+    sk_static_for<0, NT>([&](auto stepc) {
+        constexpr int i = decltype(stepc)::value, S = i % D, tile = m128_tile_of(i), hst = i % HS;
+        constexpr bool HAS_LOAD = i + D - 1 < NT, HAS_NEXT = i + 1 < NT;
+        if constexpr (i == TPW * HS) {
+            // ---- the first half of the k range is done for both tiles: the planes take the second half
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            split_x(xr2);
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+            stamp(19);
+        }
+        if constexpr (HAS_LOAD) point_w(std::integral_constant<int, i + D - 1>{});
+        const unsigned short* abase = planes + (size_t)li * RS_PB + 64 * hst + 8 * lq;
+        sk_bf16x8 af[2][3];
+        sk_static_for<0, 3>([&](auto pp) { af[0][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(abase + decltype(pp)::value * PLANE); });
+        sk_static_for<0, G>([&](auto gc) {
+            constexpr int g = decltype(gc)::value, b = g / MT, t = g % MT;
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (g + 1 < G) {
+                constexpr int b1 = (g + 1) / MT, t1 = (g + 1) % MT;
+                const unsigned short* ap = abase + (size_t)t1 * 16 * RS_PB + 32 * b1;
+                sk_static_for<0, 3>([&](auto pp) { af[(g + 1) & 1][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(ap + decltype(pp)::value * PLANE); });
+            }
+            constexpr bool X2_LOAD = i < 2 && g % 2 == 0;       // 2 steps x 8 even groups = the HS * XL = 16 float4 of the second half
+            if constexpr (HAS_LOAD)
+                sk_static_for<g * LW / G, (g + 1) * LW / G>([&](auto lc) { load_w1(std::integral_constant<int, (S + D - 1) % D>{}, lc); });
+            if constexpr (X2_LOAD) load_x1(xr2, HS, std::integral_constant<int, i * (G / 2) + g / 2>{});
+            if constexpr (b == 0 || HAS_NEXT) {
+                sk_static_for<t * WP / MT, (t + 1) * WP / MT>([&](auto pc) {
+                    if constexpr (b == 0) w_piece(std::integral_constant<int, S>{}, std::integral_constant<int, 1>{}, pc, std::integral_constant<int, 1>{});
+                    else w_piece(std::integral_constant<int, (S + 1) % D>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 1>{});
+                });
+            }
+            // operands swapped against the 64-row kernel: A = weight fragment (16 output columns), B = activation fragment (16 rows),
+            // so a lane ends up with FOUR CONSECUTIVE COLUMNS of one row (D[n = 4 lq + r][m = li]) and the tile leaves as 16-byte stores
+            // straight from the accumulators -- no LDS strip, so tile 0 can leave while tile 1 still multiplies
+            sk_static_for<0, NCT>([&](auto cc) {       // smallest terms first
+                constexpr int c = decltype(cc)::value;
+                const sk_bf16x8 b0 = __builtin_bit_cast(sk_bf16x8, bq[0][c][0]), b1_ = __builtin_bit_cast(sk_bf16x8, bq[0][c][1]),
+                                b2 = __builtin_bit_cast(sk_bf16x8, bq[0][c][2]);
+                f32x4 v = acc[t][tile * NCT + c];
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g & 1][2], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b2, af[g & 1][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1_, af[g & 1][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g & 1][1], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b1_, af[g & 1][0], v, 0, 0, 0);
+                v = __builtin_amdgcn_mfma_f32_16x16x32_bf16(b0, af[g & 1][0], v, 0, 0, 0);
+                acc[t][tile * NCT + c] = v;
+            });
+            __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
+            if constexpr (HAS_LOAD || X2_LOAD)
+                __builtin_amdgcn_sched_group_barrier(0x020, (HAS_LOAD ? (g + 1) * LW / G - g * LW / G : 0) + (X2_LOAD ? 1 : 0), 0);
+#pragma unroll
+            for (int k = 0; k < 6 * NCT; ++k) {
+                __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x002, 1, 0);
+            }
+            if constexpr (t == MT - 1) {
+                __builtin_amdgcn_sched_barrier(0);
+                sk_static_for<0, NCT * 3>([&](auto q) { bq[0][decltype(q)::value / 3][decltype(q)::value % 3] = bq[1][decltype(q)::value / 3][decltype(q)::value % 3]; });
+            }
+        });
+        stamp(3 + i);
+        if constexpr (i >= TPW * HS && i % HS == HS - 1) {
+            // second half, the tile's last stage: its accumulators leave now; tile 0's stores run beside tile 1's last two steps
+            store_tile(std::integral_constant<int, tile>{});
+            stamp(12 + tile);
+        }
+    });
+    stamp(31);
+}
+
+template <int D, bool STAMPS = false>
+__global__ __launch_bounds__(256) void gemm_resident_x3_m128_kernel(GemmArgs a) {
+    resident_x3_m128_body<D, STAMPS>(a, blockIdx.x);
+}
+constexpr size_t rs_m128_lds_bytes() { return (size_t)3 * 128 * rs_pb(2) * 2; }
+
+// ------------------------------------------------------------------------------------------------
 // Decomposition.  tot = K / 64 stages in all; a workgroup takes NSR = 4 of them (a 256-deep k range) and TPW = 2 column tiles of
 // 128: TD gates (K = 3072) 12 ranges x 16 column groups = 192 workgroups, LM gates (K = 4096) 256, vocabulary projection 160.
 // MEASURED (round 3, same box): three-stage ranges for the TD gates (256 workgroups of 192 KB of weights instead of 192 of 256 KB)
@@ -332,7 +577,7 @@ static int rs_total_stages(const GemmArgs& a) {
 int gemm_resident_x3_stages(const GemmArgs& a) { return rs_total_stages(a) % 4 == 0 ? 4 : 0; }
 // shapes the kernel can take: 33..64 rows, N a multiple of 4, whole 64-deep stages that split into ranges
 static bool rs_shape_ok(const GemmArgs& a) {
-    if (!gemm_switches().resident_x3 || a.M <= 32 || a.M > 64 || a.N % 4 || a.accumulate) return false;
+    if (!gemm_switches().resident_x3 || a.M <= 32 || a.M > (gemm_switches().resident_m128 ? 128 : 64) || a.N % 4 || a.accumulate) return false;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % SK_BK || a.seg[s].gather) return false;
     return rs_total_stages(a) >= 8 && gemm_resident_x3_stages(a) > 0;
@@ -355,6 +600,19 @@ static int rs_launch(const GemmArgs& a, hipStream_t stream) {
     return ICZ_OK;
 }
 
+template <bool STAMPS>
+static int rs_launch_m128(const GemmArgs& a, hipStream_t stream) {
+    constexpr size_t lds = rs_m128_lds_bytes();
+    static bool attr = false;
+    if (!attr) {
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_m128_kernel<3, STAMPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_resident_x3_m128_kernel<3, STAMPS>), dim3(cdiv(a.N, 256) * a.nsplit), dim3(256), lds, stream, a);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
 #ifdef ICZ_DEV
 static unsigned long long* g_sk_stamps = nullptr;       // development builds: 32 stamps for up to 4096 workgroups
 static int rs_dev_env(const char* name) { const char* e = getenv(name); return e ? atoi(e) : 0; }
@@ -370,15 +628,15 @@ int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
     if (rs_dev_env("ICZ_DEV_STAMPS")) {
         if (!g_sk_stamps) ICZ_CHECK_HIP(hipMalloc((void**)&g_sk_stamps, sizeof(unsigned long long) * 32 * 4096));
         a.bias = reinterpret_cast<const float*>(g_sk_stamps);
-        return rs_launch<4, true>(a, stream);
+        return a.M > 64 ? rs_launch_m128<true>(a, stream) : rs_launch<4, true>(a, stream);
     }
 #endif
-    return rs_launch<4, false>(a, stream);
+    return a.M > 64 ? rs_launch_m128<false>(a, stream) : rs_launch<4, false>(a, stream);
 }
 
 // the pair launch: both problems in the kernel's decomposition with four stages per k range, slabs out (nsplit > 1)
 bool gemm_resident_x3_pair_fits(const GemmArgs& a, const GemmArgs& b) {
-    return rs_shape_ok(a) && rs_shape_ok(b) && gemm_resident_x3_stages(a) == 4 && gemm_resident_x3_stages(b) == 4 && a.N >= 512 && b.N >= 512;
+    return a.M <= 64 && b.M <= 64 && rs_shape_ok(a) && rs_shape_ok(b) && gemm_resident_x3_stages(a) == 4 && gemm_resident_x3_stages(b) == 4 && a.N >= 512 && b.N >= 512;
 }
 int gemm_resident_x3_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
     ICZ_REQUIRE(gemm_resident_x3_pair_fits(a_in, b_in), "gemm_resident_x3_pair: shapes outside the kernel's decomposition");

@@ -1,6 +1,7 @@
-"""Worker of tests/test_gpu_dist_two_ranks.py: one of two data-parallel ranks on the SAME GPU (gloo backend, development
-rehearsal of the one-process-per-GPU RCCL path).  Each rank takes half of the golden Engine batches; after every step the
-parameters must equal what the reference Engine produced on the whole batch in one process."""
+"""Worker of tests/test_gpu_dist_two_ranks.py: one of WORLD_SIZE data-parallel ranks on the SAME GPU (gloo backend, development
+rehearsal of the one-process-per-GPU RCCL path).  Each rank takes its dist.shard_range share of the golden Engine batches (two
+ranks: halves; five ranks: 2 1 1 1 1 of the six images); after every step the parameters must equal what the reference Engine
+produced on the whole batch in one process."""
 import os
 import sys
 
@@ -25,7 +26,9 @@ def main():
     g, fx = tge._load(os.path.join(HERE, "golden"))
     eng, vocab = tge._engine(g, fx)
     B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
-    lo, hi = rank * B // world, (rank + 1) * B // world
+    from simpleimagecaptionzoo_amd import dist as icz_dist
+    lo, hi = icz_dist.shard_range(B, rank, world)
+    assert hi > lo
     dev = "cuda"
 
     def rng_of(seed, T, with_u):

@@ -38,7 +38,7 @@ def make_handle(g, sd=None, max_rows=None, max_len=20):
     # round of tiles (one LDS buffer), one round (eight waves), ragged edges, batched-dgrad shapes with split-K
     ("tn", 4096, 3072, 1280), ("tn", 2100, 2052, 96), ("nn", 1280, 1024, 4096), ("nn", 1280, 1024, 10112), ("nn", 300, 132, 256),
     ("nt", 640, 10102, 1024), ("nt", 2304, 2048, 2048),
-    # the skinny split-precision kernel (csrc/gemm_skinny_x3.hip, 33..128 rows, whole 64-deep chunks): decoder-step shapes at 64
+    # the skinny split-precision kernel (csrc/gemm_resident_x3.hip, 33..128 rows, whole 64-deep chunks): decoder-step shapes at 64
     # and 128 rows, ragged rows / columns, both column-tile widths, K = 64 (one stage) .. 4096
     ("nt", 64, 4096, 3072), ("nt", 128, 4096, 4096), ("nt", 128, 10102, 1024), ("nt", 50, 1024, 1024), ("nt", 100, 2100, 192),
     ("nt", 33, 70, 64), ("nt", 128, 1024, 1024), ("nt", 65, 4100, 448),

@@ -1,6 +1,8 @@
-"""Data parallelism through the real Engine: two ranks (two processes on this one GPU, gloo instead of RCCL) each take half
-of the golden batches; the normaliser is all-reduced before backward, the gradient groups from the library's callback, and
-after every XE / SCST step both ranks hold the parameters the reference Engine produced on the whole batch (tests/dp_worker.py)."""
+"""Data parallelism through the real Engine: two ranks and five ranks (processes on this one GPU, gloo instead of RCCL) each take
+their share of the golden batches (halves; 2 1 1 1 1 of six images); the normaliser is all-reduced before backward, the gradient
+groups from the library's callback, and after every XE / SCST step every rank holds the parameters the reference Engine produced on
+the whole batch (tests/dp_worker.py).  Five is the most a GPU box admits beside the test process (six GPU processes); the 8-rank
+rehearsal of the host-side rules is tests/test_cpu_dist_gloo.py."""
 import os
 import subprocess
 import sys
@@ -10,21 +12,22 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-def test_two_ranks_reproduce_the_single_process_reference_steps():
+@pytest.mark.parametrize("world", [2, 5])
+def test_ranks_reproduce_the_single_process_reference_steps(world):
     import socket
     here = os.path.dirname(os.path.abspath(__file__))
     with socket.socket() as sk:          # a free rendezvous port
         sk.bind(("127.0.0.1", 0))
         port = sk.getsockname()[1]
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(world), LOCAL_RANK="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
         procs.append(subprocess.Popen([sys.executable, os.path.join(here, "dp_worker.py")], env=env, stdout=subprocess.PIPE,
                                       stderr=subprocess.PIPE, text=True))
     outs = []
     for p in procs:
         try:
-            out, err = p.communicate(timeout=300)
+            out, err = p.communicate(timeout=600)
         except subprocess.TimeoutExpired:
             for q in procs:
                 q.kill()

@@ -507,7 +507,7 @@ def test_optimizer_state_is_saved_next_to_the_checkpoint(golden_dir, tmp_path):
 # ------------------------------------------------------------------------------------------------------------------
 def test_predict_slab_path_matches_the_unsplit_gemm(tmp_path):
     """At 33 - 64 rows the vocabulary projection of a decoder step goes through the resident-activation kernel and leaves four
-    split-K slabs that the argmax / multinomial kernels sum (gemm_predict, gemm_skinny_x3.hip); ICZ_PREDICT_SLABS=0 keeps the
+    split-K slabs that the argmax / multinomial kernels sum (gemm_predict, gemm_resident_x3.hip); ICZ_PREDICT_SLABS=0 keeps the
     un-split GEMM with finished logits.  Same 64 rows, same Philox seeds, BUTD / AoA / NIC at full width, one child process per
     setting (the switch is read once per process): identical greedy tokens; sampled tokens (explicit uniforms, Philox dropout)
     identical except where the draw's target u * sum(p) lies within 1e-6 of a CDF edge of the float64 softmax of that step's

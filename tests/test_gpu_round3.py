@@ -357,3 +357,29 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(scaling):
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == scaling and j["steps"] == 2 and j["warmup"] == 1
     assert j["config"]["global_batch"] == (128 if scaling == "weak" else 64) and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["unit"] == "captions/s" and j["higher_is_better"] is True and "grad_allreduce_ms" in j
+
+
+@pytest.mark.parametrize("n,extra", [(2, ["--scaling", "weak"]), (5, ["--scaling", "strong", "--batch", "40"])])
+def test_bench_starts_its_own_ranks(n, extra):
+    """`python bench.py --gpus N` with no launcher and no WORLD_SIZE (the form the driver uses at N = 1): bench.py must start the N
+    ranks itself -- fresh child processes, the parent stays off the GPU -- and relay ONE line with n_gpus = ranks_seen = N
+    (rehearsal mode: all ranks on the one GPU of the box over gloo).  Five ranks x 8 rows: uneven launch timing, the <= 32-row
+    decoder path, four gradient slices reduced from the library's callback under graph replay at ranks >= 2."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ICZ_REHEARSE_ONE_GPU"] = "1"
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "2", "--warmup", "1", "--headline-only"] + extra
+    r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=1200, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(line) == 1, r.stdout[-2000:]
+    j = json.loads(line[0])
+    assert j["n_gpus"] == n and j["ranks_seen"] == n and j["config"]["parallelism"] == "dp%d" % n
+    assert j["config"]["global_batch"] == (128 if n == 2 else 40) and j["value"] > 0 and "grad_allreduce_ms" in j
+
+
+def test_bench_refuses_a_rank_count_that_is_not_the_one_asked_for():
+    """--gpus 2 under WORLD_SIZE = 1 used to print a warning and an n_gpus = 1 line; now it is an error before any work starts."""
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--headline-only"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and "--gpus 2 but WORLD_SIZE = 1" in r.stderr and not [l for l in r.stdout.splitlines() if l.startswith("{")]

@@ -1,5 +1,6 @@
 """Pins the CPU oracle (oracle/) to vectors produced by the reference itself (tests/golden/)."""
 import json
+import sys
 import os
 
 import numpy as np
@@ -447,3 +448,62 @@ def test_corpus_cider_oracle_matches_reference_scorer(golden_dir):
         score, scores = corpus_cider(gts, res)
         assert score == float.fromhex(c["score"]), name
         assert [float(x) for x in scores] == [float.fromhex(x) for x in c["scores"]], name
+
+
+# ------------------------------------------------------------------------------------------------
+# Full-width goldens (tests/golden/make_fullwidth_goldens.py): the oracle at H = E = A = 1024, V = 10102 against the reference's own
+# output -- the width every bench-size parity test uses the oracle at.
+def test_butd_oracle_step_at_full_width(golden_dir):
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    sys.path.insert(0, golden_dir)
+    from synth import feats_from_seed, probe_indices
+    g = load(golden_dir, "butd_fullwidth_step")
+    B, R, D, H, E, A, V = [int(x) for x in g["dims"]]
+    seed = int(g["seed"])
+    p = random_butd_params(R, D, H, E, A, V, "cpu", seed=seed)
+    rs = np.random.RandomState(seed)
+    feats = torch.from_numpy(feats_from_seed(seed + 1, B, R, D))
+    st = tuple(torch.from_numpy((rs.randn(B, H) * 0.5).astype(np.float32)) for _ in range(4))
+    it = torch.from_numpy(rs.randint(4, V, size=(B,)).astype(np.int64))
+    with torch.no_grad():
+        logits, alpha, (h1, c1, h2, c2) = ob.step(feats, feats.mean(1), it, st, p)
+        for got, key in ((h1, "nh1"), (c1, "nc1"), (h2, "nh2"), (c2, "nc2"), (alpha, "alpha"), (logits, "logits")):
+            np.testing.assert_allclose(got.numpy(), g["s1_" + key], atol=2e-5, rtol=1e-5, err_msg=key)
+        assert np.array_equal(logits.argmax(1).numpy(), g["s1_argmax"])
+        logits2, alpha2, _ = ob.step(feats, feats.mean(1), logits.argmax(1), (h1, c1, h2, c2), p)
+    np.testing.assert_allclose(alpha2.numpy(), g["s2_alpha"], atol=2e-5, rtol=1e-5)
+    np.testing.assert_allclose(logits2.numpy().reshape(-1)[probe_indices(B * V, 2048)], g["s2_logits_probe"], atol=2e-5, rtol=1e-5)
+    assert np.array_equal(logits2.argmax(1).numpy(), g["s2_argmax"])
+
+
+def test_aoa_oracle_two_steps_at_full_width(golden_dir):
+    sys.path.insert(0, golden_dir)
+    from synth import feats_from_seed, probe_indices
+    from oracle import aoa as oa
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner
+    g = load(golden_dir, "aoa_fullwidth_step")
+    B, R, D, H, E, V, NH = [int(x) for x in g["dims"]]
+    seed = int(g["seed"])
+    torch.manual_seed(seed)
+    m = AoADetection_Captioner(vocab_size=V, num_heads=NH, hidden_dim=H, embed_dim=E, device="cpu")
+    with torch.no_grad():
+        gen = torch.Generator(device="cpu")
+        gen.manual_seed(seed + 17)
+        for name, prm in m.named_parameters():
+            if name.endswith("norm.gain"):
+                prm.add_(torch.randn(prm.shape, generator=gen) * 0.2)
+            if name.endswith("norm.bias"):
+                prm.add_(torch.randn(prm.shape, generator=gen) * 0.1)
+    p = {k: v.detach() for k, v in m.state_dict().items()}
+    rs = np.random.RandomState(seed)
+    feats = torch.from_numpy(feats_from_seed(seed + 1, B, R, D))
+    caps = np.zeros((B, 3), dtype=np.int64)
+    caps[:, 0] = 1
+    caps[:, 1:] = rs.randint(4, V, size=(B, 2))
+    with torch.no_grad():
+        refined = oa.refine(feats, p).numpy().reshape(-1)
+        np.testing.assert_allclose(refined[probe_indices(refined.size, 4096)], g["refined_probe"], atol=2e-5, rtol=1e-5)
+        packed = oa.forward_xe(feats, torch.from_numpy(caps), [2] * B, p)
+    packed = packed[0] if isinstance(packed, tuple) else packed
+    np.testing.assert_allclose(packed.numpy(), g["packed_logits"], atol=1e-4, rtol=1e-5)
+    assert np.array_equal(packed.argmax(1).numpy(), g["argmax"])

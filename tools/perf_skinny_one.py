@@ -6,5 +6,5 @@ from simpleimagecaptionzoo_amd.butd import gemm
 M, N, K, ns = [int(x) for x in sys.argv[1:5]]
 X = torch.randn(M, K, device="cuda"); Ws = [torch.randn(N, K, device="cuda") * 0.03 for _ in range(6)]
 for i in range(60):
-    gemm("nt", X, Ws[i % 6], None, ns, planes=bool(int(os.environ.get("PLANES", "0"))))
+    gemm("nt", X, Ws[i % 6], None, ns)
 torch.cuda.synchronize()
