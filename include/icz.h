@@ -351,8 +351,9 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
                  float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,
                  size_t workspace_floats, void* stream);
 size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
-/* Live timing of the dominant kernel (gemm_nt_kernel<4>: every forward GEMM of the decoder step) with HIP events on
- * its launch stream, for bench.py's roofline line.  Between begin and end every launch is bracketed by an event
+/* Live timing of the dominant kernel (the forward GEMMs of a decoder step at 33..64 rows: gemm_resident_x3_kernel, or
+ * gemm_nt_kernel<4, ...> with ICZ_GEMM_RESIDENT_X3=0; see icz_prof_select) with HIP events on its launch stream, for bench.py's
+ * roofline line.  Between begin and end every launch is bracketed by an event
  * pair; end synchronises on them and reports the average duration [us] and the ALGORITHMIC bytes / flops per launch
  * (A read once + W read once + C written once; 2MNK). */
 int icz_prof_begin(void);

@@ -109,9 +109,8 @@ int Butd::refresh(hipStream_t st) {
     hipLaunchKernelGGL(weight_norm_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
     ICZ_CHECK_HIP(hipGetLastError());
     fresh = true;
-    wt_fresh = false;
-    if (wt_lm_ih) ICZ_TRY(refresh_transposes(st));
-    return ICZ_OK;
+    wt_fresh = false;       // the transposed copies (117 MB) are rebuilt by the first backward pass that follows, outside its captured
+    return ICZ_OK;          // graph (sample_backward / xe_backward*): evaluation loops refresh per batch and never read them
 }
 
 // the transposed copies serve 33..64-row dgrad steps through gemm_resident_x3: K = 4H in whole k ranges, N = D + H / H wide enough

@@ -682,6 +682,7 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
     best = sv[0]; bi = si[0];
 #pragma unroll
     for (int w = 1; w < 16; ++w) argmax_combine(best, bi, sv[w], si[w]);
+    if ((unsigned)bi >= (unsigned)V) bi = 0;        // a row of NaN / -inf logits (diverged training) never updates bi: <pad>, not a wild read
     if (tid == 0) {
         it_next[row] = bi;
         if (ids_out) ids_out[(size_t)row * ids_stride + t] = bi;
@@ -1015,8 +1016,12 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     // pass 3: only the slice that crosses the target is walked again
     int cand = 0x7fffffff;
     {
-        double run = wave_off + inc - loc;               // cumulative sum before the slice; run + loc after it (the scan's values)
-        if (run <= target && run + loc > target) {
+        // [lower, upper) of this thread's slice: lower IS the previous lane's upper (the scan's own value, shuffled -- not
+        // inc - loc, which can differ from it in the last place and leave a one-ulp gap that no thread claims: the draw then fell
+        // through to V - 1); across waves the lower bound of lane 0 is the same sum of wave totals as the previous wave's upper
+        const double prev = __shfl_up(inc, 1, 64);
+        double run = wave_off + (lane ? prev : 0.0);
+        if (run <= target && wave_off + inc > target) {
             cand = v1 - 1;                               // the slice's last element carries the scan's own cumulative value
             for (int v = v0; v < v1 - 1; ++v) {
                 run += (double)expf((srow[v] - mx) - lse);

@@ -861,7 +861,7 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
 }
 
 // ------------------------------------------------------------------------------------------------
-// Optional timing of every gemm_nt_kernel<4> launch with HIP events on the launch stream (bench.py's live
+// Optional timing of the decoder-step forward GEMMs (33..64 rows; icz_prof_select) with HIP events on the launch stream (bench.py's live
 // roofline measurement).  Off by default; nothing is recorded or allocated unless enabled.
 struct GemmProf {
     bool on = false;

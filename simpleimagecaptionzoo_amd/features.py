@@ -17,6 +17,7 @@ images' rows with an offset table, and a batch is padded with zero rows to its l
 AoA_Engine.modify_visual_inputs does (AoA_Engine.py:33-40), the counts travelling with it as `bu_counts`.
 """
 import json
+import itertools
 import os
 
 import numpy as np
@@ -138,12 +139,14 @@ def wait_event(ev):
 class DevicePrefetcher:
     """Iterate `loader` (batch tuples of Datasets.py:153-175: img_ids first, supp_info_datas last) one batch ahead of the
     consumer.  Features come from `store` (by image id) or, without a store, from the tuples' own supp_info_datas."""
+    _tokens = itertools.count(1)
 
     def __init__(self, loader, device="cuda:0", store=None, depth=3, on_batch=None, gather_threads=4):
         """on_batch(batch): optional host-side work for a batch, run on the worker thread before the batch is handed over
         (e.g. CiderDReward.prepare: cooking the references of images the scorer has not seen yet).  gather_threads: the copy
         of a batch's per-image features into pinned memory is split over this many threads (numpy copies release the GIL)."""
         self.loader, self.store, self.on_batch = loader, store, on_batch
+        self.token = next(DevicePrefetcher._tokens)      # never reused, unlike id(self): the Engine keys its buffer-address set on it
         self.device = torch.device(device)
         self.depth = max(2, int(depth))
         self._pool = None
@@ -193,7 +196,7 @@ class DevicePrefetcher:
             ev = torch.cuda.Event()
             ev.record(self.copy_stream)
         self._ready[slot] = ev
-        out = {"bu_feats": dev, "bu_bboxes": boxes, "bu_ring": (id(self), self.depth)}      # bu_ring: one of this loader's `depth` reused device buffers
+        out = {"bu_feats": dev, "bu_bboxes": boxes, "bu_ring": (self.token, self.depth)}      # bu_ring: one of this loader's `depth` reused device buffers
         if min(counts) < R:
             out["bu_counts"] = counts
         return batch[:-1] + (out,)
