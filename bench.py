@@ -220,6 +220,29 @@ def aoa_scst(words, device, B):
            "note": "AoADetection_Eng.SCST_training_epoch: refiner x2 (eval + train mode), greedy + sampled rollout, CIDEr-D reward, "
                    "REINFORCE backward of the decoder, clamp + Adam"}
     out["roofline"] = aoa_roofline(B)
+    # config 5 names beam 5: AoADetection beam-search decode (AoA_Model.py:403-502) of the same batch, 5 rows per image, 20 steps
+    # (random-init weights never emit <end>: every step runs), refiner pass included
+    try:
+        h = eng.model._handle()
+        with torch.cuda.stream(eng.stream):
+            f = batches[0][3]["bu_feats"]
+            for _ in range(3):
+                h.beam_search(f, 5, 20)
+            torch.cuda.synchronize()
+            t0 = _t.perf_counter()
+            for _ in range(10):
+                h.beam_search(f, 5, 20)
+            torch.cuda.synchronize()
+            bdt = (_t.perf_counter() - t0) / 10
+        out["beam5"] = {"captions_per_s": B / bdt, "ms": bdt * 1e3, "batch": B, "steps": 20,
+                        "note": "AoADetection beam 5 (refiner + 20 steps at 5 x %d decoder rows), eager launches" % B,
+                        "roofline": csv_roofline(
+                            "aoa_beam5_b64_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
+                            "LSTM gates (K = 3072, N = 4096), AoA linear (2048 x 2048) and vocabulary projection (10112 x 1024) of a beam "
+                            "step at 320 rows + the refiner's GEMMs at 2304 rows (same kernel)",
+                            flops_per_launch=None)}
+    except Exception as e:
+        out["beam5"] = {"error": repr(e)}
     return out
 
 
@@ -287,7 +310,9 @@ def csv_roofline(suffix, kernel, what, flops_per_launch=None, bytes_per_launch=N
                "source": "profiles/%s (rocprofv3 --kernel-trace --stats at the committed code, NOT this run)" % os.path.basename(path)}
         t_mfma = flops_per_launch / (mfma_peak * 1e12) if flops_per_launch else 0.0
         t_hbm = bytes_per_launch / (HBM_PEAK_GBS * 1e9) if bytes_per_launch else 0.0
-        if t_mfma >= t_hbm:
+        if not flops_per_launch and not bytes_per_launch:      # mixed shapes on one kernel: duration and share only
+            out.update({"bound": "mfma", "achieved": None, "peak": mfma_peak, "unit": "TFLOP/s", "frac": None, "traffic": None})
+        elif t_mfma >= t_hbm:
             tf = flops_per_launch / (us * 1e-6) / 1e12
             out.update({"bound": "mfma", "achieved": tf, "peak": mfma_peak, "unit": "TFLOP/s", "frac": tf / mfma_peak, "traffic": None,
                         "peak_note": "2.5 PFLOP/s bf16 / 6 MFMAs per fp32 product (split precision)"})

@@ -268,6 +268,14 @@ int icz_aoa_xe_forward(icz_aoa_t* h, const float* feats, const int64_t* captions
 int icz_aoa_xe_backward(icz_aoa_t* h, float smoothing, const icz_aoa_params* grads, float* loss_out, float n_tokens_global,
                         void* stream);
 int icz_aoa_set_norm_global(icz_aoa_t* h, const float* norm_dev, void* stream);
+/* Data-parallel overlap hook of the AoA decoder's backward passes (icz_aoa_sample_backward, icz_aoa_xe_backward), as
+ * icz_butd_set_grad_callback: cb(user, stage) is called on the calling thread while the backward pass is being enqueued, each time
+ * a group of the decoder's gradients (the only parameters in the reference's optimizer, AoA_Model.py:669-674) is complete in
+ * stream order:
+ *   stage 0: decoder.predict.{weight_v, weight_g, bias} -- before the reverse-time loop, so its all-reduce runs beside all of BPTT;
+ *   stage 1: decoder.embed.0.weight, decoder.lstm.{weight_ih, weight_hh, bias_ih, bias_hh};
+ * the attention block's and h_norm's gradients are complete when the call returns.  NULL removes the hook. */
+int icz_aoa_set_grad_callback(icz_aoa_t* h, icz_grad_ready_cb cb, void* user);
 /* As icz_butd_saved_alphas: the decoder block's attention weights averaged over the heads (AoA_Model.py:118), [B, T, regions]. */
 int icz_aoa_saved_alphas(icz_aoa_t* h, float* alphas_out, void* stream);
 /* Scheduled sampling for the following icz_aoa_xe_forward calls (AoA_Model.py:258-270): see icz_butd_set_scheduled_sampling. */

@@ -116,6 +116,7 @@ def lib():
         "icz_butd_bind_params": (C.c_int, [vp, C.POINTER(ButdParams)]),
         "icz_butd_set_option": (C.c_int, [vp, C.c_char_p, i32]),
         "icz_butd_set_grad_callback": (C.c_int, [vp, GRAD_READY_CB, vp]),
+        "icz_aoa_set_grad_callback": (C.c_int, [vp, GRAD_READY_CB, vp]),
         "icz_butd_set_mask_sum_global": (C.c_int, [vp, vp, vp]),
         "icz_butd_refresh_weights": (C.c_int, [vp, vp]),
         "icz_butd_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp, vp]),

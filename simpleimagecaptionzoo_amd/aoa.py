@@ -83,6 +83,12 @@ class AoaHandle:
     def enable_graphs(self, on):      # the AoA paths are launched eagerly (no captured graphs yet)
         self._persistent = bool(on)
 
+    def set_grad_callback(self, fn):
+        """fn(stage) is called while a backward call is being enqueued, each time a group of decoder gradients is complete in
+        stream order (include/icz.h: icz_aoa_set_grad_callback); None removes it."""
+        self._grad_cb = _lib.GRAD_READY_CB(lambda user, stage: fn(int(stage))) if fn is not None else _lib.GRAD_READY_CB()
+        check(lib().icz_aoa_set_grad_callback(self._h, self._grad_cb, None))
+
     def bind(self, tensors):
         st = AoaParams()
         keep = {}

@@ -68,6 +68,7 @@ struct Aoa {
     int64_t* it = nullptr;
     float* amax_val = nullptr; int* amax_idx = nullptr;
     uint64_t* d_seed = nullptr; float* d_msum = nullptr;
+    icz_grad_ready_cb grad_cb = nullptr; void* grad_cb_user = nullptr;      // DP overlap hook (icz_aoa_set_grad_callback)
     float ss_prob = 0.f; const float* ss_gate = nullptr; const float* ss_draw = nullptr;      // scheduled sampling in xe_forward
     BeamBuf bm;
     // training buffers (aoa_train.hip), slot stride = max_rows: th/tm/tctx slot 0 = zeros, slot t+1 = after step t

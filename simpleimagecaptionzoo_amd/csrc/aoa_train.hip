@@ -487,6 +487,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     ICZ_TRY(colsum(tlogit, TB, V, Vp, G.predict_b, st));
     hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
                        G.predict_g, V, Hd);
+    if (grad_cb) grad_cb(grad_cb_user, 0);      // predict.* complete in stream order: reduced beside the reverse-time loop
     if (rows_t[T - 1] < B) {      // ragged batch: rows that are inactive at step t contribute exact zeros to the batched GEMMs
         ICZ_CHECK_HIP(hipMemsetAsync(dZ, 0, sizeof(float) * (size_t)TB * 2 * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dQp, 0, sizeof(float) * (size_t)TB * Hd, st));
@@ -540,6 +541,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st));
     ICZ_TRY(colsum(dG, TB, 4 * Hd, 4 * Hd, G.lstm_b_ih, st));
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lstm_b_hh, G.lstm_b_ih, sizeof(float) * 4 * Hd, hipMemcpyDeviceToDevice, st));
+    if (grad_cb) grad_cb(grad_cb_user, 1);      // embed + lstm.*: reduced beside the attention block's weight gradients
     ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st));
     ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st));
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
@@ -606,6 +608,12 @@ int icz_aoa_saved_alphas(icz_aoa_t* h, float* alphas_out, void* stream) {
     const int n = a->cur_B * a->cur_T * a->cur_R;
     hipLaunchKernelGGL(saved_alphas_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, a->tP, a->cur_T, a->cur_B, a->dims.NH, a->cur_R, alphas_out);
     ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+int icz_aoa_set_grad_callback(icz_aoa_t* h, icz_grad_ready_cb cb, void* user) {
+    ICZ_REQUIRE(h, "null handle");
+    Aoa* a = reinterpret_cast<Aoa*>(h);
+    a->grad_cb = cb; a->grad_cb_user = user;
     return ICZ_OK;
 }
 int icz_aoa_set_norm_global(icz_aoa_t* h, const float* norm_dev, void* stream) {

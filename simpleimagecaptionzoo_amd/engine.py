@@ -498,6 +498,11 @@ class AoADetection_Eng(BUTDDetection_Eng):
     `use_bu='adaptive'` (10..100 boxes per image, Main.py:158): the handle is sized for 100 regions and every batch carries
     its region counts (AoA_Engine.py:37-46 builds the equivalent prefix masks)."""
 
+    # the AoA library's callback stages (include/icz.h: icz_aoa_set_grad_callback): 41 MB + 92 MB of the 163 MB of decoder gradients are
+    # on the wire before the backward call returns; the attention block and h_norm (30 MB) follow after it
+    _GRAD_STAGES = (("decoder.predict.weight_v", "decoder.predict.weight_g", "decoder.predict.bias"),
+                    ("decoder.embed.0.weight", "decoder.lstm.weight_ih", "decoder.lstm.weight_hh", "decoder.lstm.bias_ih", "decoder.lstm.bias_hh"))
+
     def model_construction(self, max_batch):
         from .aoa import AoADetection_Captioner
         s = self.settings

@@ -173,9 +173,33 @@ def _supp(feats):
     return tuple({"bu_feat": feats[i], "bu_bbox": np.zeros((feats.shape[1], 4), np.float32)} for i in range(feats.shape[0]))
 
 
-def test_aoa_engine_xe_step_scst_step_and_eval(g):
+@pytest.mark.parametrize("dp", [False, True])
+def test_aoa_engine_xe_step_scst_step_and_eval(g, dp):
     """AoADetection_Eng: one training_epoch step = golden XE gradients -> clamp 0.1 -> Adam (oracle restatement) on the decoder
-    only; then one SCST step and the evaluation JSON run end to end on the device."""
+    only; then one SCST step and the evaluation JSON run end to end on the device.  dp: the same through the data-parallel path on
+    a one-rank RCCL group (sums over one rank are identities): normaliser all-reduce, the AoA library's gradient-ready callback
+    (icz_aoa_set_grad_callback: predict.* before the reverse-time loop, embed + lstm.* before the attention block's weight
+    gradients) starting an all-reduce per group, the remainder reduced after the call, clamp + Adam afterwards."""
+    import torch.distributed as td
+    from simpleimagecaptionzoo_amd import dist as icz_dist
+    real = icz_dist.is_distributed
+    if dp:
+        if not td.is_initialized():
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29534")
+            td.init_process_group(backend="nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+        icz_dist.is_distributed = lambda: True
+    try:
+        eng = _aoa_engine_steps(g)
+        if dp:
+            assert len(eng._stage_slices) == 3 and eng._hooked is not None and not eng._pending
+            lo, hi = eng._stage_slices[0]
+            assert hi - lo >= sum(eng._gviews[k].numel() for k in eng._GRAD_STAGES[0])
+    finally:
+        icz_dist.is_distributed = real
+
+
+def _aoa_engine_steps(g):
     from oracle.butd import Adam
     from simpleimagecaptionzoo_amd.engine import AoADetection_Eng, init_optimizer
     from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
@@ -213,6 +237,7 @@ def test_aoa_engine_xe_step_scst_step_and_eval(g):
     assert all(torch.equal(now[k], before[k]) for k in now if not k.startswith("decoder."))
     res = eng.eval_captions_json_generation([(tuple(range(B)), None, _supp(feats))], eval_beam_size=3, tqdm_visible=False)
     assert len(res) == B and all(isinstance(r["caption"], str) and r["image_id"] == i for i, r in enumerate(res))
+    return eng
 
 
 @pytest.mark.parametrize("cfg", [(3, 36, 96, 64, 32, 101, 8), (5, 20, 64, 128, 64, 203, 8), (2, 49, 128, 96, 48, 77, 4)])

@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 summaries of the bench command -> gpurun_out/prof_r03/ (copy what is to be judged into profiles/)
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_${ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PD=$(mktemp -d /tmp/prof_XXXXXX)

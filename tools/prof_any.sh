@@ -2,7 +2,7 @@
 # usage: tools/prof_any.sh <tag> <python script and args...>  -> gpurun_out/prof_r03/<tag>_kernel_stats.csv + top kernels on stdout
 tag=$1; shift
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_${ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PD=$(mktemp -d /tmp/prof_XXXXXX)

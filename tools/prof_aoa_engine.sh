@@ -1,7 +1,7 @@
 #!/bin/bash
 # rocprofv3 kernel stats of tools/perf_aoa_engine.py (13 AoA SCST steps through the Engine) -> gpurun_out/prof_r03/aoa_kernel_stats.csv
 ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
-OUT=$ROOT/gpurun_out/prof_r03
+OUT=$ROOT/gpurun_out/prof_${ROUND:-r04}
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 PD=$(mktemp -d /tmp/prof_XXXXXX)

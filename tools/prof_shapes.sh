@@ -12,7 +12,7 @@ for shape in "$@"; do
 import csv, sys
 for r in csv.DictReader(open(sys.argv[1])):
     n = r["Name"]
-    if "gemm" in n or "slab" in n:
+    if "gemm" in n or "slab" in n or "pack" in n:
         print("   %-70s calls %4s avg %8.2f us min %8.2f" % (n[:70], r["Calls"], float(r["AverageNs"]) / 1e3, float(r["MinNs"]) / 1e3))
 PY
 done
