@@ -936,12 +936,16 @@ static bool nt_x3big(const GemmArgs& a) {
     if (a.nseg == 1) {
         if (tiles * (a.seg[0].K / 512 > 0 ? a.seg[0].K / 512 : 1) >= 128) return true;
         // few tiles but many rows (dec_att of a beam step: 640 x 1024 x 1024 = 40 tiles): 256-deep splits still fill most of the chip,
-        // and the fp32 kernel needs 25 us for it (round 2's beam profile)
-        return a.M >= 256 && tiles * (a.seg[0].K / 256) >= 128;
+        // and the fp32 kernel needs 25 us for it (round 2's beam profile).  Round 4: from 64 such workgroups on (the query
+        // projection of an AoA beam step at 320 rows: 24 tiles x 4 splits)
+        return a.M >= 256 && tiles * (a.seg[0].K / 256) >= 64;
     }
     int tot = 0;                                   // several segments: their concatenation is split as well (gemm_pick_split)
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / 128;
-    return tiles * (tot / 8 > 0 ? tot / 8 : 1) >= 128;
+    // round 4: with few tiles (the AoA linear of a beam step, 320 x 2048 over [x_att | q]: 48 tiles) 512-deep splits count as well --
+    // the fp32 kernel took 28 us per launch for it (profiles/r04_aoa_beam5_b64_kernel_stats.csv: 15 % of AoA beam search)
+    const int per = (a.M >= 256 && tiles < 128) ? 4 : 8;
+    return tiles * (tot / per > 0 ? tot / per : 1) >= 128;
 }
 static int nt_tile_n(const GemmArgs& a) { return 64; }      // fp32 NT kernel: four waves x one 16-column tile
 
@@ -958,7 +962,8 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
             int tot = 0;
             for (int sg = 0; sg < a.nseg; ++sg) tot += a.seg[sg].K / 128;
             int s = 512 / (tiles > 0 ? tiles : 1);
-            if (s > tot / 8) s = tot / 8;
+            const int per = (a.M >= 256 && tiles < 128) ? 4 : 8;      // chunks of 128 per split at least (see nt_x3big)
+            if (s > tot / per) s = tot / per;
             if (s < 1) s = 1;
             return cdiv(tot, cdiv(tot, s));
         }
