@@ -238,9 +238,9 @@ def aoa_scst(words, device, B):
                         "note": "AoADetection beam 5 (refiner + 20 steps at 5 x %d decoder rows), eager launches" % B,
                         "roofline": csv_roofline(
                             "aoa_beam5_b64_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
-                            "LSTM gates (K = 3072, N = 4096), AoA linear (2048 x 2048) and vocabulary projection (10112 x 1024) of a beam "
-                            "step at 320 rows + the refiner's GEMMs at 2304 rows (same kernel)",
-                            flops_per_launch=None)}
+                            "per decode 13 refiner GEMMs at 2304 rows (projection 2048 -> 1024, six layers of Q/K/V 1024 -> 3072 and AoA linear "
+                            "2048 -> 2048) + the LSTM-gate GEMM (320 x 4096 x 3072) of the 19 beam steps at 5 x 64 rows: 356 GFLOP over 32 launches",
+                            flops_per_launch=(2.0 * B * R * (2048 * 1024 + 6 * (3072 * 1024 + 2048 * 2048)) + 19 * 2.0 * 5 * B * 4096 * 3072) / 32.0)}
     except Exception as e:
         out["beam5"] = {"error": repr(e)}
     return out
