@@ -102,3 +102,59 @@ def test_aoa_two_steps_match_reference_at_full_width(golden_dir):
     np.testing.assert_allclose(packed.cpu().numpy(), g["packed_logits"], atol=1e-4, rtol=1e-4)
     clear = g["margin"] > 1e-3
     assert np.array_equal(packed.argmax(1).cpu().numpy()[clear], g["argmax"][clear]) and clear.any()
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# The 128-row resident GEMM inside real decodes (65..128 decoder rows): greedy evaluation at batch 128 and beam 5 over 25 images
+# (125 rows; its first step runs one row per image = 25 rows, the later ones 125) at full width against the CPU oracle.
+def _sharp_params(seed):
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    params = random_butd_params(R, D, H, E, A, V, "cuda", seed=seed)
+    params["predict.weight_g"].mul_(6.0)        # trained decoders are far from uniform: well separated argmax (tests/test_gpu_round2.py)
+    return params
+
+
+def test_greedy_at_128_rows_matches_oracle_and_the_64_row_path():
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    params = _sharp_params(91)
+    h = ButdHandle(R, D, H, E, A, V, 128, 20)
+    h.bind(params)
+    torch.manual_seed(8)
+    feats = torch.relu(torch.randn(128, R, D, device="cuda"))
+    ids128 = h.greedy(feats, 20).cpu().numpy()
+    ids_a = h.greedy(feats[:64].contiguous(), 20).cpu().numpy()           # 33..64 rows: the 64-row resident kernel
+    ids_b = h.greedy(feats[64:].contiguous(), 20).cpu().numpy()
+    ids100 = h.greedy(feats[:100].contiguous(), 20).cpu().numpy()         # ragged: 100 of the kernel's 128 rows
+    p = {k: v.detach().cpu() for k, v in params.items()}
+    rows = [0, 63, 64, 99, 127]
+    with torch.no_grad():
+        want, _, logits = ob.greedy(feats[rows].cpu(), p, 20)
+    top2 = torch.topk(logits, 2, dim=2).values
+    clear = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()                # steps whose argmax no fp32 reordering can flip
+    for j, r in enumerate(rows):
+        n = int(np.argmin(clear[j])) if not clear[j].all() else 20        # compare up to the first unclear step
+        assert n >= 10 and np.array_equal(ids128[r, :n], want[j, :n].numpy()), (r, n)
+    same = (ids128 == np.concatenate([ids_a, ids_b])).all(1)
+    assert same.sum() >= 126, int(same.sum())                             # the two kernels sum in different orders: near-ties may differ
+    assert (ids100 == ids128[:100]).all(1).sum() >= 99
+    h.close()
+
+
+def test_beam5_at_125_rows_matches_oracle():
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.butd import ButdHandle
+    params = _sharp_params(92)
+    n_img, k, steps = 25, 5, 20
+    h = ButdHandle(R, D, H, E, A, V, n_img * k, 20)
+    h.bind(params)
+    torch.manual_seed(9)
+    feats = torch.relu(torch.randn(n_img, R, D, device="cuda"))
+    seqs, lens = h.beam_search(feats, k, steps)
+    seqs, lens = seqs.cpu().numpy(), lens.cpu().numpy()
+    p = {k_: v.detach().cpu() for k_, v in params.items()}
+    for i in (0, 12, 24):
+        want = ob.beam_search(feats[i:i + 1].cpu(), p, k, steps).numpy().ravel()
+        got = seqs[i, :lens[i]]
+        assert got.shape == want.shape and np.array_equal(got, want), (i, got.tolist(), want.tolist())
+    h.close()
