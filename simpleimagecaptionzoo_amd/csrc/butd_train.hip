@@ -506,9 +506,12 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
     if (phases & 1) {
     bptt_joined = false;
-    ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
-    ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
-    {
+    // The side branch is forked here (it depends on dlogits only) but ISSUED behind the d h2drop GEMM below, the head of the critical
+    // chain: issued first, its 10112 x 1024 x 1280 GEMM took the CUs ahead of that product.  Round 4, three same-box rounds: backward
+    // 2.738 / 2.718 / 2.729 ms against 2.777 / 2.828 / 2.803 ms (profiles/r04_backward_issue_order.log); forking it behind the
+    // product as well (no overlap with it at all): 2.762 / 2.779 / 2.750 ms.
+    auto side_branch = [&]() -> int {
+        ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
         hipStream_t sb = concurrent ? low_st : st;   // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
         int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb);
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 32)), dim3(256), 0, sb, tb.logit, TB, V, (int)Vp, G.predict_b);
@@ -516,7 +519,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
                            G.predict_v, G.predict_g, V, H);
         ICZ_CHECK_HIP(hipEventRecord(ev_join, sb));
         if (s1 != ICZ_OK) { (void)hipStreamWaitEvent(st, ev_join, 0); return s1; }
-    }
+        return ICZ_OK;
+    };
+    ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     {
         GemmArgs g = {};
         g.nseg = 1;
@@ -524,12 +529,13 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         g.M = TB; g.N = H; g.out = tb.dH2d; g.ldo = H;
         int ns;
         const int sg = gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st);
-        if (sg != ICZ_OK) { (void)hipStreamWaitEvent(st, ev_join, 0); return sg; }
+        if (sg != ICZ_OK) return sg;          // nothing is forked yet: the side branch is issued behind this product
         if (ns > 1) {
             size_t MN = (size_t)TB * H;
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, H, (const float*)nullptr, tb.dH2d);
         }
     }
+    ICZ_TRY(side_branch());
     // ---- XE only: rows that dropped out of the batch must contribute zero (the sample path writes every row, and its
     //      accumulators are initialised by the first processed step)
     const bool ragged = rows_t[T - 1] < B;
