@@ -83,6 +83,8 @@ Butd::~Butd() {
     if (low_st) (void)hipStreamDestroy(low_st);
     if (ev_fork2) (void)hipEventDestroy(ev_fork2);
     if (ev_join2) (void)hipEventDestroy(ev_join2);
+    if (ev_fork3) (void)hipEventDestroy(ev_fork3);
+    if (ev_join3) (void)hipEventDestroy(ev_join3);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     clear_graphs();

@@ -502,6 +502,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         ICZ_CHECK_HIP(hipStreamCreateWithPriority(&low_st, hipStreamNonBlocking, lo));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
     }
     hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
     if (phases & 1) {
@@ -651,6 +653,14 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     }   // phase 0
     if ((phases & 1) && grad_cb && fire_cb) grad_cb(grad_cb_user, 0);
     const int ldtd = H + D + E, ldlm = D + H;
+    // The attention block's tail (phase 3: d enc_ctx, two small weight gradients, bias sums, weight-norm backward: ~0.2 ms of kernels
+    // that fill a fraction of the chip) depends on the loop only.  When the whole backward is one call without a DP callback it is
+    // forked HERE and issued LAST, on the low-priority stream, beside the LSTM weight gradients: backward 2.685 / 2.684 / 2.698 ->
+    // 2.659 / 2.662 / 2.649 ms in three same-box rounds (profiles/r04_backward_issue_order.log; forked behind the TD gradients
+    // instead: slower, 2.73 - 2.75 ms; round 2 had issued such a branch FIRST and lost 0.25 ms).  With a callback the phases are
+    // separate graphs and stay in line.
+    const bool tail_side = phases == 0xF && !grad_cb && concurrent;
+    if (tail_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork3, st));
     if (phases & 2) {
     // ---- embedding gradient: dEmb = dG_td . W_ih_td[:, H+D:] for all steps, then ordered scatter
     {
@@ -682,6 +692,11 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     }   // phase 2
     if ((phases & 4) && grad_cb && fire_cb) grad_cb(grad_cb_user, 2);
     if (phases & 8) {
+    hipStream_t const main_st = st;
+    if (tail_side) {
+        ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork3, 0));
+        st = low_st;
+    }
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
     {   // d enc_ctx (sum over time) and the affine-weight partials, from the ds_t recorded by the loop
         AttBwdDencArgs ea = {enc_ctx, tb.dec, tb.dS, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
@@ -715,6 +730,11 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         add(tb.dWdec, H, P.dec_att_v, P.dec_att_g, n_dec, G.dec_att_v, G.dec_att_g, A, H);
         add(tb.dWaff, A, P.affine_v, P.affine_g, n_aff, G.affine_v, G.affine_g, 1, A);
         hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
+    }
+    if (tail_side) {
+        ICZ_CHECK_HIP(hipEventRecord(ev_join3, low_st));
+        st = main_st;
+        ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join3, 0));
     }
     if (!bptt_joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
     }   // phase 3
