@@ -283,88 +283,40 @@ class BUTDDetection_Eng(Engine):
                 self._stage_slices.append((lo, total))
         return self._gviews
 
-    # ---- the library's gradient-ready callback: data-parallel all-reduce per group, or (one process) clamp + Adam per group --------
-    def _set_hook(self, h, on):
-        """Install / remove the callback of `h` (include/icz.h: icz_*_set_grad_callback).  With a callback the library replays its
-        backward as one captured graph per phase and calls back in between; without one the whole backward is one graph."""
-        if not on:
-            if getattr(self, "_hooked", None) is h:
-                h.set_grad_callback(None)
-                self._hooked = None
-            return
-        if getattr(self, "_hooked", None) is h:
-            return
-
-        def on_ready(stage):
-            try:      # called from inside the C library: an exception cannot propagate through it
-                self._on_stage(stage)
-            except Exception as e:      # re-raised by _backward_end
-                self._hook_error = e
-        h.set_grad_callback(on_ready)
-        self._hooked = h
-
-    def _on_stage(self, stage):
-        mode, optimizer, clip = self._bwd
-        lo, hi = self._stage_slices[stage]
-        if mode == "dp":
+    def _reduce_grads_begin(self, h):
+        """Data-parallel: start the all-reduce of each gradient group as soon as the backward pass has enqueued it, so that
+        RCCL moves it over xGMI beside the remaining weight-gradient GEMMs (the hook is a no-op for one process)."""
+        self._pending = []
+        if not icz_dist.is_distributed() or not self._stage_slices or not hasattr(h, "set_grad_callback"):
+            return False
+        if getattr(self, "_hooked", None) is not h:
             import torch.distributed as td
-            self._pending.append(td.all_reduce(self._flat[lo:hi], op=td.ReduceOp.SUM, async_op=True))
-        elif mode == "adam":
-            # The group's gradients are complete in stream order: its clamp + Adam (Utils.py:241-250, :219-220 -- elementwise, so
-            # any grouping gives the reference's update) goes to a side stream and runs beside the remaining weight-gradient GEMMs
-            # instead of behind them.  Nothing in the rest of the backward pass reads these parameters (the decoder's own copies --
-            # weight-normed matrices, transposes -- are refreshed after the step).
-            named, grads = self._trainable(), self._gviews
-            keys = [k for k in self._GRAD_STAGES[stage] if k in grads]
-            ev = torch.cuda.Event()
-            ev.record()
-            side = self._adam_stream
-            side.wait_event(ev)
-            with torch.cuda.stream(side):
-                optimizer.step_with({named[k]: grads[k] for k in keys}, clip)
-            self._early.update(keys)
 
-    def _backward_begin(self, h, optimizer, clip):
-        """Before a backward call: choose what the gradient-ready callback does.  'dp': start the all-reduce of each gradient group
-        as soon as the backward pass has enqueued it (RCCL moves it over xGMI beside the remaining weight-gradient GEMMs);
-        'adam' (one process, FusedAdam): start the group's clamp + Adam there instead; None: no callback."""
-        self._pending, self._early = [], set()
-        mode = None
-        if getattr(self, "_stage_slices", None) and hasattr(h, "set_grad_callback"):
-            if icz_dist.is_distributed():
-                mode = "dp"
-            elif isinstance(optimizer, FusedAdam) and getattr(self, "pipeline_adam", True):
-                mode = "adam"
-                if getattr(self, "_adam_stream", None) is None:
-                    self._adam_stream = torch.cuda.Stream(device=self.device)
-        self._bwd = (mode, optimizer, clip)
-        self._set_hook(h, mode is not None)
-        return mode
+            def on_ready(stage):
+                try:      # called from inside the C library: an exception cannot propagate through it
+                    lo, hi = self._stage_slices[stage]
+                    self._pending.append(td.all_reduce(self._flat[lo:hi], op=td.ReduceOp.SUM, async_op=True))
+                except Exception as e:      # re-raised by _reduce_grads_end
+                    self._hook_error = e
+            h.set_grad_callback(on_ready)
+            self._hooked = h
+        return True
 
-    def _backward_end(self, mode, optimizer, clip):
-        """After the backward call: finish the reduction (clamp must follow it, Engine.py:271) and apply what is left."""
+    def _reduce_grads_end(self, overlapped):
+        if not icz_dist.is_distributed():
+            return
+        if not overlapped:
+            icz_dist.all_reduce_sum_(self._flat)
+            return
         err, self._hook_error = getattr(self, "_hook_error", None), None
-        if err is not None:
-            raise RuntimeError("gradient hook failed: %r" % (err,))
-        if icz_dist.is_distributed():
-            if mode != "dp":
-                icz_dist.all_reduce_sum_(self._flat)
-            else:
-                if len(self._pending) != len(self._stage_slices) - 1:
-                    raise RuntimeError("gradient hook: %d of %d groups were reduced" % (len(self._pending), len(self._stage_slices) - 1))
-                lo, hi = self._stage_slices[-1]
-                icz_dist.all_reduce_sum_(self._flat[lo:hi])
-                for w in self._pending:
-                    w.wait()
-                self._pending = []
-        if mode == "adam":
-            if len(self._early) != sum(len(st) for st in self._GRAD_STAGES):
-                raise RuntimeError("gradient hook: %d of %d early parameters were updated" % (len(self._early), sum(len(st) for st in self._GRAD_STAGES)))
-            named, grads = self._trainable(), self._gviews
-            optimizer.step_with({named[k]: grads[k] for k in grads if k not in self._early}, clip)
-            torch.cuda.current_stream().wait_stream(self._adam_stream)
-        else:
-            self._apply(optimizer, clip)
+        if err is not None or len(self._pending) != len(self._stage_slices) - 1:
+            raise RuntimeError("gradient hook: %d of %d groups were reduced%s" % (
+                len(self._pending), len(self._stage_slices) - 1, "" if err is None else " (%r)" % (err,)))
+        lo, hi = self._stage_slices[-1]
+        icz_dist.all_reduce_sum_(self._flat[lo:hi])
+        for w in self._pending:
+            w.wait()
+        self._pending = []
 
     def _features(self, visual_inputs):
         """The device tensor the decoder handle consumes (bottom-up features here; NIC: the image embedding)."""
@@ -433,9 +385,10 @@ class BUTDDetection_Eng(Engine):
                     n_glob = -1.0
                 else:
                     n_glob = icz_dist.all_reduce_scalar(n_dev)
-            mode = self._backward_begin(h, optimizer, 0.1)
+            ov = self._reduce_grads_begin(h)
             loss = h.xe_backward(grads, smoothing, n_glob)
-            self._backward_end(mode, optimizer, 0.1)
+            self._reduce_grads_end(ov)
+            self._apply(optimizer, 0.1)
             losses.append(loss)
             if tqdm_visible:
                 monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))
@@ -483,9 +436,10 @@ class BUTDDetection_Eng(Engine):
                     msum_glob = -1.0
                 else:
                     msum_glob = icz_dist.all_reduce_scalar(ms)
-            mode = self._backward_begin(h, optimizer, 0.25)
+            ov = self._reduce_grads_begin(h)
             loss, _ = h.sample_backward(rewards, grads, msum_glob)
-            self._backward_end(mode, optimizer, 0.25)
+            self._reduce_grads_end(ov)
+            self._apply(optimizer, 0.25)
             losses.append(loss.clone())      # with graphs the handle returns one persistent buffer, overwritten by the next step
             if tqdm_visible:
                 monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))

@@ -13,7 +13,7 @@ for bt in batches:
 
 
 def leg(flag):
-    eng.pipeline_adam = flag
+    eng.pipeline_adam = flag          # only read by the rejected patch (tools/cxx/rejected/r4_pipelined_adam.patch)
     eng.SCST_training_epoch(batches[:3], opt, None, tqdm_visible=False)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
