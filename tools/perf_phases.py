@@ -14,6 +14,8 @@ words = [vocab.ix2word[i] for i in range(V)]
 df = document_frequency(synthetic_references(2000, words, seed=0))
 eng = BUTDDetection_Eng({"model_type": "BUTDDetection", "atten_dim": 1024, "embed_dim": 1024, "hidden_dim": 1024, "enc_dim": 2048},
                         "SYN", vocab, data_dir="/tmp/", device="cuda:0", cider_df=df, max_batch=B)
+if os.environ.get("ICZ_NO_GRAPHS"):        # eager launches (host-issued, no captured graphs)
+    eng.use_graphs = False
 opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
 batches = bench.make_batches(4, B, words, "cuda:0", 0)
 eng.SCST_training_epoch(batches, opt, None, tqdm_visible=False)
