@@ -59,6 +59,8 @@ struct Aoa {
     }
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    hipStream_t low_st = nullptr;                         // backward: the predict layer's weight gradient beside the reverse-time loop
+    hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     float *xa = nullptr, *xb = nullptr, *ln = nullptr, *qkv = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
           *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;
     // decoder state + scratch
@@ -109,6 +111,9 @@ struct Aoa {
 
     ~Aoa() {
         if (side_st) (void)hipStreamDestroy(side_st);
+        if (low_st) (void)hipStreamDestroy(low_st);
+        if (ev_fork2) (void)hipEventDestroy(ev_fork2);
+        if (ev_join2) (void)hipEventDestroy(ev_join2);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);

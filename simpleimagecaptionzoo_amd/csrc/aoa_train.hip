@@ -483,10 +483,31 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         const size_t MN = (size_t)TB * Hd;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, Hd, (const float*)nullptr, dCd);
     }
-    ICZ_TRY(tn(tlogit, Vp, Vp, tcd, Hd, Hd, TB, dWp, Hd, 0, st));
-    ICZ_TRY(colsum(tlogit, TB, V, Vp, G.predict_b, st));
-    hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, st, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
-                       G.predict_g, V, Hd);
+    // The predict layer's weight / bias gradients need dlogits only.  Without a DP callback they go to a low-priority side stream,
+    // ISSUED behind the d(ctx) product above (the head of the critical chain, as in Butd::bptt) and joined behind the loop; with a
+    // callback they stay in line, because stage 0 reports them complete in stream order right here.
+    const bool side = !grad_cb;
+    hipStream_t ps = st;
+    if (side) {
+        if (!low_st) {
+            int lo = 0, hi = 0;
+            ICZ_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
+            ICZ_CHECK_HIP(hipStreamCreateWithPriority(&low_st, hipStreamNonBlocking, lo));
+            ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
+            ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+        }
+        ICZ_CHECK_HIP(hipEventRecord(ev_fork2, st));
+        ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork2, 0));
+        ps = low_st;
+    }
+    const int s_tn = tn(tlogit, Vp, Vp, tcd, Hd, Hd, TB, dWp, Hd, 0, ps);
+    if (s_tn == ICZ_OK) {
+        (void)colsum(tlogit, TB, V, Vp, G.predict_b, ps);
+        hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, ps, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
+                           G.predict_g, V, Hd);
+    }
+    if (side) ICZ_CHECK_HIP(hipEventRecord(ev_join2, low_st));
+    if (s_tn != ICZ_OK) { if (side) (void)hipStreamWaitEvent(st, ev_join2, 0); return s_tn; }
     if (grad_cb) grad_cb(grad_cb_user, 0);      // predict.* complete in stream order: reduced beside the reverse-time loop
     if (rows_t[T - 1] < B) {      // ragged batch: rows that are inactive at step t contribute exact zeros to the batched GEMMs
         ICZ_CHECK_HIP(hipMemsetAsync(dZ, 0, sizeof(float) * (size_t)TB * 2 * Hd, st));
@@ -528,6 +549,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         bnext = bt;
         cur ^= 1;
     }
+    if (side) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join2, 0));      // the predict branch has long finished beside the loop
     // ---- embedding gradient
     ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st));
     {
