@@ -59,7 +59,7 @@ struct Aoa {
     }
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    hipStream_t low_st = nullptr;                         // backward: the predict layer's weight gradient beside the reverse-time loop
+    hipStream_t low_st = nullptr;                         // backward: the predict layer's weight gradient beside the reverse-time loop (plain priority)
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     float *xa = nullptr, *xb = nullptr, *ln = nullptr, *qkv = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
           *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;

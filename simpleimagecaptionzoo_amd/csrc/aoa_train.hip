@@ -483,16 +483,16 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         const size_t MN = (size_t)TB * Hd;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, Hd, (const float*)nullptr, dCd);
     }
-    // The predict layer's weight / bias gradients need dlogits only.  Without a DP callback they go to a low-priority side stream,
+    // The predict layer's weight / bias gradients need dlogits only.  Without a DP callback they go to a side stream,
     // ISSUED behind the d(ctx) product above (the head of the critical chain, as in Butd::bptt) and joined behind the loop; with a
     // callback they stay in line, because stage 0 reports them complete in stream order right here.
     const bool side = !grad_cb;
     hipStream_t ps = st;
     if (side) {
         if (!low_st) {
-            int lo = 0, hi = 0;
-            ICZ_CHECK_HIP(hipDeviceGetStreamPriorityRange(&lo, &hi));
-            ICZ_CHECK_HIP(hipStreamCreateWithPriority(&low_st, hipStreamNonBlocking, lo));
+            // a plain stream: eager launches on a PRIORITISED stream beside other streams' work can serialise on this runtime
+            // (EXPERIMENTS.md, round 4, section 8), and the AoA paths are eager
+            ICZ_CHECK_HIP(hipStreamCreateWithFlags(&low_st, hipStreamNonBlocking));
             ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
             ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         }
