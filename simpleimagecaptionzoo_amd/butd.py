@@ -48,6 +48,10 @@ class ButdHandle:
     def set_concurrent(self, on=True):
         check(lib().icz_butd_set_option(self._h, b"concurrent", 1 if on else 0))
 
+    def set_option(self, name, value):
+        """icz_butd_set_option (include/icz.h): "graphs", "concurrent"."""
+        check(lib().icz_butd_set_option(self._h, name.encode(), int(value)))
+
     def _buf(self, name, shape, dtype):
         if not self._persistent:
             return torch.zeros(shape, dtype=dtype, device=self.device)

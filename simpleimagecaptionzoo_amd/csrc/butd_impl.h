@@ -163,6 +163,7 @@ struct Butd {
     int xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
     int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
     int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);
+    int bptt_prelude(hipStream_t st);
     int colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st);
     int bptt(const icz_butd_params& G, hipStream_t st, int phases = 0xF, bool fire_cb = true);
 };

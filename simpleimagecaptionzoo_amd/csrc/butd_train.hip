@@ -257,7 +257,7 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     if (mask_sum_global >= 0.f)      // < 0: keep the device value set by icz_butd_set_mask_sum_global
         hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
     mode = 0;   // the saved logits are consumed
-    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));      // outside the captured graph
+    ICZ_TRY(bptt_prelude(st));      // outside the captured graph
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
     if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
     std::vector<uintptr_t> key = {3, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)mask_sum_out, (uintptr_t)cur_B, (uintptr_t)cur_T,
@@ -409,7 +409,7 @@ int Butd::xe_backward_dlogits(const float* dpacked, const icz_butd_params* G, hi
                        tb.scalars_i + T, T, tb.logit);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
-    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
+    ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
 
@@ -428,7 +428,7 @@ int Butd::sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hi
                        tb.draw, tb.lse, tb.coef, B, T);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
-    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
+    ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
 
@@ -450,7 +450,7 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
-    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
+    ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
 
@@ -481,10 +481,20 @@ int Butd::colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t 
     return ICZ_OK;
 }
 
+// The transposed weight copies of the per-step dgrad products are rebuilt lazily, by the first backward call after an optimizer
+// step: every entry point calls this in front of bptt(), OUTSIDE its captured graph (a replayed graph must not rebuild them).
+int Butd::bptt_prelude(hipStream_t st) {
+    if (wt_lm_ih && !wt_fresh) ICZ_TRY(refresh_transposes(st));
+    return ICZ_OK;
+}
+
 // phases: bit 0 = predict layer + reverse-time loop, bit 1 = embedding and TD-LSTM weight gradients, bit 2 = LM-LSTM weight
 // gradients, bit 3 = attention block, biases, joins.  After each of the first three the corresponding gradient group is complete
 // in stream order (icz_butd_set_grad_callback); fire_cb = false leaves the callbacks to the caller, which replays every phase
 // as its own captured graph and calls them in between.
+//
+// Every ICZ_TRY inside the loop / behind it sits in a lambda: whatever fails, the side stream is joined before the status is
+// returned (inside a capture an unjoined fork would hide the original error behind a capture failure).
 int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_cb) {
     const int B = cur_B, T = cur_T;
     const int H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
@@ -548,7 +558,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dS, 0, sizeof(float) * (size_t)TB * R, st));
     }
 
-    // ---- reverse-time loop
+    // ---- reverse-time loop (a lambda: whatever it returns, the side stream is joined behind it)
+    auto loop = [&]() -> int {
     int cur = 0;
     int ns1 = 1, ns2 = 1, ns3 = 1, ns4 = 1;
     int bnext = 0;
@@ -645,11 +656,14 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         bnext = bt;
         cur ^= 1;
     }
-
-    if (grad_cb) {      // the predict branch has long finished beside the loop: join it now so that its gradients can be reduced
+    return ICZ_OK;
+    };
+    const int s_loop = loop();
+    if (grad_cb || s_loop != ICZ_OK) {      // the predict branch has long finished beside the loop: join it now so that its gradients can be reduced
         ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
         bptt_joined = true;
     }
+    if (s_loop != ICZ_OK) return s_loop;
     }   // phase 0
     if ((phases & 1) && grad_cb && fire_cb) grad_cb(grad_cb_user, 0);
     const int ldtd = H + D + E, ldlm = D + H;
@@ -661,6 +675,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     // separate graphs and stay in line.
     const bool tail_side = phases == 0xF && !grad_cb && concurrent;
     if (tail_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork3, st));
+    bool tail_forked = false;
+    hipStream_t const main_st = st;
+    auto behind_loop = [&]() -> int {
     if (phases & 2) {
     // ---- embedding gradient: dEmb = dG_td . W_ih_td[:, H+D:] for all steps, then ordered scatter
     {
@@ -692,9 +709,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     }   // phase 2
     if ((phases & 4) && grad_cb && fire_cb) grad_cb(grad_cb_user, 2);
     if (phases & 8) {
-    hipStream_t const main_st = st;
     if (tail_side) {
         ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork3, 0));
+        tail_forked = true;
         st = low_st;
     }
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
@@ -731,13 +748,21 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         add(tb.dWaff, A, P.affine_v, P.affine_g, n_aff, G.affine_v, G.affine_g, 1, A);
         hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
     }
-    if (tail_side) {
+    }   // phase 3
+    return ICZ_OK;
+    };
+    const int s_tail = behind_loop();
+    st = main_st;
+    // joins, also on an error (inside a capture an unjoined side stream would hide the original error behind a capture failure)
+    if (tail_forked) {
         ICZ_CHECK_HIP(hipEventRecord(ev_join3, low_st));
-        st = main_st;
         ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join3, 0));
     }
-    if (!bptt_joined) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));      // join the predict-gradient branch
-    }   // phase 3
+    if (((phases & 8) || s_tail != ICZ_OK) && !bptt_joined) {      // join the predict-gradient branch
+        ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
+        bptt_joined = true;
+    }
+    if (s_tail != ICZ_OK) return s_tail;
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
