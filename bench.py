@@ -73,6 +73,47 @@ def make_batches(n, B, words, device, rank, id_base=0):
     return batches
 
 
+def break_step(seq):
+    """The number of steps the reference's sample_rl runs for this rollout (BUTD_Model.py:233: it breaks out behind the first step
+    that leaves no row unfinished): index of the last column with a non-zero token + 2, at most the number of columns."""
+    live = (seq != 0).any(0).nonzero()
+    last = int(live.max().item()) if live.numel() else -1
+    return min(seq.shape[1], last + 2)
+
+
+def end_bias(eng, batches, target_step=11.0):
+    """Make the engine's model END its sampled captions: the <end> row of `predict` becomes a constant logit (weight_g[2] = 0) whose
+    bias is bisected until the reference's sample_rl would break out (BUTD_Model.py:233, all rows finished) after ~target_step of
+    its 20 steps, averaged over `batches`.  Random-init weights never end a caption (the headline's worst case: all 20 steps of
+    both rollouts); a trained captioner does.  Returns the break steps of one rollout per batch at the bias chosen."""
+    named = eng.model._named()
+    bias, gain = named["predict.bias"], named["predict.weight_g"]
+    h = eng._hot_handle()
+
+    def steps_at(b):
+        with torch.no_grad():
+            bias[2] = b
+        h.refresh()
+        out = []
+        for bt in batches:
+            _, seq, _ = h.rollouts(bt[3]["bu_feats"], T, eng.model._next_rng())
+            out.append(break_step(seq))
+        return out
+    with torch.cuda.stream(eng.stream):
+        with torch.no_grad():
+            gain[2] = 0.0
+        lo, hi = 0.0, 30.0
+        for _ in range(12):
+            mid = 0.5 * (lo + hi)
+            if float(np.mean(steps_at(mid))) > target_step:
+                lo = mid
+            else:
+                hi = mid
+        steps = steps_at(hi)
+    torch.cuda.synchronize()
+    return steps
+
+
 def secondary(eng, opt, words, device, B):
     """The other rates SURVEY.md 8d lists next to the headline metric, on the same engine and model size (N = 1, a few
     hundred ms each): XE training step (Engine.training_epoch), greedy and beam-5 decode (eval_captions_json_generation's

@@ -214,13 +214,14 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {embp, P.td_w_ih + H + D, E, H + D + E, E, nullptr};
         g.seg[2] = {s.h1_in, P.td_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
+        g.live = s.live;
         const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
         g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_cap);
         ns = g.nsplit;
         ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_cap && (size_t)rows * 4 * H <= ws_cap, "butd: workspace too small");
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
-        LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H};
+        LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H, s.live};
         launch_lstm_point(a, off, st);
     }
     {   // attention
@@ -228,10 +229,11 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.nseg = 1;
         g.seg[0] = {s.h1_out, w_dec, H, H, H, nullptr};
         g.M = rows; g.N = A; g.out = ws; g.ldo = A;
+        g.live = s.live;
         g.nsplit = gemm_pick_split(g, STEP_WGS);
         ns = g.nsplit;
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
-        AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A};
+        AttScoreArgs a = {enc_ctx, s.img_of_row, ws, ns, P.dec_att_b, w_aff, P.affine_b, s.dec_ctx_out, scores, rows, R, A, s.live};
         const int G = s.rows_per_img;
         // compare the accumulation order: the per-row kernel sums a region row in the lane order of three regions at a time, the
         // grouped one region by region -- identical per (row, region): a wave's lanes cover the same columns in the same order
@@ -244,7 +246,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
                                s.alpha_out ? s.alpha_out : alpha, s.ctx_out ? s.ctx_out : ctx, R, D, G);
         else
             hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 512)), dim3(256), 0, st, s.feats, s.img_of_row, (const float*)scores,
-                               s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D);
+                               s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D, s.live);
     }
     const float* ctxp = s.ctx_out ? s.ctx_out : ctx;
     {   // language LSTM: [ctx, h1] W_ih^T + h2 W_hh^T
@@ -254,19 +256,20 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         g.seg[1] = {s.h1_out, P.lm_w_ih + D, H, D + H, H, nullptr};
         g.seg[2] = {s.h2_in, P.lm_w_hh, H, H, H, nullptr};
         g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
+        g.live = s.live;
         const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;
         g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_cap);
         ns = g.nsplit;
         ICZ_REQUIRE(gemm_slab_floats(rows, 4 * H, ns) <= ws_cap && (size_t)rows * 4 * H <= ws_cap, "butd: workspace too small");
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, nullptr, nullptr, P.lm_b_ih, P.lm_b_hh, s.c2_in, s.h2_out, s.c2_out, s.gates_lm_out,
-                           s.h2drop_out ? s.h2drop_out : h2drop, rows, H};
+                           s.h2drop_out ? s.h2drop_out : h2drop, rows, H, s.live};
         launch_lstm_point(a, s.drop_out, st);
     }
     if (!s.skip_predict) {   // predict: logits = drop(h2) w_pred^T + b  (finished logits, or split-K slabs in the chain's workspace for a consumer that sums them)
         const size_t ws_cap = s.ws_alt ? (tb.xfloats < ws_floats ? tb.xfloats : ws_floats) : ws_floats;      // ws_alt = tb.X[0]
         ICZ_TRY(gemm_predict(s.h2drop_out ? s.h2drop_out : h2drop, H, w_pred, P.predict_b, rows, V, Vp, s.logits_out ? s.logits_out : logits,
-                             s.logits_ld ? s.logits_ld : Vp, ws, ws_cap, s.pred_nsplit, st));
+                             s.logits_ld ? s.logits_ld : Vp, ws, ws_cap, s.pred_nsplit, st, s.live));
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
@@ -292,11 +295,17 @@ int Butd::greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, 
 }
 
 // the decode loop after the per-image prologue
-int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st) {
+// scst = true (the baseline of an SCST step, rollouts_impl): the chain keeps count of the rows that have not emitted <end> yet and,
+// once there is none, the kernels of the remaining steps return at entry (ids = 0 there).  The reference's greedy loop has no break
+// (BUTD_Model.py:171-186), but nothing behind a row's <end> reaches the reward (Utils.py:354 cuts there): the SCST step's results
+// are the same.  icz_butd_greedy (evaluation, `sampler`) never does this: its ids are the reference's in every column.
+int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st, bool scst) {
     ICZ_TRY(zero_state(B, 0, st));
-    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);   // <sta>
+    int* const gn = (scst && early_out && tb.gnunf && tb.T >= max_len && tb.B >= B) ? tb.gnunf : nullptr;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(cdiv(B > max_len ? B : max_len, 256)), dim3(256), 0, st, it, B, gn, max_len);   // <sta>
     int cur = 0;
     const int Vp = pad_vocab(dims.V);
+    bool track = false;
     for (int t = 0; t < max_len; ++t) {
         StepIO s = {};
         s.rows = B; s.feats = feats; s.it = it;
@@ -306,10 +315,13 @@ int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out,
         if (alphas_out) { s.alpha_out2 = alphas_out + (size_t)t * dims.R; s.alpha2_stride = max_len * dims.R; }
         int pns = 1;
         s.pred_nsplit = &pns;
+        if (track && t > 0) s.live = gn + (t - 1);
         ICZ_TRY(step(s, st));
+        if (t == 0) track = gn && pns > 1;     // the one-launch select below keeps the count (the two-kernel argmax of <= 32 rows does not)
         if (pns > 1)         // 33 - 64 rows: the slabs of the vocabulary projection -> token + next embedding in one launch
             hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, (const float*)ws, dims.V, Vp, pns, (size_t)B * Vp,
-                               (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, max_len, t);
+                               (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, max_len, t, 1,
+                               track ? tb.gunf : (uint8_t*)nullptr, track ? gn : (int*)nullptr);
         else {
             hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
             hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
@@ -370,6 +382,7 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
     Butd* b = reinterpret_cast<Butd*>(h);
     if (strcmp(name, "graphs") == 0) { b->use_graphs = value != 0; return ICZ_OK; }
     if (strcmp(name, "concurrent") == 0) { b->concurrent = value != 0; return ICZ_OK; }
+    if (strcmp(name, "early_out") == 0) { b->early_out = value != 0; return ICZ_OK; }
     set_error("icz_butd_set_option: unknown option '%s'", name);
     return ICZ_ERR_INVALID;
 }

@@ -35,6 +35,8 @@ struct StepIO {
     float* scores_alt;               // two decode chains running concurrently must not share them
     DropCfg drop_emb, drop_att, drop_out;
     bool skip_predict;               // teacher-forced XE forward: the vocabulary projection of ALL time steps is one GEMM after the loop
+    const int* live;                 // sampled rollout: the count of unfinished rows after the previous step; 0 = every kernel of this step
+                                     // returns at entry (step_dead, icz_common.h: the reference's break, BUTD_Model.py:233)
 };
 
 // Activations kept by a training-mode forward (slot t = time step, slot stride = B rows) and backward scratch.
@@ -45,6 +47,8 @@ struct TrainBuf {
     float *gtd = nullptr, *glm = nullptr, *dec = nullptr, *alpha = nullptr, *ctx = nullptr, *h2d = nullptr, *logit = nullptr;
     int32_t* draw = nullptr; float* lse = nullptr;
     uint8_t* unf = nullptr; int* nunf = nullptr; float *coef = nullptr, *loss_rows = nullptr;
+    uint8_t* gunf = nullptr; int* gnunf = nullptr;            // the same for the greedy baseline of an SCST step (greedy_chain, scst = true)
+    int* live_rows = nullptr;                                 // (steps the sampled rollout ran) x B: row limit of the backward pass's batched GEMMs
     float *dGtd = nullptr, *dGlm = nullptr, *dDec = nullptr, *dEmb = nullptr, *dH2d = nullptr, *dEnc = nullptr;
     float *dwaff = nullptr, *dalpha = nullptr, *dS = nullptr, *dGsum = nullptr;
     float *dc1[2] = {nullptr, nullptr}, *dc2[2] = {nullptr, nullptr};
@@ -121,7 +125,7 @@ struct Butd {
     void clear_graphs();                 // captured kernel arguments hold parameter / buffer addresses: drop them when those change
     int greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
     int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
-    int greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
+    int greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st, bool scst = false);
     int sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
@@ -134,6 +138,8 @@ struct Butd {
     int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st,
                              int phases = 0xF, bool fire_cb = true);
     bool bptt_joined = false;            // the predict-gradient branch has been joined (bptt phases)
+    bool early_out = true;               // option "early_out": 0 = run the steps behind the reference's break as rounds 1 - 4 did (A/B)
+    bool bptt_early_out = false;         // backward of a sampled rollout: steps behind the reference's break return at entry (bptt)
 
     // beam search (butd_beam.hip)
     BeamBuf bm;
@@ -150,7 +156,7 @@ struct Butd {
     std::vector<int> rows_t;
     int ensure_train(int B, int T);
     int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false, int* pred_nsplit = nullptr,
-                   bool skip_predict = false);
+                   bool skip_predict = false, const int* live = nullptr);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_mask_sum(float* out, hipStream_t st);
     int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,
@@ -162,7 +168,7 @@ struct Butd {
     int upload_pack_index(hipStream_t st);
     int xe_backward(float smoothing, const icz_butd_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
     int gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_floats, int* ns_out, hipStream_t st);
-    int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st);
+    int wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st, const int* rows_live = nullptr);
     int bptt_prelude(hipStream_t st);
     int colsum(const float* X, int K, int N, int ldx, float* out, hipStream_t st);
     int bptt(const icz_butd_params& G, hipStream_t st, int phases = 0xF, bool fire_cb = true);
@@ -176,7 +182,7 @@ int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& f
     if (!use_graphs) return fn(st);
     ++tick;
     std::vector<uintptr_t> key = key_in;
-    key.push_back(concurrent ? 1 : 0);          // flags that change the captured launch sequence
+    key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0));          // flags that change the captured launch sequence
     key.push_back(gemm_prof_on() ? 1 : 0);
     for (auto& e : graphs)
         if (e.key == key) {

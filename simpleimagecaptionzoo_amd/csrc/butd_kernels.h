@@ -142,6 +142,7 @@ struct LstmPointArgs {
     float* gates_out;                              // [rows,4H] activated i,f,g,o or null
     float* hdrop_out;                              // [rows,H] or null
     int rows, H;
+    const int* live;                               // step_dead(live): return at entry (icz_common.h)
 };
 // sum of ns split-K slabs at one element, loads issued four at a time (independent), added in slab order
 __device__ __forceinline__ float sum_slabs1(const float* __restrict__ p, int ns, size_t stride, size_t off) {
@@ -159,6 +160,7 @@ __device__ __forceinline__ float sum_slabs1(const float* __restrict__ p, int ns,
 // grid (H/256, rows): one hidden unit per thread (4-byte accesses, 256 B per wave instruction, 4x the workgroups of
 // a float4 layout -- at 64 rows the kernel is latency-bound, not bandwidth-bound)
 __global__ __launch_bounds__(256) void lstm_point_kernel(LstmPointArgs a, DropCfg dc) {
+    if (step_dead(a.live)) return;
     const int row = blockIdx.y;
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.H) return;
@@ -204,6 +206,10 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
     const int H = a.H, G = 4 * H;
     const int j0 = blockIdx.x * 256, j4 = j0 + lane * 4;
     const size_t MN = (size_t)a.rows * G;
+    // early-out of a dead rollout step (live_flag / flag_dead, icz_common.h): tested once, behind the first batch of slab loads
+    const int lflag = live_flag(a.live);
+    bool tested = false;
+#define ICZ_LIVE_TEST() do { if (!tested) { if (flag_dead(lflag)) return; tested = true; } } while (0)
     if (j4 < H) {
         const size_t off = (size_t)row * G + (size_t)q * H + j4;
         const float* p = a.slab + off;
@@ -213,6 +219,7 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
             f32x4 v[8];
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + i) * MN);
+            ICZ_LIVE_TEST();
 #pragma unroll
             for (int i = 0; i < 8; ++i) s += v[i];
         }
@@ -220,10 +227,15 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
             f32x4 v[4];
 #pragma unroll
             for (int i = 0; i < 4; ++i) v[i] = *reinterpret_cast<const f32x4*>(p + (size_t)(z + i) * MN);
+            ICZ_LIVE_TEST();
 #pragma unroll
             for (int i = 0; i < 4; ++i) s += v[i];
         }
-        for (; z < a.nsplit; ++z) s += *reinterpret_cast<const f32x4*>(p + (size_t)z * MN);
+        for (; z < a.nsplit; ++z) {
+            const f32x4 v = *reinterpret_cast<const f32x4*>(p + (size_t)z * MN);
+            ICZ_LIVE_TEST();
+            s += v;
+        }
         if (a.pre) {
             const int pr = a.pre_row ? a.pre_row[row] : row;
             s += *reinterpret_cast<const f32x4*>(a.pre + (size_t)pr * G + (size_t)q * H + j4);
@@ -232,6 +244,8 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
         s += *reinterpret_cast<const f32x4*>(a.b_hh + (size_t)q * H + j4);
         *reinterpret_cast<f32x4*>(&sg[q][lane * 4]) = s;
     }
+    ICZ_LIVE_TEST();          // (lanes past H, no slabs)
+#undef ICZ_LIVE_TEST
     __syncthreads();
     const int j = j0 + tid;
     if (j >= H) return;
@@ -274,12 +288,14 @@ struct AttScoreArgs {
     float* dec_ctx_out;          // [rows, A] or null (kept for backward)
     float* scores;               // [rows, R]
     int rows, R, A;
+    const int* live;             // step_dead(live): return at entry
 };
 // Grid (rows, parts), 256 threads.  Part p owns regions p, p + parts, p + 2 parts, ...; a wave takes up to three of them
 // at a time and issues all their loads (3 regions x 4 float4 per lane) before the first use: the kernel moves
 // R*A*4 bytes per row once and is bound by how many bytes each CU keeps in flight, not by arithmetic.
 __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg dc) {
     extern __shared__ __attribute__((aligned(16))) float sdec[];   // A floats
+    const int lflag = live_flag(a.live);
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const size_t MN = (size_t)a.rows * a.A;
@@ -297,6 +313,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
             for (int u = 0; u < 4; ++u) xf[b][u] = *reinterpret_cast<const f32x4*>(e + min(lane * 4 + 256 * u, a.A - 4));
         }
     }
+    if (flag_dead(lflag)) return;                 // behind the first loads, in front of the first write (icz_common.h)
     for (int c = tid * 4; c < a.A; c += 1024) {
         const size_t off = (size_t)row * a.A + c;
         f32x4 s = *reinterpret_cast<const f32x4*>(a.dec_slab + off);
@@ -449,9 +466,10 @@ __global__ __launch_bounds__(256) void att_scores_group_kernel(AttScoreArgs a, i
 __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ feats, const int32_t* __restrict__ img_of_row,
                                                       const float* __restrict__ scores, float* __restrict__ alpha_out,
                                                       float* __restrict__ alpha_out2, int alpha2_stride,
-                                                      float* __restrict__ ctx, int R, int D) {
+                                                      float* __restrict__ ctx, int R, int D, const int* __restrict__ live) {
     __shared__ float sal[64];
     __shared__ __attribute__((aligned(16))) float spart[128 * 4];
+    const int lflag = live_flag(live);
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
     const int cg = tid & 127, half = tid >> 7;
     const int d = blockIdx.y * 512 + cg * 4;
@@ -468,6 +486,7 @@ __global__ __launch_bounds__(256) void att_ctx_kernel(const float* __restrict__ 
     for (int u = 0; u < RB; ++u) x0[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r_lo + u, r_hi - 1) * D);
 #pragma unroll
     for (int u = 0; u < RB; ++u) x1[u] = *reinterpret_cast<const f32x4*>(f + (size_t)min(r_lo + RB + u, r_hi - 1) * D);
+    if (flag_dead(lflag)) return;                 // behind the first loads, in front of the first write (icz_common.h)
     const float scv = lane < R ? scores[(size_t)row * R + lane] : -INFINITY;
     const float mx = wave_max(scv);
     const float ex = lane < R ? expf(scv - mx) : 0.f;
@@ -652,10 +671,17 @@ __global__ __launch_bounds__(256) void embed_argmax_kernel(const float* __restri
 __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __restrict__ logits, int V, int ldl, int ns, size_t slab_stride,
                                                             const float* __restrict__ bias, const float* __restrict__ table, int E,
                                                             float* __restrict__ emb, int64_t* __restrict__ it_next,
-                                                            int64_t* __restrict__ ids_out, int ids_stride, int t, int relu = 1) {
+                                                            int64_t* __restrict__ ids_out, int ids_stride, int t, int relu = 1,
+                                                            uint8_t* __restrict__ unfinished = nullptr, int* __restrict__ n_unfinished = nullptr) {
     __shared__ float sv[16];
     __shared__ int si[16];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // SCST baseline only (n_unfinished != null): once EVERY row has emitted <end> nothing downstream reads the greedy ids any more
+    // (get_self_critical_reward cuts each row at its <end>, Utils.py:354) -- the steps behind that point return at entry, ids = 0
+    if (n_unfinished && t > 0 && n_unfinished[t - 1] == 0) {
+        if (tid == 0 && ids_out) ids_out[(size_t)row * ids_stride + t] = 0;
+        return;
+    }
     const float* l = logits + (size_t)row * ldl;
     float best = -INFINITY;
     int bi = 0x7fffffff;
@@ -686,6 +712,11 @@ __global__ __launch_bounds__(1024) void greedy_select_kernel(const float* __rest
     if (tid == 0) {
         it_next[row] = bi;
         if (ids_out) ids_out[(size_t)row * ids_stride + t] = bi;
+        if (n_unfinished) {
+            const bool unf = (t == 0 || unfinished[row] != 0) && bi != 2;
+            unfinished[row] = unf ? 1 : 0;
+            if (unf) atomicAdd(&n_unfinished[t], 1);
+        }
     }
     for (int e = tid * 4; e < E; e += 4096) {
         f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)bi * E + e);
@@ -750,6 +781,12 @@ __global__ void saved_alphas_kernel(const float* __restrict__ src, int T, int B,
     out[i] = s / (float)NH;
 }
 
+// start of a greedy chain: first input token <sta>; the per-step counters of unfinished rows (SCST baseline, may be null) = 0
+__global__ void greedy_init_kernel(int64_t* it, int rows, int* n_unfinished, int T) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < rows) it[i] = 1;
+    if (n_unfinished && i < T) n_unfinished[i] = 0;
+}
 __global__ void fill_i64_kernel(int64_t* p, int64_t v, int n) {
     int i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) p[i] = v;
@@ -804,6 +841,8 @@ struct SampleSelArgs {
     // ns > 1: `logits` holds the ns split-K slabs of the predict GEMM (slab z at + z * slab_stride, no bias yet); the kernel
     // sums them in slab order, adds bias[v] and leaves the finished row in logits_store (the saved logits of backward)
     int ns; size_t slab_stride; const float* bias; float* logits_store;
+    int* live_rows;               // optional: (number of steps the reference ran so far) x rows -- the (t, b) rows the batched GEMMs of
+                                  // the backward pass need to read (GemmArgs::rows_live, embed_grad_kernel)
 };
 constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS
 __device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
@@ -941,23 +980,16 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
     if (a.t > 0 && a.n_unfinished[a.t - 1] == 0) {          // every row has finished: zeros, as the reference's early break leaves them (:233)
-        if (tid == 0) {
+        if (tid == 0) {                                     // (the kernels of the steps behind it return at entry: step_dead)
             a.seq_out[(size_t)row * a.T + a.t] = 0;
             a.logp_out[(size_t)row * a.T + a.t] = 0.f;
             a.it_next[row] = 0;
             a.draw_out[row] = -1;
             a.lse_out[row] = 0.f;
         }
-        if (a.emb_next)             // token 0 (<pad>), as embed_kernel would produce for it_next = 0
-            for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
-                f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + e);
-                const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
-                *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
-            }
         return;
     }
+    if (a.live_rows && row == 0 && tid == 0) *a.live_rows = (a.t + 1) * (int)gridDim.x;
     const float* l = a.logits + (size_t)row * a.ldl;
     const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
     const bool was_unf = a.unfinished[row] != 0;             // loaded early: the tail below is a chain of dependent accesses
@@ -1193,6 +1225,9 @@ struct LstmBwdArgs {
     int rows, H;
     int rows_a, rows_b, rows_c;       // row counts of the slab sets (slab stride = rows_x * lda_x)
     int dc_in_rows;                   // valid rows of dc_in
+    const int* live;                  // step_dead(live): this step never ran -> its dgates rows are ZERO (the weight-gradient GEMMs read
+                                      // every (t, b) row) and nothing else is touched
+    const int* carry_live;            // step_dead(carry_live): the step behind this one (t + 1) never ran -> no dh_a, no dc_in
 };
 // grid (H/256, rows): one hidden unit per thread (see lstm_point_kernel)
 __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, DropCfg dc) {
@@ -1200,21 +1235,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, Drop
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= a.H) return;
     const int H = a.H, G = 4 * H;
-    // a slab set only holds rows_x rows (XE: the batch shrinks with t); rows beyond contribute zero
-    float dh = 0.f;
-    if (a.dh_a && row < a.rows_a) dh += sum_slabs1(a.dh_a, a.ns_a, (size_t)a.rows_a * a.lda_a, (size_t)row * a.lda_a + j);
-    if (a.dh_b && row < a.rows_b) dh += sum_slabs1(a.dh_b, a.ns_b, (size_t)a.rows_b * a.lda_b, (size_t)row * a.lda_b + j);
-    if (a.dh_c && row < a.rows_c) dh += sum_slabs1(a.dh_c, a.ns_c, (size_t)a.rows_c * a.lda_c, (size_t)row * a.lda_c + j);
-    if (a.dhdrop) {
-        float d = a.dhdrop[(size_t)row * H + j];
-        if (dc.mode) d = dc.keep((uint64_t)row * H + j) ? d * 2.0f : 0.f;
-        dh += d;
-    }
+    // loads that do not depend on the step's liveness first: the two flags are tested behind them (live_flag / flag_dead, icz_common.h)
+    const int lflag = live_flag(a.live), cflag = live_flag(a.carry_live);
     const float* g = a.gates + (size_t)row * G + j;
     const float gi = g[0], gf = g[H], gg = g[2 * H], go = g[3 * H];
     const float cc = a.c_cur[(size_t)row * H + j];
     const float cp = a.c_prev ? a.c_prev[(size_t)row * H + j] : 0.f;
-    const float dcin = (a.dc_in && row < a.dc_in_rows) ? a.dc_in[(size_t)row * H + j] : 0.f;
+    float dhd = 0.f;
+    if (a.dhdrop) dhd = a.dhdrop[(size_t)row * H + j];
+    if (flag_dead(lflag)) {
+        float* o = a.dgates + (size_t)row * G + j;
+        o[0] = 0.f; o[H] = 0.f; o[2 * H] = 0.f; o[3 * H] = 0.f;
+        return;
+    }
+    const bool carry = cflag != 0;
+    // a slab set only holds rows_x rows (XE: the batch shrinks with t); rows beyond contribute zero
+    float dh = 0.f;
+    if (a.dh_a && carry && row < a.rows_a) dh += sum_slabs1(a.dh_a, a.ns_a, (size_t)a.rows_a * a.lda_a, (size_t)row * a.lda_a + j);
+    if (a.dh_b && row < a.rows_b) dh += sum_slabs1(a.dh_b, a.ns_b, (size_t)a.rows_b * a.lda_b, (size_t)row * a.lda_b + j);
+    if (a.dh_c && row < a.rows_c) dh += sum_slabs1(a.dh_c, a.ns_c, (size_t)a.rows_c * a.lda_c, (size_t)row * a.lda_c + j);
+    if (a.dhdrop) {
+        float d = dhd;
+        if (dc.mode) d = dc.keep((uint64_t)row * H + j) ? d * 2.0f : 0.f;
+        dh += d;
+    }
+    const float dcin = (a.dc_in && carry && row < a.dc_in_rows) ? a.dc_in[(size_t)row * H + j] : 0.f;
     const float tc = tanhf(cc);
     const float dcv = dcin + dh * go * (1.f - tc * tc);
     float* o = a.dgates + (size_t)row * G + j;
@@ -1242,18 +1287,13 @@ __global__ __launch_bounds__(256) void lstm_bwd_point_kernel(LstmBwdArgs a, Drop
 constexpr int DALPHA_COLS = 512;
 __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __restrict__ dctx, int ns, int ldc, int rows,
                                                              const float* __restrict__ feats, int R, int D,
-                                                             float* __restrict__ dalpha_part) {
+                                                             float* __restrict__ dalpha_part, const int* __restrict__ live) {
     __shared__ __attribute__((aligned(16))) float sd[DALPHA_COLS];
+    const int lflag = live_flag(live);
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int c0 = part * DALPHA_COLS;
     const size_t ss = (size_t)rows * ldc;
-    if (tid < DALPHA_COLS / 4) {
-        const int c = c0 + 4 * tid;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (c < D) v = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
-        *reinterpret_cast<f32x4*>(sd + 4 * tid) = v;
-    }
     constexpr int NR = 5;                         // regions per wave and pass (R <= 64: at most 16 per wave)
     const int ca = c0 + 4 * lane, cb = ca + 256;
     const bool va = ca < D, vb = cb < D;
@@ -1268,6 +1308,13 @@ __global__ __launch_bounds__(256) void att_bwd_dalpha_kernel(const float* __rest
         }
     };
     load_pass(wave);                              // in flight behind the slab sum
+    if (flag_dead(lflag)) return;                 // behind the first loads, in front of the first write (icz_common.h)
+    if (tid < DALPHA_COLS / 4) {
+        const int c = c0 + 4 * tid;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (c < D) v = sum_slabs4(dctx, ns, ss, (size_t)row * ldc + c);
+        *reinterpret_cast<f32x4*>(sd + 4 * tid) = v;
+    }
     __syncthreads();
     const f32x4 ga = *reinterpret_cast<const f32x4*>(sd + 4 * lane), gb = *reinterpret_cast<const f32x4*>(sd + 256 + 4 * lane);
     for (int r0 = wave; r0 < R; r0 += 4 * NR) {
@@ -1290,15 +1337,24 @@ struct AttBwdDdecArgs {
     const float* enc_ctx; const float* dec_ctx; const float* w_aff; const float* alpha; const float* dalpha;   // dalpha: [rows][nparts][R] partials
     float* ddec; float* ds_out;
     int R, A, nparts;
+    const int* live;              // step_dead(live): ddec and ds rows of this step are ZERO (read by the GEMMs / kernels over all steps)
 };
 __global__ __launch_bounds__(256) void att_bwd_ddec_kernel(AttBwdDdecArgs a, DropCfg dc) {
     __shared__ float sds[64];
     __shared__ __attribute__((aligned(16))) float spart[3 * 64 * 4];
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wq = tid >> 6;
+    const int lflag = live_flag(a.live);
     const float al = lane < a.R ? a.alpha[(size_t)row * a.R + lane] : 0.f;
-    float da = 0.f;
+    const float da0 = lane < a.R ? a.dalpha[(size_t)row * a.nparts * a.R + lane] : 0.f;
+    if (flag_dead(lflag)) {                       // behind the first loads (icz_common.h); a dead step's d dec / ds rows are zeros
+        if (blockIdx.y == 0 && tid < a.R) a.ds_out[(size_t)row * a.R + tid] = 0.f;
+        const int c = blockIdx.y * 256 + tid;
+        if (c < a.A) a.ddec[(size_t)row * a.A + c] = 0.f;
+        return;
+    }
+    float da = da0;
     if (lane < a.R)
-        for (int p = 0; p < a.nparts; ++p) da += a.dalpha[((size_t)row * a.nparts + p) * a.R + lane];
+        for (int p = 1; p < a.nparts; ++p) da += a.dalpha[((size_t)row * a.nparts + p) * a.R + lane];
     const float dot = wave_sum(al * da);
     const float ds_l = al * (da - dot);
     if (tid < 64) {
@@ -1540,11 +1596,12 @@ constexpr int EG_ROWS = 8;
 __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restrict__ tok, int n_tok,
                                                          const float* __restrict__ demb, int ns, size_t slab_stride,
                                                          const float* __restrict__ emb, float scale, int E,
-                                                         float* __restrict__ dE, int V, int relu) {
+                                                         float* __restrict__ dE, int V, int relu, const int* __restrict__ rows_live) {
     extern __shared__ int eg_sm[];     // tokens [n_tok], then the occurrence lists of the eight rows [8][n_tok]
     __shared__ int snh[EG_ROWS];
     int* stok = eg_sm;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    if (rows_live) n_tok = min(n_tok, *rows_live);       // the (t, b) prefix of the steps a sampled rollout really ran (d emb rows behind it are stale)
     for (int i = tid; i < n_tok; i += 256) stok[i] = (int)tok[i];
     __syncthreads();
     for (int rr = 0; rr < EG_ROWS / 4; ++rr) {
@@ -1589,7 +1646,7 @@ __global__ __launch_bounds__(256) void embed_grad_kernel(const int64_t* __restri
 }
 // host side: grid, LDS size (above the 64 KB default the kernel needs the explicit opt-in)
 inline hipError_t embed_grad_launch(hipStream_t st, const int64_t* tok, int n_tok, const float* demb, int ns, size_t slab_stride,
-                                    const float* emb, float scale, int E, float* dE, int V, int relu) {
+                                    const float* emb, float scale, int E, float* dE, int V, int relu, const int* rows_live = nullptr) {
     const size_t lds = sizeof(int) * (1 + EG_ROWS) * (size_t)n_tok;
     if (lds > 160 * 1024 - 1024) return hipErrorInvalidValue;
     if (lds > 48 * 1024) {
@@ -1597,7 +1654,7 @@ inline hipError_t embed_grad_launch(hipStream_t st, const int64_t* tok, int n_to
         if (e != hipSuccess) return e;
     }
     hipLaunchKernelGGL(embed_grad_kernel, dim3((V + EG_ROWS - 1) / EG_ROWS), dim3(256), lds, st, tok, n_tok, demb, ns, slab_stride, emb, scale, E, dE,
-                       V, relu);
+                       V, relu, rows_live);
     return hipSuccess;
 }
 

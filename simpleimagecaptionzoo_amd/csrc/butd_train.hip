@@ -68,6 +68,9 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.lse, sizeof(float) * TB));
     ICZ_TRY(zalloc((void**)&tb.unf, B));
     ICZ_TRY(zalloc((void**)&tb.nunf, sizeof(int) * T));
+    ICZ_TRY(zalloc((void**)&tb.gunf, B));
+    ICZ_TRY(zalloc((void**)&tb.gnunf, sizeof(int) * T));
+    ICZ_TRY(zalloc((void**)&tb.live_rows, 16));
     ICZ_TRY(zalloc((void**)&tb.coef, sizeof(float) * TB));
     ICZ_TRY(zalloc((void**)&tb.loss_rows, sizeof(float) * TB));
     ICZ_TRY(zalloc((void**)&tb.dGtd, sizeof(float) * TB * 4 * H));
@@ -114,7 +117,8 @@ static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base
 
 // ------------------------------------------------------------------------------------------------
 // forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
-int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit, bool skip_predict) {
+int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit, bool skip_predict,
+                     const int* live) {
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
     const size_t Vp = round4(dims.V);
     const size_t slot = (size_t)t * Bs;
@@ -136,6 +140,7 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
     s.pred_nsplit = pred_nsplit;
     s.skip_predict = skip_predict;
+    s.live = live;
     return step(s, st);
 }
 
@@ -189,7 +194,7 @@ int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* 
 int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
     ICZ_TRY(prologue(feats, B, st));
     if (!concurrent) {
-        ICZ_TRY(greedy_chain(feats, B, T, ids_out, nullptr, st));
+        ICZ_TRY(greedy_chain(feats, B, T, ids_out, nullptr, st, true));
         return sample_chain(feats, B, T, seq_out, logp_out, st);
     }
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
@@ -198,7 +203,7 @@ int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int6
     // ready the runtime then takes its first.  Measured round 4, three same-box rounds: rollouts 2.758 / 2.774 / 2.769 ms against
     // 2.783 / 2.785 / 2.806 ms with the greedy chain first (profiles/r04_chain_issue_order.log)
     const int ss = sample_chain(feats, B, T, seq_out, logp_out, st);
-    const int sg = greedy_chain(feats, B, T, ids_out, nullptr, side_st);
+    const int sg = greedy_chain(feats, B, T, ids_out, nullptr, side_st, true);
     ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));       // always join, also on error (a capture must be closed)
     ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     return sg != ICZ_OK ? sg : ss;
@@ -216,7 +221,9 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
     hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok, B, T);
     for (int t = 0; t < T; ++t) {
         int pns = 1;
-        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0, &pns));
+        // step t > 0 is dead when no row was left unfinished by step t - 1 (the reference breaks out of its loop there, :233): every
+        // kernel of it returns at entry, sample_select_kernel writes the zeros the reference's pre-allocated outputs keep
+        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0, &pns, false, (t > 0 && early_out) ? tb.nunf + (t - 1) : nullptr));
         SampleSelArgs a = {};
         a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
         if (pns > 1) {          // the predict GEMM left split-K slabs in the chain's workspace (train_step: tb.X[0])
@@ -226,6 +233,7 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
         a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = tb.unf; a.n_unfinished = tb.nunf;
+        a.live_rows = tb.live_rows;
         a.seq_out = seq_out; a.logp_out = logp_out;
         a.it_next = tb.tok + (size_t)(t + 1) * B;
         a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
@@ -257,6 +265,7 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     if (mask_sum_global >= 0.f)      // < 0: keep the device value set by icz_butd_set_mask_sum_global
         hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum_global, mask_sum_global);
     mode = 0;   // the saved logits are consumed
+    bptt_early_out = true;
     ICZ_TRY(bptt_prelude(st));      // outside the captured graph
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
     if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
@@ -409,6 +418,7 @@ int Butd::xe_backward_dlogits(const float* dpacked, const icz_butd_params* G, hi
                        tb.scalars_i + T, T, tb.logit);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    bptt_early_out = false;
     ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
@@ -428,6 +438,7 @@ int Butd::sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hi
                        tb.draw, tb.lse, tb.coef, B, T);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    bptt_early_out = true;
     ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
@@ -450,6 +461,7 @@ int Butd::xe_backward(float smoothing, const icz_butd_params* G, float* loss_out
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, tb.loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
+    bptt_early_out = false;
     ICZ_TRY(bptt_prelude(st));
     return bptt(*G, st);
 }
@@ -468,9 +480,10 @@ int Butd::gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_flo
 }
 
 // C (ldc) = A^T B over K rows, written directly (no split): weight gradients
-int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st) {
+int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st, const int* rows_live) {
     GemmArgs g = {};
     g.nseg = 1;
+    g.rows_live = rows_live;
     g.seg[0] = {dY, X, ldy, ldx, K, nullptr};
     g.M = M; g.N = N; g.out = out; g.ldo = ldo; g.nsplit = 1;
     return gemm_f32(GEMM_TN, g, st);
@@ -502,6 +515,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     const int TB = T * B;
     const float* feats = cur_feats;
     const size_t sH = (size_t)B * H;
+    // backward of a sampled rollout: the GEMMs over all (t, b) rows stop behind the last step the rollout ran (GemmArgs::rows_live)
+    const int* const rl = (bptt_early_out && early_out) ? tb.live_rows : nullptr;
 
     // ---- predict layer, all time steps at once.  d h2drop feeds the BPTT chain; the weight / bias gradients of
     //      `predict` depend only on dlogits, so they run on the side stream concurrently with the (skinny,
@@ -525,7 +540,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     auto side_branch = [&]() -> int {
         ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork, 0));
         hipStream_t sb = concurrent ? low_st : st;   // low priority: the big GEMM only fills CUs the BPTT chain leaves idle
-        int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb);
+        int s1 = wgrad(tb.logit, Vp, Vp, tb.h2d, H, H, TB, tb.dWp, H, sb, rl);
         hipLaunchKernelGGL(colsum_kernel, dim3(cdiv(V, 32)), dim3(256), 0, sb, tb.logit, TB, V, (int)Vp, G.predict_b);
         hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, sb, tb.dWp, H, P.predict_v, P.predict_g, n_pred,
                            G.predict_v, G.predict_g, V, H);
@@ -538,7 +553,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {tb.logit, w_pred, Vp, H, Vp, nullptr};
-        g.M = TB; g.N = H; g.out = tb.dH2d; g.ldo = H;
+        g.M = TB; g.N = H; g.out = tb.dH2d; g.ldo = H; g.rows_live = rl;
         int ns;
         const int sg = gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st);
         if (sg != ICZ_OK) return sg;          // nothing is forked yet: the side branch is issued behind this product
@@ -566,6 +581,11 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     for (int t = T - 1; t >= 0; --t) {
         const int bt = rows_t[t];
         const size_t slot = (size_t)t * B;
+        // REINFORCE backward of a sampled rollout: the steps behind the reference's break never ran (sample_chain) -- their kernels
+        // return at entry, the producers of d gates / d dec / ds rows write zeros (the GEMMs over all steps read them), and the
+        // first live step takes no carry from the dead one behind it
+        const int* const live = (bptt_early_out && early_out && t > 0) ? tb.nunf + (t - 1) : nullptr;
+        const int* const carry_live = (bptt_early_out && early_out && t + 1 < T) ? tb.nunf + t : nullptr;
         DropCfg d_out = make_drop(d_seed, cur_train, rng.out_mask, (size_t)B * H, RNG_OUT, t);
         DropCfg d_att = make_drop(d_seed, cur_train, rng.att_mask, (size_t)B * R * A, RNG_ATT, t);
         DropCfg d_off = {0, nullptr, nullptr, 0, 0};
@@ -577,7 +597,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             a.gates = tb.glm + slot * 4 * H;
             a.c_prev = tb.c2 + slot * H; a.c_cur = tb.c2 + slot * H + sH;
             a.dgates = tb.dGlm + slot * 4 * H; a.dc_prev = tb.dc2[cur ^ 1];
-            a.rows = bt; a.H = H;
+            a.rows = bt; a.H = H; a.live = live; a.carry_live = carry_live;
             hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_out);
         }
         // 33 .. 64 rows: the per-step dgrad products as NT products on the transposed weight copies (resident-activation kernel)
@@ -589,7 +609,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             GemmArgs g = {};
             g.nseg = 1;
             g.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_ih, 4 * H, 4 * H, 4 * H, nullptr};
-            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H;
+            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H; g.live = live;
             g.nsplit = ns1 = gemm_resident_x3_nsplit(g);
             ICZ_REQUIRE(gemm_slab_floats(bt, D + H, ns1) <= tb.xfloats, "butd: slab buffer too small for the dgrad slabs");
             ICZ_TRY(gemm_f32(GEMM_NT, g, st));
@@ -597,19 +617,19 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             GemmArgs g = {};
             g.nseg = 1;
             g.seg[0] = {tb.dGlm + slot * 4 * H, P.lm_w_ih, 4 * H, D + H, 4 * H, nullptr};
-            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H;
+            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H; g.live = live;
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[0], tb.xfloats, &ns1, st));
         }
         {   // attention backward
             const int dparts = cdiv(D, DALPHA_COLS);
-            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, dparts), dim3(256), 0, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha);
-            AttBwdDdecArgs da = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dDec + slot * A, tb.dS + slot * R, R, A, dparts};
+            hipLaunchKernelGGL(att_bwd_dalpha_kernel, dim3(bt, dparts), dim3(256), 0, st, tb.X[0], ns1, D + H, bt, feats, R, D, tb.dalpha, live);
+            AttBwdDdecArgs da = {enc_ctx, tb.dec + slot * A, w_aff, tb.alpha + slot * R, tb.dalpha, tb.dDec + slot * A, tb.dS + slot * R, R, A, dparts, live};
             hipLaunchKernelGGL(att_bwd_ddec_kernel, dim3(bt, cdiv(A, 256)), dim3(256), 0, st, da, d_att);
             // X2 = dDec . w_dec   [bt, H]
             GemmArgs g = {};
             g.nseg = 1;
             g.seg[0] = {tb.dDec + slot * A, w_dec, A, H, A, nullptr};
-            g.M = bt; g.N = H; g.out = tb.X[1]; g.ldo = H;
+            g.M = bt; g.N = H; g.out = tb.X[1]; g.ldo = H; g.live = live;
             ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[1], tb.xfloats, &ns2, st));
         }
         {   // TD LSTM backward (pointwise): dh1 = carry + X1[:, D:] + X2
@@ -621,7 +641,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             a.gates = tb.gtd + slot * 4 * H;
             a.c_prev = tb.c1 + slot * H; a.c_cur = tb.c1 + slot * H + sH;
             a.dgates = tb.dGtd + slot * 4 * H; a.dc_prev = tb.dc1[cur ^ 1];
-            a.rows = bt; a.H = H;
+            a.rows = bt; a.H = H; a.live = live; a.carry_live = carry_live;
             hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d_off);
         }
         if (t > 0 && rdg) {   // d h2_{t-1} (X3) and d h1_{t-1} (X4) in one launch
@@ -629,8 +649,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             g3.nseg = 2;
             g3.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_hh, 4 * H, 4 * H, 4 * H, nullptr};
             g3.seg[1] = {tb.dGtd + slot * 4 * H, wt_td_ih_h2, 4 * H, 4 * H, 4 * H, nullptr};
-            g3.M = bt; g3.N = H; g3.out = tb.X[2]; g3.ldo = H;
-            g4.nseg = 1;
+            g3.M = bt; g3.N = H; g3.out = tb.X[2]; g3.ldo = H; g3.live = live;
+            g4.nseg = 1; g4.live = live;
             g4.seg[0] = {tb.dGtd + slot * 4 * H, wt_td_hh, 4 * H, 4 * H, 4 * H, nullptr};
             g4.M = bt; g4.N = H; g4.out = tb.X[3]; g4.ldo = H;
             ns3 = gemm_resident_x3_nsplit(g3); ns4 = gemm_resident_x3_nsplit(g4);
@@ -642,14 +662,14 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
                 g.nseg = 2;
                 g.seg[0] = {tb.dGlm + slot * 4 * H, P.lm_w_hh, 4 * H, H, 4 * H, nullptr};
                 g.seg[1] = {tb.dGtd + slot * 4 * H, P.td_w_ih, 4 * H, H + D + E, 4 * H, nullptr};
-                g.M = bt; g.N = H; g.out = tb.X[2]; g.ldo = H;
+                g.M = bt; g.N = H; g.out = tb.X[2]; g.ldo = H; g.live = live;
                 ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[2], tb.xfloats, &ns3, st));
             }
             {   // X4 = dG_td . W_hh_td   -> d h1_{t-1}
                 GemmArgs g = {};
                 g.nseg = 1;
                 g.seg[0] = {tb.dGtd + slot * 4 * H, P.td_w_hh, 4 * H, H, 4 * H, nullptr};
-                g.M = bt; g.N = H; g.out = tb.X[3]; g.ldo = H;
+                g.M = bt; g.N = H; g.out = tb.X[3]; g.ldo = H; g.live = live;
                 ICZ_TRY(gemm_auto(GEMM_NN, g, tb.X[3], tb.xfloats, &ns4, st));
             }
         }
@@ -684,7 +704,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {tb.dGtd, P.td_w_ih + H + D, 4 * H, H + D + E, 4 * H, nullptr};
-        g.M = TB; g.N = E; g.out = tb.dEmb; g.ldo = E;
+        g.M = TB; g.N = E; g.out = tb.dEmb; g.ldo = E; g.rows_live = rl;
         int ns;
         ICZ_TRY(gemm_auto(GEMM_NN, g, ws, ws_floats, &ns, st));
         if (ns > 1) {
@@ -692,20 +712,20 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, E, (const float*)nullptr, tb.dEmb);
         }
         // inactive (t,b) rows have dG = 0 -> dEmb = 0; their token ids are whatever the buffer held (valid ids)
-        ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1));
+        ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st));                 // h2_{t-1}
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st, rl));             // h2_{t-1}
     hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)B * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)B * 4 * H, tb.dGsum);
     ICZ_TRY(wgrad(tb.dGsum, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));               // mean features
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st));         // embedding
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st));                     // h1_{t-1}
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st, rl));     // embedding
+    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st, rl));                 // h1_{t-1}
     }   // phase 1
     if ((phases & 2) && grad_cb && fire_cb) grad_cb(grad_cb_user, 1);
     if (phases & 4) {
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st));                 // ctx_t
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st));         // h1_t
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st));                     // h2_{t-1}
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st, rl));             // ctx_t
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st, rl));     // h1_t
+    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st, rl));                 // h2_{t-1}
     }   // phase 2
     if ((phases & 4) && grad_cb && fire_cb) grad_cb(grad_cb_user, 2);
     if (phases & 8) {

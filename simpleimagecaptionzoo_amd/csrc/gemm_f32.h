@@ -55,6 +55,10 @@ struct GemmArgs {
     int chunks_per_split;
     int accumulate;      // nsplit == 1 only: C += result (used by wgrad accumulation)
     int spread;          // set by gemm_f32 (NN, skinny shapes): spread the next stage's loads over the stage
+    const int* live;     // step_dead(live): the kernel returns at entry without writing anything (icz_common.h); null = always run
+    const int* rows_live; // 128 x 128 split-precision kernel only, optional: a device count of the leading (t, b) rows that matter (the steps a
+                         // sampled rollout really ran) -- TN: K is cut there (rounded up to 32), NN: row tiles behind it return at entry.
+                         // Rows behind the count must hold finite values whose products are zero or never read (BPTT: d gates = 0)
 };
 
 int gemm_f32(GemmLayout layout, const GemmArgs& a, hipStream_t stream);
@@ -86,7 +90,7 @@ int gemm_resident_x3_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stre
 // needs finished logits -> always the un-split GEMM into `logits` (row stride ldl).  Otherwise *pred_nsplit reports what was
 // done: 1 = finished logits in `logits`, > 1 = that many slabs in `ws` (no bias yet).  ICZ_PREDICT_SLABS=0 keeps the un-split GEMM.
 int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
-                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st);
+                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st, const int* live = nullptr);
 
 // Library switches, read from the environment once at first use (defaults = the product configuration): ICZ_GEMM_TN_X3,
 // ICZ_GEMM_NN_X3, ICZ_GEMM_NT_X3BIG, ICZ_GEMM_RESIDENT_X3 (0: the fp32-input MFMA kernels -- bench.py's fp32_mfma_gemms leg),

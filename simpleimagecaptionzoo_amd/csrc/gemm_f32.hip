@@ -84,6 +84,7 @@ __device__ __forceinline__ f32x4 ld4z(const float* p, bool ok) {
 // columns that are never stored, so no zero-fill is needed; only the K tail must be zero (TAIL variant).
 template <int MT, int NTW, bool TAIL, int BKC, int NW = 4, bool SPREAD = false>
 __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
+    const int lflag = live_flag(a.live);
     constexpr int BN = 16 * NW * NTW;
     constexpr int NTHR = 64 * NW;
     constexpr int LDSS = BKC + 8;                 // dwords per staged A row; (LDSS/4) mod 16 == 2 -> conflict-free b128 reads
@@ -227,9 +228,11 @@ __global__ __launch_bounds__(64 * NW) void gemm_nt_kernel(GemmArgs a) {
     // stage i+1 are in flight; they are stored to the other LDS buffer after the MFMAs.  One barrier per stage.
     const int n = c_end - c_begin;
     f32x4 wa[NTW][NS], wb[NTW][NS];
+    if (n <= 0 && lflag == 0) return;
     if (n > 0) {
         seek(c_begin);
         load_stage(wa);
+        if (flag_dead(lflag)) return;           // behind the first stage's loads, in front of the first write (icz_common.h)
         store_stage(0);
         __syncthreads();
         auto body = [&](int buf, const f32x4 (&wuse)[NTW][NS], f32x4 (&wload)[NTW][NS]) {
@@ -354,6 +357,7 @@ __device__ __forceinline__ void split3(float a, float b, uint32_t& p0, uint32_t&
 // float4 along n at [k][4i..4i+3] supplies column 4i+j to column tile j, so one ds_read_b128 feeds 4 MFMAs.
 template <bool TAIL, int BKC = GEMM_BK>
 __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
+    const int lflag = live_flag(a.live);
     constexpr int NS = BKC / 16;                 // k-groups of 16 per stage = A float4 per lane = B staging loads per thread
     __shared__ __attribute__((aligned(16))) float lds[2][BKC * GEMM_BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -394,9 +398,11 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
             *reinterpret_cast<f32x4*>(&lds[buf][((tid >> 4) + 16 * j) * GEMM_BN + 4 * (tid & 15)]) = br[j];
     };
 
+    if (c_begin >= c_end && lflag == 0) return;
     if (c_begin < c_end) {
         cc.seek(a, c_begin);
         load_chunk(acur);
+        if (flag_dead(lflag)) return;           // behind the first stage's loads, in front of the first write (icz_common.h)
         store_stage(0);
         __syncthreads();
         for (int c = c_begin; c < c_end; ++c) {
@@ -479,6 +485,7 @@ __global__ __launch_bounds__(256) void gemm_nn_kernel(GemmArgs a) {
 // 16 MFMAs.  The four waves' partial tiles are summed through LDS at the end.
 template <bool TAIL>
 __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
+    if (step_dead(a.live)) return;
     __shared__ __attribute__((aligned(16))) float red[3][64 * 64];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int li = lane & 15, lq = lane >> 4;
@@ -565,6 +572,7 @@ __global__ __launch_bounds__(256) void gemm_tn_kernel(GemmArgs a) {
 // above: the lane's float4 along m (n) at row k supplies row 4i+j (column 4i+j) of quadrant tile j, so one ds_read_b128
 // per operand and k-step feeds 16 MFMAs.  Loads of the next stage are spread over the stage (one per k-step).
 __global__ __launch_bounds__(256) void gemm_tn128_kernel(GemmArgs a) {
+    if (step_dead(a.live)) return;
     constexpr int KC = 32, LD = 128 + 4;                       // row stride 132 dwords: the four k rows of a read hit disjoint banks
     __shared__ __attribute__((aligned(16))) float sA[2][KC * LD];
     __shared__ __attribute__((aligned(16))) float sB[2][KC * LD];
@@ -679,11 +687,14 @@ constexpr size_t t3_lds(int nbuf) { return (size_t)nbuf * 2 * 3 * T3_PLANE * 2; 
 // blockIdx.z = split-K part (slabs [z][M][N] in a.out).
 template <int NBUF, int NW, bool AROW = false, bool BROW = false>
 __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
+    if (step_dead(a.live)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char t3_smem[];
     unsigned short* const lds = reinterpret_cast<unsigned short*>(t3_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int n0 = blockIdx.x * 128, m0 = blockIdx.y * 128;
+    const int rows_live = a.rows_live ? ((*a.rows_live + 31) & ~31) : 0x7fffffff;
+    if (AROW && !BROW && m0 >= rows_live) return;            // NN: a row tile of steps the rollout never ran
     constexpr int NT = 64 * NW, NU = NW == 4 ? 2 : 1, IPT = 512 / NT;       // column tiles per wave; staging items per thread and operand
     const int mbase = NW == 4 ? 64 * (wave >> 1) : 64 * (wave >> 2), nbase = NW == 4 ? 64 * (wave & 1) : 32 * (wave & 3);
     f32x16 acc[2][NU];
@@ -822,7 +833,8 @@ __global__ __launch_bounds__(64 * NW) void gemm_tn128_x3_kernel(GemmArgs a) {
     if (a.nseg == 1) {
         // K range of this split: a.chunks_per_split counts 128-deep chunks (gemm_f32), a stage here is 32 deep
         const int kbeg = a.nsplit > 1 ? (int)blockIdx.z * a.chunks_per_split * 128 : 0;
-        const int kend = a.nsplit > 1 ? min(a.seg[0].K, kbeg + a.chunks_per_split * 128) : a.seg[0].K;
+        int kend = a.nsplit > 1 ? min(a.seg[0].K, kbeg + a.chunks_per_split * 128) : a.seg[0].K;
+        if (!AROW && !BROW) kend = min(kend, rows_live);     // TN: the sum over (t, b) stops behind the last step that ran
         run_segment(a.seg[0], kbeg, kend);
     } else {
         // several K segments: the split's range [gbeg, gend) of the concatenated K is cut at the segment borders

@@ -97,6 +97,7 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
         }
     };
     stamp(0);
+    const int lflag = live_flag(a.live);
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
     unsigned short* const planes = reinterpret_cast<unsigned short*>(sk_smem);
     constexpr int ROWS = 16 * MT, NCT = 2, NT = TPW * NSR;
@@ -176,6 +177,9 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
         point_w(std::integral_constant<int, 0>{});
         sk_static_for<0, LW>([&](auto lc) { load_w1(std::integral_constant<int, 0>{}, lc); });
         __builtin_amdgcn_sched_barrier(0);
+        // early-out of a rollout / BPTT step behind the reference's break, behind the issue of the activation and first weight loads
+        // (live_flag / flag_dead, icz_common.h): nothing has been written yet
+        if (flag_dead(lflag)) return;
         if constexpr (STAMPS) {
             stamp(21);
             asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
@@ -340,6 +344,7 @@ __device__ __forceinline__ void resident_x3_m128_body(const GemmArgs& a, const i
         }
     };
     stamp(0);
+    if (step_dead(a.live)) return;
     extern __shared__ __attribute__((aligned(16))) unsigned char sk_smem[];
     unsigned short* const planes = reinterpret_cast<unsigned short*>(sk_smem);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -661,9 +666,10 @@ int gemm_resident_x3_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_
 }
 
 int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
-                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st) {
+                 float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st, const int* live) {
     GemmArgs g = {};
     g.nseg = 1;
+    g.live = live;
     g.seg[0] = {x, w_pred, H, H, H, nullptr};
     g.M = rows; g.N = Vp; g.out = ws; g.ldo = Vp;
     if (gemm_switches().predict_slabs && pred_nsplit && ws && gemm_resident_x3_fits(g) &&

@@ -1,0 +1,119 @@
+"""Round 5: device-side early-out of the rollout / BPTT steps behind the reference's break (`if unfinished.sum() == 0: break`,
+BUTD_Model.py:233, AoA_Model.py:400, NIC_Model.py:150): every kernel of such a step returns at entry."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+R, D, H, E, A, V = 36, 2048, 1024, 1024, 1024, 10102
+
+
+def _end_biased_params(seed, p_end, B=64):
+    """full-width parameters whose <end> logit is raised until a sampled step draws <end> with probability ~ p_end"""
+    from simpleimagecaptionzoo_amd.butd import ButdHandle, make_rng
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    params = random_butd_params(R, D, H, E, A, V, "cuda", seed=seed)
+    h = ButdHandle(R, D, H, E, A, V, B, 20)
+    h.bind(params)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(seed)
+    feats = torch.relu(torch.randn(B, R, D, generator=g)).cuda()
+    params["predict.bias"][2] += float(np.log(p_end * V / (1.0 - p_end)))
+    for _ in range(3):
+        h.refresh()
+        seq, _ = h.sample(feats, 20, make_rng(123))
+        p = float((seq[:, 0] == 0).float().mean().clamp(1.0 / (4 * B), 1 - 1.0 / (4 * B)))
+        params["predict.bias"][2] += float(np.log(p_end / (1 - p_end)) - np.log(p / (1 - p)))
+    h.close()
+    return params, feats
+
+
+def test_fullsize_rollout_with_early_break_matches_oracle_and_autograd():
+    """64 rows x 20 steps at full width, <end> likely enough that every row has finished around step 10: ids, log-probs and the
+    REINFORCE gradients against the oracle WITH the reference's break (oracle/butd.py: early_exit=True) -- the steps behind the
+    break are zeros in the outputs and contribute nothing to any gradient.  The handle's step slots are first filled by a
+    rollout that never ends (stale activations in every slot the short rollout leaves untouched)."""
+    from oracle import butd as ob
+    from simpleimagecaptionzoo_amd.butd import ButdHandle, make_rng
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    B, T = 64, 20
+    params, feats = _end_biased_params(91, 0.35)
+    h = ButdHandle(R, D, H, E, A, V, B, T)
+    long_params = random_butd_params(R, D, H, E, A, V, "cuda", seed=92)
+    h.bind(long_params)
+    seq0, _ = h.sample(feats * 3.0, T, make_rng(5))          # fills all 20 slots; random weights never emit <end>
+    assert int((seq0[:, -1] != 0).sum()) > B // 2
+    g0 = h.new_grads()
+    h.sample_backward(torch.ones(B, T, device="cuda"), g0)
+    h.bind(params)
+    rs = np.random.RandomState(7)
+    em, am, om = rs.rand(T, B, E) < 0.5, rs.rand(T, B, R, A) < 0.5, rs.rand(T, B, H) < 0.5
+    u = rs.rand(T, B).astype(np.float32)
+    dev = "cuda"
+    rng = make_rng(0, torch.tensor(u, device=dev), torch.tensor(em.astype(np.uint8), device=dev),
+                   torch.tensor(am.astype(np.uint8), device=dev), torch.tensor(om.astype(np.uint8), device=dev))
+    greedy, seq, lp = h.rollouts(feats, T, rng)
+    seq_h, lp_h = seq.cpu().numpy(), lp.cpu().numpy()
+    # the SCST baseline: the reference's greedy ids (icz_butd_greedy: no break, BUTD_Model.py:171-186) up to and including every row's
+    # first <end> -- all the reward reads (Utils.py:354) -- and zeros behind the step at which the last row emitted it
+    g_roll, g_full = greedy.cpu().numpy(), h.greedy(feats, T).cpu().numpy()
+    ends = [(np.nonzero(r == 2)[0][0] if (r == 2).any() else T - 1) for r in g_full]
+    for b in range(B):
+        assert np.array_equal(g_roll[b, :ends[b] + 1], g_full[b, :ends[b] + 1]), b
+    if all((r == 2).any() for r in g_full):
+        assert max(ends) < T - 1 and (g_roll[:, max(ends) + 1:] == 0).all()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in params.items()}
+    w_seq, w_lp, w_logits = ob.sample_rl(feats.cpu(), p, u.astype(np.float64), em, am, om, T, early_exit=True)
+    steps_run = w_logits.shape[1]
+    assert 4 <= steps_run <= 16, steps_run                    # the regime does what it is for: the reference broke out early
+    same = (w_seq.numpy() == seq_h).all(1)
+    assert same.sum() >= B - 2, (int(same.sum()), steps_run)  # a draw within fp32 rounding of a CDF edge may differ (test_gpu_round2)
+    assert (seq_h[:, steps_run:] == 0).all() and (lp_h[:, steps_run:] == 0).all()
+    np.testing.assert_allclose(lp_h[same], w_lp.detach().numpy()[same], atol=1e-4)
+    rw = (rs.randn(B, 1).astype(np.float32) * same[:, None]).repeat(T, 1)
+    grads = h.new_grads()
+    for v in grads.values():
+        v.fill_(float("nan"))
+    loss, _ = h.sample_backward(torch.tensor(rw, device=dev), grads)
+    w_seq_m = torch.from_numpy(np.where(same[:, None], w_seq.numpy(), seq_h))
+    w_loss = ob.reward_criterion(w_lp, w_seq_m, torch.from_numpy(rw))
+    w_loss.backward()
+    assert abs(loss.item() - w_loss.item()) < 1e-4
+    for k, gt in grads.items():
+        want = p[k].grad.numpy()
+        got = gt.cpu().numpy()
+        assert np.isfinite(got).all(), k
+        scale = max(1e-6, float(np.abs(want).max()))
+        assert np.abs(got - want).max() <= 5e-4 * scale + 1e-7, (k, float(np.abs(got - want).max()), scale)
+    h.close()
+
+
+def test_early_break_under_graph_replay_equals_eager_launches():
+    """The Engine's form: Philox randomness, whole rollouts and the backward pass replayed as hipGraphs.  Same seed, same
+    inputs: replayed and eager launches give the same tokens, log-probs and gradients bit for bit, break or no break."""
+    from simpleimagecaptionzoo_amd.butd import ButdHandle, make_rng
+    B, T = 64, 20
+    params, feats = _end_biased_params(93, 0.4)
+    out = {}
+    for graphs in (False, True):
+        h = ButdHandle(R, D, H, E, A, V, B, T)
+        h.bind(params)
+        h.enable_graphs(graphs)
+        res = []
+        for rep in range(3):                                   # the first call captures, the others replay
+            greedy, seq, lp = h.rollouts(feats, T, make_rng(1000 + rep))
+            grads = getattr(h, "_test_grads", None) or h.new_grads()
+            h._test_grads = grads
+            rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous() if rep == 0 else res[0][3]
+            loss, _ = h.sample_backward(rew, grads)
+            res.append((seq.clone(), lp.clone(), {k: v.clone() for k, v in grads.items()}, rew, loss.clone()))
+        out[graphs] = res
+        h.close()
+    broke = 0
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[4], b[4])
+        for k in a[2]:
+            assert torch.equal(a[2][k], b[2][k]), k
+        broke += int((a[0][:, -1] == 0).all())
+    assert broke == 3                                          # every rollout ended before the last step

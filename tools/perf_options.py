@@ -1,18 +1,23 @@
-"""dev tool (round 5): one BUTD SCST step by phase with the LSTM weight gradients in 1 (= behind the loop, rounds 1-4) .. n time chunks
-beside the reverse-time loop (option "wgrad_chunks"), alternating legs in ONE process.  usage: perf_bwd_chunks.py [chunk counts ...]"""
+"""dev tool (round 5): one BUTD SCST step by phase under different handle options (icz_butd_set_option), alternating legs in ONE
+process (same box, same clocks: differences of 0.01 ms are visible).  usage: perf_options.py name=value[,name=value] ...
+e.g. `perf_options.py early_out=0 early_out=1`; ICZ_PERF_BREAK=11 raises the <end> logit until the reference's break
+(BUTD_Model.py:233) triggers after ~11 of the 20 steps (bench.end_bias)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 
 B = int(os.environ.get("ICZ_PERF_B", "64"))
-counts = sys.argv[1:] or ["1", "2", "4"]       # "3" = three chunks, pieces on the 48 KB kernel; "3x" = on the regular kernels
+legs = sys.argv[1:] or ["early_out=1"]
 eng, opt, vocab, words = bench.build_engine("cuda:0", B)
 if os.environ.get("ICZ_NO_GRAPHS"):
     eng.use_graphs = False
 batches = bench.make_batches(4, B, words, "cuda:0", 0)
 eng.SCST_training_epoch(batches, opt, None, tqdm_visible=False)
 torch.cuda.synchronize()
+brk = float(os.environ.get("ICZ_PERF_BREAK", "0"))
+if brk > 0:
+    print("<end> bias: break steps", bench.end_bias(eng, batches, brk))
 scorer = eng.scorer()
 N = int(os.environ.get("ICZ_PERF_STEPS", "14"))
 ROUNDS = int(os.environ.get("ICZ_PERF_ROUNDS", "3"))
@@ -20,8 +25,9 @@ ROUNDS = int(os.environ.get("ICZ_PERF_ROUNDS", "3"))
 
 def leg(n):
     h = eng._hot_handle()
-    h.set_option("wgrad_chunks", int(n.rstrip("x")))
-    h.set_option("wgrad_polite", 0 if n.endswith("x") else 1)
+    for kv in n.split(","):
+        k, v = kv.split("=")
+        h.set_option(k, int(v))
     ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(N)]
     with torch.cuda.stream(eng.stream):
         eng.model.train()
@@ -44,7 +50,9 @@ def leg(n):
     return ph, span
 
 
+h0 = eng._hot_handle()
 for r in range(ROUNDS):
-    for n in counts:
+    for n in legs:
         ph, span = leg(n)
-        print("chunks=%-3s rollouts %.3f  reward %.3f  backward %.3f  adam %.3f  span %.3f ms" % (n, ph[0], ph[1], ph[2], ph[3], span), flush=True)
+        brk_now = bench.break_step(h0._bufs[("sample_seq", B, 20)])
+        print("%-24s break %2d  rollouts %.3f  reward %.3f  backward %.3f  adam %.3f  span %.3f ms" % (n, brk_now, ph[0], ph[1], ph[2], ph[3], span), flush=True)

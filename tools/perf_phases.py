@@ -22,6 +22,8 @@ eng.SCST_training_epoch(batches, opt, None, tqdm_visible=False)
 torch.cuda.synchronize()
 scorer = eng.scorer()
 N = 12
+if os.environ.get("ICZ_EARLY_OUT") == "0":
+    eng._hot_handle().set_option("early_out", 0)
 ev = [[torch.cuda.Event(enable_timing=True) for _ in range(5)] for _ in range(N)]
 with torch.cuda.stream(eng.stream):
     eng.model.train()
