@@ -72,19 +72,26 @@ class ReferenceCooker:
         self._log_cache = {}
         # ---- df table over id n-grams.  Words outside the caption vocabulary get private ids >= V right here, so that the
         #      n-grams containing them keep their document frequency for the reference weights (hypotheses never look them up)
-        keys, vals = [], []
-        for gram, cnt in document_frequency.items():
-            keys.append([self._word_id(w) for w in gram] + [-1] * (4 - len(gram)))
-            vals.append(self._idf(cnt))
-        n = len(keys)
+        # (one pass of plain dict look-ups: ~4 s per million n-grams, once per run -- COCO14's table has ~3 M; the reference pays an
+        # unpickle of the same table for every batch, Utils.py:359)
+        n = len(document_frequency)
+        keys = np.full((n, 4), -1, dtype=np.int32)
+        cnts = np.empty(n, dtype=np.float64)
+        get, oov = self.word2ix.get, self._word_id
+        for i, (gram, cnt) in enumerate(document_frequency.items()):
+            row = [get(w, -2) for w in gram]
+            if -2 in row:
+                row = [oov(w) for w in gram]
+            keys[i, :len(row)] = row
+            cnts[i] = cnt
+        uniq, inv = np.unique(cnts, return_inverse=True)                  # the scalar formula per distinct count: the same bits as _idf()
+        vals = np.asarray([self._idf(float(c)) for c in uniq], dtype=np.float64)[inv] if n else np.zeros(0)
         cap = 2
         while cap < 2 * max(n, 1):
             cap *= 2
         tkeys = np.full((cap, 4), -1, dtype=np.int32)
         tidf = np.zeros(cap, dtype=np.float64)
         if n:
-            keys = np.asarray(keys, dtype=np.int32)
-            vals = np.asarray(vals, dtype=np.float64)
             h = _hash_keys(keys)
             probe = np.zeros(n, dtype=np.uint32)
             todo = np.arange(n)
@@ -409,3 +416,41 @@ class CiderDReward:
                                               ptr(st["key"]), ptr(st["ord"]), ptr(st["w"]), ptr(st["norm"]), ptr(st["len"]),
                                               ptr(reward), ptr(scores), stream_ptr()))
         return (reward, scores) if return_scores else reward
+
+
+# ---- the reference's own entry point -----------------------------------------------------------------------------------
+_SCORERS = {}            # (dataset name, device) -> (caption vocabulary, CiderDReward): built once, kept for the whole run
+_SCORERS_LOCK = threading.Lock()
+
+
+def get_self_critical_reward(gen_result, greedy_res, ground_truth, img_ids, caption_vocab, dataset_name, cider_weight=1):
+    """Utils.py:319-367 with its signature and its return value: FloatTensor (batch_size, max_len) on the CPU, every column of row i
+    = cider_weight * (CIDEr-D(sampled caption i) - CIDEr-D(greedy caption i)).  With this, the reference's Engine needs one edit
+    to stop paying for the reward (`from simpleimagecaptionzoo_amd.ciderd import get_self_critical_reward`):
+    the reference builds `CiderD(df='<dataset>-train')` -- an unpickle of the whole document-frequency table -- and re-cooks every
+    reference for EVERY batch (Utils.py:359, ciderD_scorer.py:79-83); here the table is read once per (dataset, device) from the same
+    file, `cider/data/<dataset_name>-train.p` relative to the working directory (ciderD_scorer.py:80), hashed onto the device, and
+    each image's references are cooked once and stay there.  Scores are float64 on the device (csrc/ciderd.hip); the difference,
+    the weight and the float32 cast are done here exactly as the reference does them (Utils.py:361-365)."""
+    import os
+    import pickle
+    dev = gen_result.device if (torch.is_tensor(gen_result) and gen_result.is_cuda) else torch.device("cuda", torch.cuda.current_device())
+    key = (str(dataset_name), str(dev))
+    with _SCORERS_LOCK:
+        hit = _SCORERS.get(key)
+        if hit is None or hit[0] is not caption_vocab:
+            path = os.path.join("cider/data", "%s-train.p" % dataset_name)
+            with open(path, "rb") as f:
+                df = pickle.load(f, encoding="latin1")
+            t0 = time.perf_counter()
+            scorer = CiderDReward(df["document_frequency"], df["ref_len"], caption_vocab.word2ix, dev)
+            scorer.build_seconds = time.perf_counter() - t0
+            hit = _SCORERS[key] = (caption_vocab, scorer)
+    scorer = hit[1]
+    batch_size = gen_result.shape[0]
+    _, scores = scorer.reward(gen_result, greedy_res, ground_truth, list(img_ids), return_scores=True)
+    cider_scores = scores.cpu().numpy()                                  # float64 (2 B): sampled rows, then greedy rows
+    scores = cider_weight * cider_scores
+    scores = scores[:batch_size] - scores[batch_size:]
+    rewards = np.repeat(scores[:, np.newaxis], gen_result.shape[1], 1)
+    return torch.from_numpy(rewards).float()
