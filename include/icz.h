@@ -373,6 +373,13 @@ int icz_prof_select(int32_t which);
  * of the bracketed kernel add to every duration icz_prof_end reports. */
 int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us);
 int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_launch, long long* launches);
+/* The same for the small kernels of a BUTD decoder step (bench.py's roofline entries of the attention trio and the select kernels):
+ * between icz_kprof_begin and icz_kprof_end every EAGER launch (never inside a captured graph) of a group is bracketed by an event
+ * pair on its stream.  Groups: 0 = SoftAttention.forward (BUTD_Model.py:49-62: dec_att product + scores + softmax / weighted sum,
+ * three launches), 1 = greedy token choice + next embedding (:183), 2 = multinomial draw + log-prob + next embedding (:221-233),
+ * 3 = one LSTMCell's pointwise part (:82-83).  icz_kprof_end synchronises and reports the average pair time [us] and the count. */
+int icz_kprof_begin(void);
+int icz_kprof_end(int32_t group, double* avg_us, long long* pairs);
 
 #ifdef __cplusplus
 }

@@ -222,9 +222,12 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         if (ns == 1) { g.out = ws; }
         ICZ_TRY(gemm_f32(GEMM_NT, g, st));
         LstmPointArgs a = {ws, ns, premean, s.img_of_row, P.td_b_ih, P.td_b_hh, s.c1_in, s.h1_out, s.c1_out, s.gates_td_out, nullptr, rows, H, s.live};
+        kprof_mark(KP_LSTM_POINT, true, st);
         launch_lstm_point(a, off, st);
+        kprof_mark(KP_LSTM_POINT, false, st);
     }
     {   // attention
+        kprof_mark(KP_ATTENTION, true, st);
         GemmArgs g = {};
         g.nseg = 1;
         g.seg[0] = {s.h1_out, w_dec, H, H, H, nullptr};
@@ -247,6 +250,7 @@ int Butd::step(const StepIO& s, hipStream_t st) {
         else
             hipLaunchKernelGGL(att_ctx_kernel, dim3(rows, cdiv(D, 512)), dim3(256), 0, st, s.feats, s.img_of_row, (const float*)scores,
                                s.alpha_out ? s.alpha_out : alpha, s.alpha_out2, s.alpha2_stride, s.ctx_out ? s.ctx_out : ctx, R, D, s.live);
+        kprof_mark(KP_ATTENTION, false, st);
     }
     const float* ctxp = s.ctx_out ? s.ctx_out : ctx;
     {   // language LSTM: [ctx, h1] W_ih^T + h2 W_hh^T
@@ -318,6 +322,7 @@ int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out,
         if (track && t > 0) s.live = gn + (t - 1);
         ICZ_TRY(step(s, st));
         if (t == 0) track = gn && pns > 1;     // the one-launch select below keeps the count (the two-kernel argmax of <= 32 rows does not)
+        kprof_mark(KP_GREEDY_SELECT, true, st);
         if (pns > 1)         // 33 - 64 rows: the slabs of the vocabulary projection -> token + next embedding in one launch
             hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, (const float*)ws, dims.V, Vp, pns, (size_t)B * Vp,
                                (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, max_len, t, 1,
@@ -327,6 +332,7 @@ int Butd::greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out,
             hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
                                P.embed_weight, dims.E, emb, it, ids_out, max_len, t);
         }
+        kprof_mark(KP_GREEDY_SELECT, false, st);
         cur ^= 1;
     }
     ICZ_CHECK_HIP(hipGetLastError());

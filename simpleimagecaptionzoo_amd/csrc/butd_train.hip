@@ -241,7 +241,9 @@ int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float
             a.emb_table = P.embed_weight; a.emb_next = tb.emb + (size_t)(t + 1) * B * dims.E; a.E = dims.E;
             a.emb_drop = make_drop(d_seed, true, rng.emb_mask, (size_t)B * dims.E, RNG_EMB, t + 1);
         }
+        kprof_mark(KP_SAMPLE_SELECT, true, st);
         launch_sample_select(st, B, a);
+        kprof_mark(KP_SAMPLE_SELECT, false, st);
     }
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;

@@ -887,6 +887,27 @@ static GemmProf g_prof;
 static thread_local bool g_capturing = false;
 void gemm_set_capturing(bool on) { g_capturing = on; }
 
+// ---- event pairs around groups of small kernels (icz_kprof_*, include/icz.h)
+struct KProf { bool on = false; std::vector<hipEvent_t> ev[KP_GROUPS]; size_t used[KP_GROUPS] = {}; };
+static KProf g_kprof;
+void kprof_mark(int group, bool begin, hipStream_t st) {
+    if (!g_kprof.on || g_capturing || group < 0 || group >= KP_GROUPS) return;
+    std::vector<hipEvent_t>& ev = g_kprof.ev[group];
+    size_t& u = g_kprof.used[group];
+    if (begin) {
+        if (u + 2 > ev.size()) {
+            if (ev.size() >= 8192) return;
+            hipEvent_t a = nullptr, b = nullptr;
+            if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return;
+            ev.push_back(a); ev.push_back(b);
+        }
+        (void)hipEventRecord(ev[u], st);
+    } else if (u + 2 <= ev.size()) {
+        (void)hipEventRecord(ev[u + 1], st);
+        u += 2;
+    }
+}
+
 static void prof_account(const GemmArgs& a) {
     double kb = 0.0, k = 0.0;
     for (int s = 0; s < a.nseg; ++s) { k += a.seg[s].K; }
@@ -1222,6 +1243,26 @@ int gemm_prof_pair_overhead(hipStream_t stream, int n, double* avg_us) {
 extern "C" {
 int icz_prof_pair_overhead(void* stream, int32_t n, double* avg_us) { return icz::gemm_prof_pair_overhead((hipStream_t)stream, n, avg_us); }
 int icz_prof_begin(void) { icz::gemm_prof_begin(); return ICZ_OK; }
+int icz_kprof_begin(void) {
+    icz::g_kprof.on = true;
+    for (size_t& u : icz::g_kprof.used) u = 0;
+    return ICZ_OK;
+}
+int icz_kprof_end(int32_t group, double* avg_us, long long* pairs) {
+    ICZ_REQUIRE(group >= 0 && group < icz::KP_GROUPS && avg_us && pairs, "icz_kprof_end: bad arguments");
+    icz::g_kprof.on = false;
+    ICZ_CHECK_HIP(hipDeviceSynchronize());
+    const size_t n = icz::g_kprof.used[group] / 2;
+    double tot = 0.0;
+    for (size_t i = 0; i < n; ++i) {
+        float ms = 0.f;
+        ICZ_CHECK_HIP(hipEventElapsedTime(&ms, icz::g_kprof.ev[group][2 * i], icz::g_kprof.ev[group][2 * i + 1]));
+        tot += ms;
+    }
+    *avg_us = n ? tot * 1e3 / (double)n : 0.0;
+    *pairs = (long long)n;
+    return ICZ_OK;
+}
 int icz_prof_select(int32_t which) {
     if (which < 0 || which > 1) { icz::set_error("icz_prof_select: %d (0 = all skinny forward GEMMs, 1 = resident-activation kernel)", which); return ICZ_ERR_INVALID; }
     icz::gemm_prof_select(which);

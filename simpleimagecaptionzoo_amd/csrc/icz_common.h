@@ -35,6 +35,9 @@ void set_error(const char* fmt, ...);
     } while (0)
 
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+// event pairs around groups of small kernels (icz_kprof_begin / icz_kprof_end, include/icz.h); no-ops unless enabled, never inside a capture
+enum { KP_ATTENTION = 0, KP_GREEDY_SELECT = 1, KP_SAMPLE_SELECT = 2, KP_LSTM_POINT = 3, KP_GROUPS = 4 };
+void kprof_mark(int group, bool begin, hipStream_t st);
 // padded vocabulary size (row stride of logits, rows of the materialised predict weight): a multiple of 64 so that
 // V can be the K dimension of a GEMM on the fast (tail-free) path; pad entries are kept at zero
 static inline int pad_vocab(int V) { return (V + 63) & ~63; }

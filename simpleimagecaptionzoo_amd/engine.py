@@ -129,6 +129,12 @@ class Engine(object):
         self._pinned = None
         self._dev_feats = None
         self.use_graphs = True      # replay captured hipGraphs in SCST / greedy evaluation (buffers are persistent)
+        # data-parallel: start each gradient group's all-reduce from the library's gradient-ready callback, beside the rest of the backward
+        # pass (default); False (or ICZ_DP_OVERLAP=0) = ONE all-reduce of the flat buffer behind the backward pass -- the A/B leg
+        # bench.py reports as `dp_overlap`
+        import os
+        self.dp_overlap = os.environ.get("ICZ_DP_OVERLAP", "1") not in ("0", "")
+        self.phase_events = None    # a list: every SCST step appends its phase-boundary events (phase_times() turns them into ms)
         # The hot path runs on its own non-default stream: after hipGraph replays, eager launches on the legacy null
         # stream were measured 2-3x slower on ROCm 7.2 (implicit synchronisation with the graph's internal streams).
         self.stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
@@ -289,6 +295,11 @@ class BUTDDetection_Eng(Engine):
         self._pending = []
         if not icz_dist.is_distributed() or not self._stage_slices or not hasattr(h, "set_grad_callback"):
             return False
+        if not self.dp_overlap:
+            if getattr(self, "_hooked", None) is h:
+                h.set_grad_callback(None)
+                self._hooked = None
+            return False
         if getattr(self, "_hooked", None) is not h:
             import torch.distributed as td
 
@@ -417,14 +428,34 @@ class BUTDDetection_Eng(Engine):
             restore()
         return losses
 
+    def _mark(self, marks):
+        if marks is not None:
+            e = torch.cuda.Event(enable_timing=True)
+            e.record()
+            marks.append(e)
+
+    def phase_times(self, skip=0):
+        """Mean GPU time per phase (ms) of the SCST steps recorded since `phase_events = []`: rollouts / reward / backward /
+        allreduce_exposed (what the step WAITS for the gradient exchange behind its backward pass: 0 for one process, the whole
+        all-reduce with dp_overlap off) / adam.  Call after a synchronize."""
+        names = ("rollouts", "reward", "backward", "allreduce_exposed", "adam")
+        steps = (self.phase_events or [])[skip:]
+        if not steps:
+            return {}
+        return {n: sum(m[i].elapsed_time(m[i + 1]) for m in steps) / len(steps) for i, n in enumerate(names)}
+
     def _scst_steps(self, monitor, scorer, optimizer, rngs, tqdm_visible, losses):
         for batch_i, (img_ids, img_tensors, img_gts, supp_info_datas) in enumerate(monitor):
             visual_inputs = self.modify_visual_inputs(img_tensors=img_tensors, supp_info_datas=supp_info_datas)
             feats = self._features(visual_inputs)
             h = self._hot_handle()
             rng = rngs[batch_i] if rngs is not None else self.model._next_rng()
+            marks = [] if self.phase_events is not None else None
+            self._mark(marks)
             greedy_res, seq_gen, seq_logprobs = h.rollouts(feats, 20, rng)
+            self._mark(marks)
             rewards = scorer.reward(seq_gen, greedy_res, img_gts, img_ids)
+            self._mark(marks)
             grads = self._grads()
             msum_glob = 0.0
             if icz_dist.is_distributed():
@@ -438,8 +469,13 @@ class BUTDDetection_Eng(Engine):
                     msum_glob = icz_dist.all_reduce_scalar(ms)
             ov = self._reduce_grads_begin(h)
             loss, _ = h.sample_backward(rewards, grads, msum_glob)
+            self._mark(marks)
             self._reduce_grads_end(ov)
+            self._mark(marks)
             self._apply(optimizer, 0.25)
+            self._mark(marks)
+            if marks is not None:
+                self.phase_events.append(marks)
             losses.append(loss.clone())      # with graphs the handle returns one persistent buffer, overwritten by the next step
             if tqdm_visible:
                 monitor.set_postfix(Loss=np.round(loss.item(), decimals=4))

@@ -357,6 +357,18 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(scaling):
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == scaling and j["steps"] == 2 and j["warmup"] == 1
     assert j["config"]["global_batch"] == (128 if scaling == "weak" else 64) and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["unit"] == "captions/s" and j["higher_is_better"] is True and "grad_allreduce_ms" in j
+    _check_dp_fields(j)
+
+
+def _check_dp_fields(j):
+    """round 5: the N > 1 line explains itself -- per-phase times (max over ranks) and the same steps with the gradient exchange not
+    overlapped with the backward pass"""
+    ph = j["phases_ms"]
+    assert set(("rollouts", "reward", "backward", "allreduce_exposed", "adam")) <= set(ph) and all(ph[k] >= 0 for k in ph)
+    assert ph["rollouts"] > 0 and ph["backward"] > 0 and ph["adam"] > 0
+    ov = j["dp_overlap"]
+    assert ov["on_ms"] > 0 and ov["off_ms"] > 0 and ov["allreduce_exposed_off_ms"] > 0 and ov["allreduce_exposed_on_ms"] >= 0
+    assert j["vs_baseline"] is None and j["vs_reference_in_container"] > 0
 
 
 @pytest.mark.parametrize("n,extra", [(2, ["--scaling", "weak"]), (5, ["--scaling", "strong", "--batch", "40"])])
@@ -375,6 +387,22 @@ def test_bench_starts_its_own_ranks(n, extra):
     j = json.loads(line[0])
     assert j["n_gpus"] == n and j["ranks_seen"] == n and j["config"]["parallelism"] == "dp%d" % n
     assert j["config"]["global_batch"] == (128 if n == 2 else 40) and j["value"] > 0 and "grad_allreduce_ms" in j
+    _check_dp_fields(j)
+
+
+def test_bench_launcher_kills_the_other_ranks_when_one_dies():
+    """A rank that exits early used to leave the others in the rendezvous until the process-group timeout, with their output
+    discarded: now the launcher polls every child, kills the rest at the first failure (or at ICZ_BENCH_RANK_TIMEOUT), prints
+    every rank's tail and exits non-zero -- within seconds."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env.update(ICZ_REHEARSE_ONE_GPU="1", ICZ_BENCH_TEST_FAIL_RANK="1", ICZ_BENCH_RANK_TIMEOUT="300")
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--headline-only"],
+                       env=env, capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode != 0 and time.time() - t0 < 120
+    assert "rank 1 exited with code" in r.stderr and "---- rank 1" in r.stderr and "told to fail" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
 
 
 def test_bench_refuses_a_rank_count_that_is_not_the_one_asked_for():
