@@ -49,6 +49,8 @@ struct TrainBuf {
     uint8_t* unf = nullptr; int* nunf = nullptr; float *coef = nullptr, *loss_rows = nullptr;
     uint8_t* gunf = nullptr; int* gnunf = nullptr;            // the same for the greedy baseline of an SCST step (greedy_chain, scst = true)
     int* live_rows = nullptr;                                 // (steps the sampled rollout ran) x B: row limit of the backward pass's batched GEMMs
+    int* nany = nullptr;                                      // merged chain: unfinished sampled rows + greedy rows that have not ended, per step
+    int32_t* img2 = nullptr;                                  // merged chain: image of each decoder row (row r of 2 B -> image r mod B)
     float *dGtd = nullptr, *dGlm = nullptr, *dDec = nullptr, *dEmb = nullptr, *dH2d = nullptr, *dEnc = nullptr;
     float *dwaff = nullptr, *dalpha = nullptr, *dS = nullptr, *dGsum = nullptr;
     float *dc1[2] = {nullptr, nullptr}, *dc2[2] = {nullptr, nullptr};
@@ -126,7 +128,7 @@ struct Butd {
     int greedy_impl(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st);
     int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
     int greedy_chain(const float* feats, int B, int max_len, int64_t* ids_out, float* alphas_out, hipStream_t st, bool scst = false);
-    int sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, int row0 = 0, int64_t* ids_out = nullptr);
     int rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     hipStream_t side_st = nullptr;
@@ -138,6 +140,12 @@ struct Butd {
     int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st,
                              int phases = 0xF, bool fire_cb = true);
     bool bptt_joined = false;            // the predict-gradient branch has been joined (bptt phases)
+    int merge_small = 8;                 // option "merge_small" = n: SCST rollouts of <= n images (n <= 32) run as ONE chain of 2 B decoder rows
+                                         // (sample_chain with row0 = B); 0 = never.  Default 8: measured round 5 (EXPERIMENTS.md), the
+                                         // merged chain saves 0.2 ms of rollouts at every size but costs the backward pass 0.06 / 0.15 /
+                                         // 0.37 ms at 8 / 16 / 32 images (its batched GEMMs then run over 2 B rows per step)
+    int cur_rows = 0, cur_row0 = 0;      // rows per step slot of the stored forward pass and the offset of the rows the backward pass works on
+                                         // (a merged chain stores 2 B rows per step, the sampled rollout's are rows B .. 2 B - 1)
     bool early_out = true;               // option "early_out": 0 = run the steps behind the reference's break as rounds 1 - 4 did (A/B)
     bool bptt_early_out = false;         // backward of a sampled rollout: steps behind the reference's break return at entry (bptt)
 
@@ -156,7 +164,7 @@ struct Butd {
     std::vector<int> rows_t;
     int ensure_train(int B, int T);
     int train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready = false, int* pred_nsplit = nullptr,
-                   bool skip_predict = false, const int* live = nullptr);
+                   bool skip_predict = false, const int* live = nullptr, int row0 = 0);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_mask_sum(float* out, hipStream_t st);
     int sample_backward(const float* reward, const icz_butd_params* G, float* loss_out, float* mask_sum_out,
@@ -182,7 +190,7 @@ int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& f
     if (!use_graphs) return fn(st);
     ++tick;
     std::vector<uintptr_t> key = key_in;
-    key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0));          // flags that change the captured launch sequence
+    key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0) + 4 * merge_small);          // flags that change the captured launch sequence
     key.push_back(gemm_prof_on() ? 1 : 0);
     for (auto& e : graphs)
         if (e.key == key) {

@@ -102,7 +102,9 @@ __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ ta
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= E) return;
     f32x4 x = *reinterpret_cast<const f32x4*>(table + (size_t)it[row] * E + e);
-    uint32_t k = dc.mode ? dc.keep4((uint64_t)row * E + e) : 0xFu;
+    const int drow = row - dc.row0;                    // (DropCfg::row0: evaluation-mode rows of a merged chain in front)
+    if (drow < 0) dc.mode = 0;
+    uint32_t k = dc.mode ? dc.keep4((uint64_t)drow * E + e) : 0xFu;
     const float sc = dc.mode ? 2.0f : 1.0f;
 #pragma unroll
     for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? (relu ? fmaxf(x[j], 0.f) : x[j]) * sc : 0.f;
@@ -189,7 +191,8 @@ __global__ __launch_bounds__(256) void lstm_point_kernel(LstmPointArgs a, DropCf
     }
     if (a.hdrop_out) {
         float hd = hn;
-        if (dc.mode) hd = dc.keep((uint64_t)row * H + j) ? hn * 2.0f : 0.f;
+        const int drow = row - dc.row0;                // (DropCfg::row0)
+        if (dc.mode && drow >= 0) hd = dc.keep((uint64_t)drow * H + j) ? hn * 2.0f : 0.f;
         a.hdrop_out[(size_t)row * H + j] = hd;
     }
 }
@@ -261,7 +264,8 @@ __global__ __launch_bounds__(256) void lstm_point_gw_kernel(LstmPointArgs a, Dro
     }
     if (a.hdrop_out) {
         float hd = hn;
-        if (dc.mode) hd = dc.keep((uint64_t)row * H + j) ? hn * 2.0f : 0.f;
+        const int drow = row - dc.row0;                // (DropCfg::row0)
+        if (dc.mode && drow >= 0) hd = dc.keep((uint64_t)drow * H + j) ? hn * 2.0f : 0.f;
         a.hdrop_out[(size_t)row * H + j] = hd;
     }
 }
@@ -324,6 +328,8 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
     }
     __syncthreads();
     const float baff = a.b_aff[0];
+    const int drow = row - dc.row0;                    // (DropCfg::row0: evaluation-mode rows of a merged chain in front)
+    if (drow < 0) dc.mode = 0;
     const float sc = dc.mode ? 2.0f : 1.0f;
     const bool shared_bits = dc.mode == 2 && (a.A & 255) == 0;       // whole 256-column strips: every lane runs every c0 iteration
     for (int i0 = wave; part + nparts * i0 < a.R; i0 += 4 * NB) {
@@ -358,7 +364,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
             if (shared_bits) {
                 const int pb = lane >> 3, pg = lane & 7;
                 const int pr = pb == 0 ? rr[0] : (pb == 1 ? rr[1] : rr[NB - 1]);
-                const uint64_t g = (((uint64_t)row * a.R + pr) * a.A + (c0 - lane * 4) + 128 * pg) >> 7;
+                const uint64_t g = (((uint64_t)drow * a.R + pr) * a.A + (c0 - lane * 4) + 128 * pg) >> 7;
                 const uint64_t seed = *dc.seed_p;
                 uint4_ ctr = {(uint32_t)g, (uint32_t)(g >> 32), dc.step, dc.stream};
                 const uint4_ pw = philox4x32_10(ctr, (uint32_t)seed, (uint32_t)(seed >> 32));
@@ -381,7 +387,7 @@ __global__ __launch_bounds__(256) void att_scores_kernel(AttScoreArgs a, DropCfg
                     const f32x4 w = *reinterpret_cast<const f32x4*>(a.w_aff + c);
 #pragma unroll
                     for (int b = 0; b < NB; ++b) {
-                        const uint32_t k = shared_bits ? kq[b][u] : (dc.mode ? dc.keep4(((uint64_t)row * a.R + rr[b]) * a.A + c) : 0xFu);
+                        const uint32_t k = shared_bits ? kq[b][u] : (dc.mode ? dc.keep4(((uint64_t)drow * a.R + rr[b]) * a.A + c) : 0xFu);
 #pragma unroll
                         for (int j = 0; j < 4; ++j) {
                             float zv = fmaxf(x[b][u][j] + d[j], 0.f);
@@ -843,6 +849,8 @@ struct SampleSelArgs {
     int ns; size_t slab_stride; const float* bias; float* logits_store;
     int* live_rows;               // optional: (number of steps the reference ran so far) x rows -- the (t, b) rows the batched GEMMs of
                                   // the backward pass need to read (GemmArgs::rows_live, embed_grad_kernel)
+    // merged chain (row0 > 0, sample_select_kernel<true>): rows < row0 are the greedy baseline's
+    int row0; int64_t* ids_out; uint8_t* g_unfinished; int* n_any;
 };
 constexpr int SEL_THREADS = 1024;       // 16 waves per row: the row (40 KB) sits in LDS
 __device__ __forceinline__ float block_max_n(float v, float* sm, int nw) {
@@ -971,6 +979,12 @@ inline int ss_select_launch(hipStream_t st, int rows, const float* logits_prev, 
 // workgroup per row for the draw: 7.9 + 8.1 us against 15.4 us for round 2's kernel) made the SCST rollouts SLOWER, 2.83 -> 3.09 ms:
 // the sampled chain runs beside the greedy chain, and a launch that fills every CU stalls the other chain's kernels, while this
 // one leaves three quarters of the chip to them.
+// MG = true: the merged chain of a small SCST batch (Butd::merged_chain): rows [0, row0) are the GREEDY baseline's rows (evaluation
+// mode: argmax with ties to the lowest index, BUTD_Model.py:183, next embedding without dropout, ids to ids_out), rows >= row0 the
+// sampled rollout's (row - row0 of every per-row array of the sampled batch).  Two counters: n_unfinished[t] = sampled rows still
+// unfinished (the reference's break, :233: behind it seq / logp are zeros and BPTT has nothing to do), n_any[t] = those + the
+// greedy rows that have not emitted <end> (0 = no kernel of the remaining steps runs).
+template <bool MG>
 __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArgs a) {
     extern __shared__ __attribute__((aligned(16))) float srow[];     // V floats: the finished logits of the row
     __shared__ float smf[16];
@@ -978,21 +992,33 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
     __shared__ int smi[16];
     constexpr int NW = SEL_THREADS / 64;
     const int row = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int sr = MG ? row - a.row0 : row;                 // row of the sampled batch; < 0: a greedy row of the merged chain
+    const bool greedy_row = MG && sr < 0;
     const float sc = a.emb_drop.mode ? 2.0f : 1.0f;
-    if (a.t > 0 && a.n_unfinished[a.t - 1] == 0) {          // every row has finished: zeros, as the reference's early break leaves them (:233)
-        if (tid == 0) {                                     // (the kernels of the steps behind it return at entry: step_dead)
-            a.seq_out[(size_t)row * a.T + a.t] = 0;
-            a.logp_out[(size_t)row * a.T + a.t] = 0.f;
+    const int* const gate = MG ? a.n_any : a.n_unfinished;
+    const bool all_dead = a.t > 0 && gate[a.t - 1] == 0;    // the kernels of this step returned at entry (step_dead)
+    if (all_dead || (MG && !greedy_row && a.t > 0 && a.n_unfinished[a.t - 1] == 0)) {
+        // every (sampled) row has finished: zeros, as the reference's early break leaves them (:233)
+        if (tid == 0) {
+            if (greedy_row) a.ids_out[(size_t)row * a.T + a.t] = 0;
+            else { a.seq_out[(size_t)sr * a.T + a.t] = 0; a.logp_out[(size_t)sr * a.T + a.t] = 0.f; }
             a.it_next[row] = 0;
             a.draw_out[row] = -1;
             a.lse_out[row] = 0.f;
         }
+        if (MG && !all_dead && a.emb_next)                  // the greedy half goes on: this row keeps running on <pad> (finite, never read)
+            for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+                *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
+            }
         return;
     }
-    if (a.live_rows && row == 0 && tid == 0) *a.live_rows = (a.t + 1) * (int)gridDim.x;
+    if (a.live_rows && sr == 0 && tid == 0) *a.live_rows = (a.t + 1) * (int)gridDim.x;
     const float* l = a.logits + (size_t)row * a.ldl;
-    const float u = a.uniforms ? a.uniforms[row] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)row);
-    const bool was_unf = a.unfinished[row] != 0;             // loaded early: the tail below is a chain of dependent accesses
+    const float u = greedy_row ? 0.f : (a.uniforms ? a.uniforms[sr] : rng_uniform(*a.seed_p, (uint32_t)a.t, (uint64_t)sr));
+    const bool was_unf = greedy_row ? (a.t == 0 || a.g_unfinished[row] != 0) : a.unfinished[sr] != 0;   // loaded early: the tail below is a chain of dependent accesses
     // pass 1: one coalesced pass over HBM / L2; every later pass runs out of LDS
     float mx = -INFINITY;
     if (a.ns > 1) {
@@ -1018,6 +1044,39 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         for (int v = tid; v < a.V; v += SEL_THREADS) { const float x = l[v]; srow[v] = x; mx = fmaxf(mx, x); }
     }
     mx = block_max_n(mx, smf, NW);
+    if (greedy_row) {
+        // argmax, ties to the lowest index: the first element of the row that equals its maximum
+        const int per = (a.V + SEL_THREADS - 1) / SEL_THREADS;
+        const int v0 = min(a.V, tid * per), v1 = min(a.V, v0 + per);
+        int cand = 0x7fffffff;
+        for (int v = v0; v < v1; ++v)
+            if (srow[v] == mx) { cand = v; break; }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) cand = min(cand, __shfl_xor(cand, o, 64));
+        if (lane == 0) smi[wave] = cand;
+        __syncthreads();
+        int bi = smi[0];
+#pragma unroll
+        for (int w = 1; w < NW; ++w) bi = min(bi, smi[w]);
+        if ((unsigned)bi >= (unsigned)a.V) bi = 0;      // a row of NaN logits (diverged training): <pad>, not a wild read
+        if (tid == 0) {
+            const bool unf = was_unf && bi != 2;
+            a.g_unfinished[row] = unf ? 1 : 0;
+            a.ids_out[(size_t)row * a.T + a.t] = bi;
+            a.it_next[row] = bi;
+            a.draw_out[row] = -1;                       // no gradient flows into an evaluation-mode row (reinforce_dlogits_kernel)
+            a.lse_out[row] = 0.f;
+            if (unf) atomicAdd(&a.n_any[a.t], 1);
+        }
+        if (a.emb_next)
+            for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
+                f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + (size_t)bi * a.E + e);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) x[j] = fmaxf(x[j], 0.f);
+                *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
+            }
+        return;
+    }
     // pass 2: contiguous slice per thread -> the first index above the target is the minimum over threads.
     // p_v = exp(log_softmax(x)_v) = expf((x_v - M) - lse) with lse = logf(sum expf(x - M)) in float32 -- the reference's own
     // float expression (:221-223), so that the float64 CDF below agrees with the oracle's to the last bit in all but a few draws in 10^5
@@ -1074,26 +1133,30 @@ __global__ __launch_bounds__(SEL_THREADS) void sample_select_kernel(SampleSelArg
         const bool unf = was_unf && (d != 2);
         tok = unf ? d : 0;
         if (tid == 0) {
-            a.unfinished[row] = unf ? 1 : 0;
-            a.seq_out[(size_t)row * a.T + a.t] = tok;
-            a.logp_out[(size_t)row * a.T + a.t] = (srow[d] - mx) - lse;
+            a.unfinished[sr] = unf ? 1 : 0;
+            a.seq_out[(size_t)sr * a.T + a.t] = tok;
+            a.logp_out[(size_t)sr * a.T + a.t] = (srow[d] - mx) - lse;
             a.it_next[row] = tok;
             a.draw_out[row] = d;
             a.lse_out[row] = mx + lse;
-            if (unf) atomicAdd(&a.n_unfinished[a.t], 1);
+            if (unf) {
+                atomicAdd(&a.n_unfinished[a.t], 1);
+                if (MG) atomicAdd(&a.n_any[a.t], 1);
+            }
         }
     }
     if (a.emb_next)
         for (int e = tid * 4; e < a.E; e += 4 * SEL_THREADS) {
             f32x4 x = *reinterpret_cast<const f32x4*>(a.emb_table + (size_t)tok * a.E + e);
-            const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)row * a.E + e) : 0xFu;
+            const uint32_t k = a.emb_drop.mode ? a.emb_drop.keep4((uint64_t)sr * a.E + e) : 0xFu;
 #pragma unroll
             for (int j = 0; j < 4; ++j) x[j] = ((k >> j) & 1u) ? fmaxf(x[j], 0.f) * sc : 0.f;
             *reinterpret_cast<f32x4*>(a.emb_next + (size_t)row * a.E + e) = x;
         }
 }
 inline void launch_sample_select(hipStream_t st, int rows, const SampleSelArgs& a) {
-    hipLaunchKernelGGL(sample_select_kernel, dim3(rows), dim3(SEL_THREADS), sizeof(float) * a.V, st, a);
+    if (a.row0 > 0) hipLaunchKernelGGL(sample_select_kernel<true>, dim3(rows), dim3(SEL_THREADS), sizeof(float) * a.V, st, a);
+    else hipLaunchKernelGGL(sample_select_kernel<false>, dim3(rows), dim3(SEL_THREADS), sizeof(float) * a.V, st, a);
 }
 
 // ---------------------------------------------------------------------------------------------------------
@@ -1133,13 +1196,16 @@ __global__ __launch_bounds__(256) void reinforce_loss_kernel(const float* __rest
 // Written in place over the saved logits; pad columns [V, ldl) are zeroed.
 __global__ __launch_bounds__(256) void reinforce_dlogits_kernel(float* __restrict__ logits, int V, int ldl,
                                                                 const int32_t* __restrict__ draw, const float* __restrict__ lse,
-                                                                const float* __restrict__ coef, int B, int T) {
+                                                                const float* __restrict__ coef, int B, int T, int Bs = 0, int row0 = 0) {
+    // Bs > 0: the slots hold Bs rows per step, of which rows [row0, row0 + B) are the sampled rollout's (merged chain); the rows in
+    // front are evaluation-mode rows (draw = -1): zero gradient
     const int row = blockIdx.y;
     const int v = blockIdx.x * 256 + threadIdx.x;
     if (v >= ldl) return;
-    const int t = row / B, b = row % B;
+    const int stride = Bs > 0 ? Bs : B;
+    const int t = row / stride, b = row % stride - row0;
     float* l = logits + (size_t)row * ldl;
-    const float c = coef[(size_t)b * T + t];
+    const float c = b >= 0 ? coef[(size_t)b * T + t] : 0.f;
     const int d = draw[row];
     float g = 0.f;
     if (v < V && d >= 0 && c != 0.f) g = c * ((v == d ? 1.f : 0.f) - expf(l[v] - lse[row]));
@@ -1429,6 +1495,7 @@ struct AttBwdDencArgs {
     float* denc; float* dwaff_part;
     int B, R, A, T;
     int mode; const uint8_t* mask; size_t mask_step; const uint64_t* seed_p; uint32_t stream;
+    int Bs;          // rows per time step in dec_all / ds_all (0 = B; a merged chain stores 2 B, the pointers then start at its second half)
 };
 template <int TT>
 __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
@@ -1440,9 +1507,10 @@ __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
     __shared__ uint32_t sbits[4][2][TT][4];
     const int row = blockIdx.x, part = blockIdx.y, nparts = gridDim.y, tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6, half = lane >> 5, hl = lane & 31;
+    const int Bst = a.Bs > 0 ? a.Bs : a.B;
     for (int i = tid; i < a.T * a.R; i += 256) {
         const int t = i / a.R, r = i % a.R;
-        sds_t[i] = a.ds_all[((size_t)t * a.B + row) * a.R + r];
+        sds_t[i] = a.ds_all[((size_t)t * Bst + row) * a.R + r];
     }
     __syncthreads();
     const float sc = a.mode ? 2.0f : 1.0f;
@@ -1457,7 +1525,7 @@ __global__ __launch_bounds__(256) void att_bwd_denc_kernel(AttBwdDencArgs a) {
 #pragma unroll
             for (int j = 0; j < TT; ++j) {
                 const int t = min(t0 + j, a.T - 1);
-                d[j] = cv ? *reinterpret_cast<const f32x4*>(a.dec_all + ((size_t)t * a.B + row) * a.A + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
+                d[j] = cv ? *reinterpret_cast<const f32x4*>(a.dec_all + ((size_t)t * Bst + row) * a.A + c) : (f32x4){0.f, 0.f, 0.f, 0.f};
             }
             for (int r = part; r < a.R; r += nparts) {
                 const size_t eoff = ((size_t)row * a.R + r) * a.A + c;

@@ -17,7 +17,7 @@ __global__ void sample_init_kernel(uint8_t* unf, int* nunf, int64_t* tok, int B,
 
 int Butd::ensure_train(int B, int T) {
     if (tb.B >= B && tb.T >= T) return ICZ_OK;
-    ICZ_REQUIRE(B <= dims.max_rows, "butd: batch %d exceeds capacity %d", B, dims.max_rows);
+    ICZ_REQUIRE(B <= 2 * dims.max_rows, "butd: batch %d exceeds capacity %d", B, dims.max_rows);      // (2 x: the merged chain of a small SCST batch)
     ICZ_REQUIRE(T <= XE_MAX_T, "butd: %d steps exceed the limit of %d", T, XE_MAX_T);
     // Sized by what the batches ask for, not by the handle's row capacity (which also covers images x beam rows): the
     // reference never truncates captions (Datasets.py:47-51), so the step count of an XE batch is only known when it
@@ -71,6 +71,8 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.gunf, B));
     ICZ_TRY(zalloc((void**)&tb.gnunf, sizeof(int) * T));
     ICZ_TRY(zalloc((void**)&tb.live_rows, 16));
+    ICZ_TRY(zalloc((void**)&tb.nany, sizeof(int) * T));
+    ICZ_TRY(zalloc((void**)&tb.img2, sizeof(int32_t) * B));
     ICZ_TRY(zalloc((void**)&tb.coef, sizeof(float) * TB));
     ICZ_TRY(zalloc((void**)&tb.loss_rows, sizeof(float) * TB));
     ICZ_TRY(zalloc((void**)&tb.dGtd, sizeof(float) * TB * 4 * H));
@@ -107,8 +109,8 @@ int Butd::ensure_train(int B, int T) {
     return ICZ_OK;
 }
 
-static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base, size_t per_step, uint32_t stream, int t) {
-    DropCfg d = {0, nullptr, seed_p, stream, (uint32_t)t};
+static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base, size_t per_step, uint32_t stream, int t, int row0 = 0) {
+    DropCfg d = {0, nullptr, seed_p, stream, (uint32_t)t, row0};
     if (!train) return d;
     if (base) { d.mode = 1; d.mask = base + per_step * t; }
     else d.mode = 2;
@@ -117,8 +119,9 @@ static DropCfg make_drop(const uint64_t* seed_p, bool train, const uint8_t* base
 
 // ------------------------------------------------------------------------------------------------
 // forward step into the saved-activation slots of time t (rows = active rows; slot stride = Bs rows)
+// row0 > 0: the merged chain -- rows [0, row0) are evaluation-mode rows, the dropout arrays / Philox indices belong to the Bs - row0 rows behind
 int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hipStream_t st, bool emb_ready, int* pred_nsplit, bool skip_predict,
-                     const int* live) {
+                     const int* live, int row0) {
     const size_t H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R;
     const size_t Vp = round4(dims.V);
     const size_t slot = (size_t)t * Bs;
@@ -135,9 +138,11 @@ int Butd::train_step(const float* feats, int rows, int Bs, int t, bool train, hi
     // own slab workspace / score scratch (backward-only buffers, idle during the forward): the sampled rollout can
     // then run concurrently with the greedy rollout, which uses the handle's
     s.ws_alt = tb.X[0]; s.scores_alt = tb.dalpha;
-    s.drop_emb = make_drop(d_seed, train, rng.emb_mask, (size_t)Bs * E, RNG_EMB, t);
-    s.drop_att = make_drop(d_seed, train, rng.att_mask, (size_t)Bs * R * A, RNG_ATT, t);
-    s.drop_out = make_drop(d_seed, train, rng.out_mask, (size_t)Bs * H, RNG_OUT, t);
+    const size_t Bd = (size_t)(Bs - row0);            // rows the dropout arrays are laid out for
+    s.drop_emb = make_drop(d_seed, train, rng.emb_mask, Bd * E, RNG_EMB, t, row0);
+    s.drop_att = make_drop(d_seed, train, rng.att_mask, Bd * R * A, RNG_ATT, t, row0);
+    s.drop_out = make_drop(d_seed, train, rng.out_mask, Bd * H, RNG_OUT, t, row0);
+    if (row0 > 0) s.img_of_row = tb.img2;
     s.pred_nsplit = pred_nsplit;
     s.skip_predict = skip_predict;
     s.live = live;
@@ -152,6 +157,7 @@ int Butd::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* se
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats;
+    cur_rows = B; cur_row0 = 0;
     rows_t.assign(T, B);
     cur_seq = seq_out; cur_logp = logp_out;
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
@@ -174,7 +180,9 @@ int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* 
     ICZ_REQUIRE(feats && ids_out && seq_out && logp_out && r, "butd rollouts: null argument");
     ICZ_REQUIRE(B > 0 && T > 0 && B <= dims.max_rows, "butd rollouts: bad B/T");
     ICZ_REQUIRE(fresh, "butd: call icz_butd_refresh_weights after binding/updating parameters");
-    ICZ_TRY(ensure_train(B, T));
+    // <= 32 images: ONE chain of 2 B decoder rows (sample_chain with row0 = B) instead of two chains that each stream the weights
+    const bool merged = B <= merge_small;
+    ICZ_TRY(ensure_train(merged ? 2 * B : B, T));
     if (!side_st) {
         ICZ_CHECK_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
@@ -183,6 +191,7 @@ int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* 
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_feats = feats;
+    cur_rows = merged ? 2 * B : B; cur_row0 = merged ? B : 0;
     rows_t.assign(T, B);
     cur_seq = seq_out; cur_logp = logp_out;
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
@@ -193,6 +202,7 @@ int Butd::rollouts(const float* feats, int B, int T, const icz_rng* r, int64_t* 
 
 int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
     ICZ_TRY(prologue(feats, B, st));
+    if (cur_row0 > 0) return sample_chain(feats, B, T, seq_out, logp_out, st, cur_row0, ids_out);
     if (!concurrent) {
         ICZ_TRY(greedy_chain(feats, B, T, ids_out, nullptr, st, true));
         return sample_chain(feats, B, T, seq_out, logp_out, st);
@@ -209,40 +219,56 @@ int Butd::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int6
     return sg != ICZ_OK ? sg : ss;
 }
 
-int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st) {
+__global__ void merged_init_kernel(int32_t* img2, int B, int* nany, int T, int64_t* tok_greedy) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < 2 * B) img2[i] = i % B;
+    if (i < T) nany[i] = 0;
+    if (i < B) tok_greedy[i] = 1;
+}
+
+// The sampled rollout of B rows into the saved-activation slots.  row0 = B (and ids_out): the MERGED chain of a small SCST batch --
+// every step carries 2 B decoder rows, the greedy baseline's (evaluation mode, argmax) in front of the sampled rollout's, so that
+// the weights are streamed once per step pair instead of once per chain (at <= 32 rows a decoder step is bound by its weight
+// stream: 196.68 MB against 8 - 32 x 0.49 MB of per-row data).  Per-row modes live in the kernels (DropCfg::row0,
+// sample_select_kernel<true>); the slots hold 2 B rows per step, the backward pass works on the second half (Butd::bptt).
+int Butd::sample_chain(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, int row0, int64_t* ids_out) {
     const size_t H = dims.H;
     const size_t Vp = round4(dims.V);
+    const int Bs = B + row0;
     // slot 0 of the state buffers = zeros; unfinished flags = 1, counters = 0, first token = <sta>
     {
         ZeroList z = {{tb.h1, tb.c1, tb.h2, tb.c2}, 4};
-        const size_t n = (size_t)B * H;
+        const size_t n = (size_t)Bs * H;
         hipLaunchKernelGGL(zero_bufs_kernel, dim3(cdiv((int)(n / 4), 256)), dim3(256), 0, st, z, n);
     }
-    hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok, B, T);
+    hipLaunchKernelGGL(sample_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, tb.unf, tb.nunf, tb.tok + row0, B, T);
+    if (row0) hipLaunchKernelGGL(merged_init_kernel, dim3(cdiv(2 * B > T ? 2 * B : T, 256)), dim3(256), 0, st, tb.img2, B, tb.nany, T, tb.tok);
+    const int* const counts = row0 ? tb.nany : tb.nunf;           // what keeps a step alive
     for (int t = 0; t < T; ++t) {
         int pns = 1;
         // step t > 0 is dead when no row was left unfinished by step t - 1 (the reference breaks out of its loop there, :233): every
         // kernel of it returns at entry, sample_select_kernel writes the zeros the reference's pre-allocated outputs keep
-        ICZ_TRY(train_step(feats, B, B, t, true, st, t > 0, &pns, false, (t > 0 && early_out) ? tb.nunf + (t - 1) : nullptr));
+        ICZ_TRY(train_step(feats, Bs, Bs, t, true, st, t > 0, &pns, false, (t > 0 && early_out) ? counts + (t - 1) : nullptr, row0));
         SampleSelArgs a = {};
-        a.logits = tb.logit + (size_t)t * B * Vp; a.V = dims.V; a.ldl = (int)Vp;
+        a.logits = tb.logit + (size_t)t * Bs * Vp; a.V = dims.V; a.ldl = (int)Vp;
         if (pns > 1) {          // the predict GEMM left split-K slabs in the chain's workspace (train_step: tb.X[0])
-            a.logits = tb.X[0]; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b;
-            a.logits_store = tb.logit + (size_t)t * B * Vp;
+            a.logits = tb.X[0]; a.ns = pns; a.slab_stride = (size_t)Bs * Vp; a.bias = P.predict_b;
+            a.logits_store = tb.logit + (size_t)t * Bs * Vp;
         }
         a.uniforms = rng.uniforms ? rng.uniforms + (size_t)t * B : nullptr;
         a.seed_p = d_seed; a.t = t; a.T = T;
         a.unfinished = tb.unf; a.n_unfinished = tb.nunf;
         a.live_rows = tb.live_rows;
         a.seq_out = seq_out; a.logp_out = logp_out;
-        a.it_next = tb.tok + (size_t)(t + 1) * B;
-        a.draw_out = tb.draw + (size_t)t * B; a.lse_out = tb.lse + (size_t)t * B;
+        a.row0 = row0; a.ids_out = ids_out; a.g_unfinished = tb.gunf; a.n_any = tb.nany;
+        a.it_next = tb.tok + (size_t)(t + 1) * Bs;
+        a.draw_out = tb.draw + (size_t)t * Bs; a.lse_out = tb.lse + (size_t)t * Bs;
         if (t + 1 < T) {             // the next step's input embedding, fused (step t + 1's slot and dropout stream)
-            a.emb_table = P.embed_weight; a.emb_next = tb.emb + (size_t)(t + 1) * B * dims.E; a.E = dims.E;
+            a.emb_table = P.embed_weight; a.emb_next = tb.emb + (size_t)(t + 1) * Bs * dims.E; a.E = dims.E;
             a.emb_drop = make_drop(d_seed, true, rng.emb_mask, (size_t)B * dims.E, RNG_EMB, t + 1);
         }
         kprof_mark(KP_SAMPLE_SELECT, true, st);
-        launch_sample_select(st, B, a);
+        launch_sample_select(st, Bs, a);
         kprof_mark(KP_SAMPLE_SELECT, false, st);
     }
     ICZ_CHECK_HIP(hipGetLastError());
@@ -296,8 +322,8 @@ int Butd::sample_backward_impl(const float* reward, const icz_butd_params& G, fl
     if (phases & 1) {
         hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum_global,
                            tb.coef, loss_out, mask_sum_out);
-        hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
-                           tb.draw, tb.lse, tb.coef, B, T);
+        hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * cur_rows), dim3(256), 0, st, tb.logit, dims.V, Vp,
+                           tb.draw, tb.lse, tb.coef, B, T, cur_rows, cur_row0);
         ICZ_CHECK_HIP(hipGetLastError());
     }
     return bptt(G, st, phases, fire_cb);
@@ -334,6 +360,7 @@ int Butd::xe_forward(const float* feats, const int64_t* captions, int B, int L, 
     ICZ_REQUIRE(!train || r, "butd xe_forward: training mode needs an icz_rng");
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 2; cur_B = B; cur_T = T; cur_train = train != 0; cur_feats = feats;
+    cur_rows = B; cur_row0 = 0;
     rows_t.assign(T, 0);
     n_tokens = 0;
     for (int t = 0; t < T; ++t) {
@@ -436,8 +463,8 @@ int Butd::sample_backward_dlogp(const float* dlogp, const icz_butd_params* G, hi
     const int B = cur_B, T = cur_T;
     const int Vp = round4(dims.V);
     ICZ_CHECK_HIP(hipMemcpyAsync(tb.coef, dlogp, sizeof(float) * B * T, hipMemcpyDeviceToDevice, st));
-    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tb.logit, dims.V, Vp,
-                       tb.draw, tb.lse, tb.coef, B, T);
+    hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * cur_rows), dim3(256), 0, st, tb.logit, dims.V, Vp,
+                       tb.draw, tb.lse, tb.coef, B, T, cur_rows, cur_row0);
     ICZ_CHECK_HIP(hipGetLastError());
     mode = 0;
     bptt_early_out = true;
@@ -511,12 +538,14 @@ int Butd::bptt_prelude(hipStream_t st) {
 // Every ICZ_TRY inside the loop / behind it sits in a lambda: whatever fails, the side stream is joined before the status is
 // returned (inside a capture an unjoined fork would hide the original error behind a capture failure).
 int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_cb) {
-    const int B = cur_B, T = cur_T;
+    // B rows are worked on per step; the buffers hold Bs rows per step, of which those are rows [roff, roff + B) (Bs = B, roff = 0
+    // except behind a merged chain, whose evaluation-mode rows in front carry zero gradient rows through the GEMMs over all steps)
+    const int B = cur_B, T = cur_T, Bs = cur_rows, roff = cur_row0;
     const int H = dims.H, D = dims.D, E = dims.E, A = dims.A, R = dims.R, V = dims.V;
     const int Vp = round4(V);
-    const int TB = T * B;
+    const int TB = T * Bs;
     const float* feats = cur_feats;
-    const size_t sH = (size_t)B * H;
+    const size_t sH = (size_t)Bs * H;
     // backward of a sampled rollout: the GEMMs over all (t, b) rows stop behind the last step the rollout ran (GemmArgs::rows_live)
     const int* const rl = (bptt_early_out && early_out) ? tb.live_rows : nullptr;
 
@@ -567,7 +596,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     ICZ_TRY(side_branch());
     // ---- XE only: rows that dropped out of the batch must contribute zero (the sample path writes every row, and its
     //      accumulators are initialised by the first processed step)
-    const bool ragged = rows_t[T - 1] < B;
+    const bool ragged = rows_t[T - 1] < B || roff > 0;
     if (ragged) {
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dGtd, 0, sizeof(float) * (size_t)TB * 4 * H, st));
         ICZ_CHECK_HIP(hipMemsetAsync(tb.dGlm, 0, sizeof(float) * (size_t)TB * 4 * H, st));
@@ -582,7 +611,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     int bnext = 0;
     for (int t = T - 1; t >= 0; --t) {
         const int bt = rows_t[t];
-        const size_t slot = (size_t)t * B;
+        const size_t slot = (size_t)t * Bs + roff;
         // REINFORCE backward of a sampled rollout: the steps behind the reference's break never ran (sample_chain) -- their kernels
         // return at entry, the producers of d gates / d dec / ds rows write zeros (the GEMMs over all steps read them), and the
         // first live step takes no carry from the dead one behind it
@@ -718,8 +747,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st, rl));             // h2_{t-1}
-    hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)B * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)B * 4 * H, tb.dGsum);
-    ICZ_TRY(wgrad(tb.dGsum, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));               // mean features
+    hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)Bs * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)Bs * 4 * H, tb.dGsum);
+    ICZ_TRY(wgrad(tb.dGsum + (size_t)roff * 4 * H, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));      // mean features
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st, rl));     // embedding
     ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st, rl));                 // h1_{t-1}
     }   // phase 1
@@ -738,8 +767,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     }
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
     {   // d enc_ctx (sum over time) and the affine-weight partials, from the ds_t recorded by the loop
-        AttBwdDencArgs ea = {enc_ctx, tb.dec, tb.dS, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
-                             cur_train ? (rng.att_mask ? 1 : 2) : 0, rng.att_mask, (size_t)B * R * A, d_seed, (uint32_t)RNG_ATT};
+        AttBwdDencArgs ea = {enc_ctx, tb.dec + (size_t)roff * A, tb.dS + (size_t)roff * R, w_aff, tb.dEnc, tb.dwaff, B, R, A, T,
+                             cur_train ? (rng.att_mask ? 1 : 2) : 0, rng.att_mask, (size_t)B * R * A, d_seed, (uint32_t)RNG_ATT, Bs};
         hipLaunchKernelGGL(att_bwd_denc_kernel<20>, dim3(B, ATT_PARTS), dim3(256), sizeof(float) * T * R, st, ea);
     }
     ICZ_TRY(wgrad(tb.dEnc, A, A, feats, D, D, B * R, tb.dWenc, D, st));
@@ -826,6 +855,7 @@ int icz_butd_saved_alphas(icz_butd_t* h, float* alphas_out, void* stream) {
     ICZ_REQUIRE(h && alphas_out, "icz_butd_saved_alphas: null argument");
     Butd* b = reinterpret_cast<Butd*>(h);
     ICZ_REQUIRE(b->mode != 0 && b->tb.alpha, "icz_butd_saved_alphas: no forward pass stored");
+    ICZ_REQUIRE(b->cur_row0 == 0, "icz_butd_saved_alphas: not available behind a merged SCST rollout (set option merge_small = 0)");
     const int n = b->cur_B * b->cur_T * b->dims.R;
     hipLaunchKernelGGL(saved_alphas_kernel, dim3(cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, b->tb.alpha, b->cur_T, b->cur_B, 1, b->dims.R, alphas_out);
     ICZ_CHECK_HIP(hipGetLastError());

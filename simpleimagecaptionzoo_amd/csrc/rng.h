@@ -57,6 +57,8 @@ struct DropCfg {
     const uint8_t* mask;    // mode 1: keep flags for this step, element-indexed
     const uint64_t* seed_p; // mode 2: seed lives in device memory (a captured graph is replayed with new seeds)
     uint32_t stream, step;
+    int row0;               // forward kernels of a merged greedy + sampled chain: rows < row0 are evaluation-mode rows (no dropout), row
+                            // r >= row0 is row r - row0 of the sampled batch (mask / Philox index); 0 = every row is a training-mode row
     __device__ __forceinline__ bool keep(uint64_t idx) const {
         if (mode == 1) return mask[idx] != 0;
         return rng_keep(*seed_p, stream, step, idx);

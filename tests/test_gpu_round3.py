@@ -107,8 +107,9 @@ def attention_kink_units(feats64, p64, h1_steps, att_masks, tol=3e-6, active_row
     return hit.numpy()
 
 
-def _butd_scst_case(B, T, seed, sharpen=6.0):
-    """device rollouts + REINFORCE gradients of B rows x T steps at full width, and the fp32 / float64 oracle passes on the same inputs"""
+def _butd_scst_case(B, T, seed, sharpen=6.0, options=None):
+    """device rollouts + REINFORCE gradients of B rows x T steps at full width, and the fp32 / float64 oracle passes on the same inputs
+    (options: {handle option: value} set before the run)"""
     from oracle import butd as ob
     from simpleimagecaptionzoo_amd.butd import ButdHandle, make_rng
     from simpleimagecaptionzoo_amd.synth import random_butd_params
@@ -116,6 +117,8 @@ def _butd_scst_case(B, T, seed, sharpen=6.0):
     params["predict.weight_g"].mul_(sharpen)
     h = ButdHandle(R, D, H, E, A, V, max(B, 8), T)
     h.bind(params)
+    for name, value in (options or {}).items():
+        h.set_option(name, value)
     g = torch.Generator(device="cpu")
     g.manual_seed(1000 + seed)
     feats_c = torch.relu(torch.randn(B, R, D, generator=g))
