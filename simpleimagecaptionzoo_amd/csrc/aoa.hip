@@ -34,6 +34,12 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_TRY(alloc((void**)&zeros, sizeof(float) * rows * Hd));
     const size_t nmax = 4 * Hd > (size_t)Vp ? 4 * Hd : (size_t)Vp;
     ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    {   // the resident decoder-step GEMMs (33..128 rows) leave one slab per 256-deep k range (Butd::init's rule): the LSTM gates take
+        // K = E + 2 Hd, the AoA linear K = 2 Hd with N = 2 Hd -- without this the split shrinks to fit and the launch falls to the fp32 kernel
+        const size_t kmax = E + 2 * Hd, r128 = rows < 128 ? rows : 128;
+        const size_t need = (kmax / 256 + 1) * r128 * 4 * Hd;
+        if (need > ws_floats) ws_floats = need;
+    }
     for (int b = 0; b < 2; ++b) {
         Bank& s = bank[b];
         float** ref[] = {&s.xa, &s.xb, &s.ln, &s.o, &s.od, &s.nd, &s.refined, &s.Kd, &s.Vd};

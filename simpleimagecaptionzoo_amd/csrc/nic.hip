@@ -92,6 +92,11 @@ int Nic::init(const icz_nic_dims& d) {
     ICZ_TRY(alloc((void**)&d_msum, 16));
     const size_t nmax = 4 * H > (size_t)Vp ? 4 * H : (size_t)Vp;
     ws_floats = (size_t)TARGET_WGS * 4096 * 2 + rows * nmax;
+    {   // the resident decoder-step GEMM (33..128 rows) leaves one slab per 256-deep k range of K = E + H (Butd::init's rule)
+        const size_t kmax = (size_t)d.E + H, r128 = rows < 128 ? rows : 128;
+        const size_t need = (kmax / 256 + 1) * r128 * 4 * H;
+        if (need > ws_floats) ws_floats = need;
+    }
     ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
     return ICZ_OK;
 }
