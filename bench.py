@@ -261,6 +261,36 @@ def aoa_scst(words, device, B):
            "note": "AoADetection_Eng.SCST_training_epoch: refiner x2 (eval + train mode), greedy + sampled rollout, CIDEr-D reward, "
                    "REINFORCE backward of the decoder, clamp + Adam"}
     out["roofline"] = aoa_roofline(B)
+    out["graphs"] = "rollout pair and backward pass replayed as hipGraphs (round 5); same-box A/B against eager launches: no difference in wall time (the step is device-bound), host issue 2.3 -> 2.1 ms"
+    # the AoA decode step by itself: (greedy decode of 20 steps - greedy decode of 1 step) / 19, refiner pass cancelled out
+    try:
+        h = eng.model._handle()
+        with torch.cuda.stream(eng.stream):
+            f = batches[0][3]["bu_feats"]
+
+            def greedy_ms(T_, reps=10):
+                for _ in range(3):
+                    h.greedy(f, T_)
+                torch.cuda.synchronize()
+                t0_ = _t.perf_counter()
+                for _ in range(reps):
+                    h.greedy(f, T_)
+                torch.cuda.synchronize()
+                return (_t.perf_counter() - t0_) / reps * 1e3
+            t20, t1 = greedy_ms(20), greedy_ms(1)
+        us = (t20 - t1) / 19.0 * 1e3
+        wbytes = 4.0 * (4 * H * (E + H) + 4 * H * H + 8 * H + (H * H + H) + (2 * H * 2 * H + 2 * H) + 2 * H + V * H + V)
+        sbytes = 4.0 * (2 * R * H + H + 6 * H + E)
+        full = wbytes + B * sbytes
+        out["roofline_decode_step"] = {
+            "what": "one AoA greedy decode step of %d rows (embed + LSTM + LayerNorm + query projection + 8-head attention over the hoisted "
+                    "K / V + AoA linear + GLU + predict + argmax), eager launches; (20-step decode - 1-step decode) / 19" % B,
+            "us_per_step": us, "bytes_per_step": full, "achieved": full / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": full / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "bound": "hbm", "traffic": None,
+            "greedy_20_steps_ms": t20, "refiner_and_first_step_ms": t1,
+            "bytes_note": "SURVEY.md 8d: W = 112.8 MB of decoder weights once + per row 2 x 36 x 1024 hoisted K / V, mean, states, embedding (327 680 B)"}
+    except Exception as e:
+        out["roofline_decode_step"] = {"error": repr(e)}
     # config 5 names beam 5: AoADetection beam-search decode (AoA_Model.py:403-502) of the same batch, 5 rows per image, 20 steps
     # (random-init weights never emit <end>: every step runs), refiner pass included
     try:

@@ -249,6 +249,11 @@ int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream);
  * :650-653 -- here the whole refiner does: the padded rows the reference carries along never reach a result) and
  * mean_features averages the valid rows (:253). */
 int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev, const int32_t* counts_host, int32_t n_img);
+/* Option "graphs" = 1 (round 5): icz_aoa_scst_rollouts and icz_aoa_sample_backward are captured into hipGraphs on first use and
+ * replayed afterwards, as icz_butd_set_option("graphs") does for the BUTD decoder; keyed by every pointer and size of the call, so
+ * enable it only when buffers are reused.  Batches with per-image region counts (icz_aoa_set_regions), explicit randomness arrays
+ * and a backward pass under a gradient-ready callback stay eager. */
+int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value);
 /* eval-mode refined features [B,regions,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests.  With
  * region counts the refiner runs on the packed valid rows; rows past an image's count come back as zeros. */
 int icz_aoa_refine(icz_aoa_t* h, const float* feats, int32_t B, float* refined_out, void* stream);

@@ -80,8 +80,21 @@ class AoaHandle:
         except Exception:
             pass
 
-    def enable_graphs(self, on):      # the AoA paths are launched eagerly (no captured graphs yet)
+    def enable_graphs(self, on):
+        """Capture the SCST rollout pair and the REINFORCE backward pass into hipGraphs and replay them (include/icz.h:
+        icz_aoa_set_option).  Implies persistent output buffers: the tensors those calls return are overwritten by the next call."""
         self._persistent = bool(on)
+        check(lib().icz_aoa_set_option(self._h, b"graphs", 1 if on else 0))
+
+    def _buf(self, name, shape, dtype):
+        if not self._persistent:
+            return torch.zeros(shape, dtype=dtype, device=self.device)
+        bufs = self.__dict__.setdefault("_bufs", {})
+        key = (name,) + tuple(shape)
+        t = bufs.get(key)
+        if t is None:
+            t = bufs[key] = torch.zeros(shape, dtype=dtype, device=self.device)
+        return t
 
     def set_grad_callback(self, fn):
         """fn(stage) is called while a backward call is being enqueued, each time a group of decoder gradients is complete in
@@ -178,9 +191,9 @@ class AoaHandle:
         feats = self._feats(feats)
         B = feats.shape[0]
         rng = rng or make_aoa_rng(0)
-        ids = torch.empty(B, max_len, dtype=torch.int64, device=feats.device)
-        seq = torch.zeros(B, max_len, dtype=torch.int64, device=feats.device)
-        lp = torch.zeros(B, max_len, dtype=torch.float32, device=feats.device)
+        ids = self._buf("greedy_ids", (B, max_len), torch.int64)
+        seq = self._buf("sample_seq", (B, max_len), torch.int64)
+        lp = self._buf("sample_lp", (B, max_len), torch.float32)
         check(lib().icz_aoa_scst_rollouts(self._h, ptr(feats), B, max_len, C.byref(rng), ptr(ids), ptr(seq), ptr(lp), stream_ptr()))
         self._live = (feats, rng, seq, lp)
         return ids, seq, lp
@@ -196,8 +209,8 @@ class AoaHandle:
 
     def sample_backward(self, reward, grads, mask_sum_global=0.0):
         reward = reward.to(device=self.device, dtype=torch.float32).contiguous()
-        loss = torch.zeros(1, device=self.device)
-        msum = torch.zeros(1, device=self.device)
+        loss = self._buf("rl_loss", (1,), torch.float32)
+        msum = self._buf("rl_msum", (1,), torch.float32)
         gs = self._grad_struct(grads)
         check(lib().icz_aoa_sample_backward(self._h, ptr(reward), C.byref(gs), ptr(loss), ptr(msum), float(mask_sum_global), stream_ptr()))
         return loss, msum

@@ -122,7 +122,8 @@ int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, in
 
 // img_feats_porjection + AoA_Refine_Core (AoA_Model.py:661-665, 140-162) -> refined [n_img,R,Hd], its region mean, and the
 // decoder block's linear_K / linear_V of it (time-invariant, hoisted out of the decoding loop)
-int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
+// proj != null: img_feats_porjection(feats) has been computed (Aoa::project, packed rows for 'adaptive' batches): only its ReLU / dropout runs
+int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st, const float* proj) {
     const int R = cur_R, Hd = dims.Hd, NH = dims.NH;
     ICZ_REQUIRE(!lens || lens_n == n_img, "aoa: region counts were set for %d images, the batch has %d (icz_aoa_set_regions)", lens_n, n_img);
     const int rows = (int)region_row_count(n_img);
@@ -130,7 +131,7 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
     const size_t nel = (size_t)rows * Hd;
     const unsigned eb = (unsigned)((nel + 255) / 256);
     const float* xin = feats;
-    if (lens) {      // 'adaptive' features: the refiner runs on the valid rows only (packed)
+    if (lens && !proj) {      // 'adaptive' features: the refiner runs on the valid rows only (packed)
         if (!bank[0].featp)
             for (int b = 0; b < 2; ++b) ICZ_TRY(alloc((void**)&bank[b].featp, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.D));
         float* featp = bank[cur_bank].featp;
@@ -140,8 +141,9 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
                            (size_t)rows, dims.D);
         xin = featp;
     }
-    ICZ_TRY(lin(xin, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
-    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, xa, nel, dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), rr, Hd);
+    if (!proj) ICZ_TRY(lin(xin, rows, dims.D, P.proj_w, P.proj_b, Hd, xa, st));
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, proj ? proj : (const float*)xa, xa, nel,
+                       dropp(train, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), rr, Hd);
     const int qc = self_qc(R);
     const size_t lds = self_lds(R, qc);
     float *cur = xa, *nxt = xb;
@@ -173,6 +175,11 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st) {
     ICZ_TRY(lin(refined, rows, Hd, P.dec.v_w, P.dec.v_b, Hd, Vd, st));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
+}
+
+// img_feats_porjection alone (fixed region counts), for the two refiner passes of an SCST step to share (Aoa::rollouts)
+int Aoa::project(const float* feats, int n_img, float* out, hipStream_t st) {
+    return lin(feats, n_img * cur_R, dims.D, P.proj_w, P.proj_b, dims.Hd, out, st);
 }
 
 // One decoder step (AoA_Model.py:319-336)
@@ -248,11 +255,11 @@ static int zero_state(Aoa& a, int rows, hipStream_t st) {
 }
 
 // AoA_Decoder.sample (AoA_Model.py:289-345) behind AoADetection_Captioner.sampler (:698-714)
-int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st) {
+int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj) {
     ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && T > 0, "aoa greedy: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     use_bank(0);
-    ICZ_TRY(refine(feats, B, false, st));
+    ICZ_TRY(refine(feats, B, false, st, proj));
     ICZ_TRY(zero_state(*this, B, st));
     hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);
     int cur = 0;
@@ -363,8 +370,19 @@ int icz_aoa_bind_params(icz_aoa_t* h, const icz_aoa_params* p) {
         ICZ_REQUIRE(((uintptr_t)q[i] & 15) == 0, "icz_aoa_bind_params: parameter %zu not 16-byte aligned", i);
     }
     Aoa* n = reinterpret_cast<Aoa*>(h);
+    if (n->bound && memcmp(&n->P, p, sizeof(*p)) != 0) {      // captured graphs carry the old parameter addresses
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+        n->gc.clear();
+    }
     n->P = *p; n->bound = true; n->fresh = false;
     return ICZ_OK;
+}
+int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value) {
+    ICZ_REQUIRE(h && name, "icz_aoa_set_option: null argument");
+    Aoa* n = reinterpret_cast<Aoa*>(h);
+    if (strcmp(name, "graphs") == 0) { n->use_graphs = value != 0; return ICZ_OK; }
+    set_error("icz_aoa_set_option: unknown option '%s'", name);
+    return ICZ_ERR_INVALID;
 }
 int icz_aoa_refresh_weights(icz_aoa_t* h, void* stream) {
     ICZ_REQUIRE(h, "null handle");

@@ -57,6 +57,12 @@ struct Aoa {
         xa = s.xa; xb = s.xb; ln = s.ln; qkv = s.qkv; o = s.o; od = s.od; nd = s.nd; z = s.z;
         refined = s.refined; meanf = s.meanf; Kd = s.Kd; Vd = s.Vd; ws = s.ws; off = s.off; rowmap = s.rowmap;
     }
+    // hipGraph replay of the SCST rollout pair and of the REINFORCE backward pass (option "graphs"; fixed region counts and Philox
+    // randomness only: an 'adaptive' batch changes its grid sizes, explicit mask arrays their addresses)
+    GraphCache gc;
+    bool use_graphs = false;
+    float* proj_shared = nullptr;        // rollouts: img_feats_porjection(feats) before ReLU / dropout, computed ONCE for the evaluation-
+                                         // mode pass of the greedy baseline and the training-mode pass of the sampled rollout
     hipStream_t side_st = nullptr;
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t low_st = nullptr;                         // backward: the predict layer's weight gradient beside the reverse-time loop (plain priority)
@@ -130,9 +136,11 @@ struct Aoa {
     int refresh(hipStream_t st);
     // out[M,N] = A[M,K] W[N,K]^T + bias  (split-K through `ws` when the launch would be too small)
     int lin(const float* A, int M, int K, const float* W, const float* bias, int N, float* out, hipStream_t st);
-    int refine(const float* feats, int n_img, bool train, hipStream_t st);
+    int refine(const float* feats, int n_img, bool train, hipStream_t st, const float* proj = nullptr);
+    int project(const float* feats, int n_img, float* out, hipStream_t st);
     int step(const AoaStepIO& s, hipStream_t st);
-    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
+    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj = nullptr);
+    int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
     DropP dropp(bool train, const uint8_t* mask, size_t off, uint32_t stream, int step, float p) const {
@@ -151,6 +159,9 @@ struct Aoa {
     int ensure_train(int B, int T);
     AoaStepIO train_io(int rows, int t, bool train);
     int sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_prelude(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
+    int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj = nullptr);
+    int sample_backward_impl(const float* reward, const icz_aoa_params& G, float* loss_out, float* msum_out, hipStream_t st);
     int sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st);
     int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_aoa_rng* r, int train,
                    float* packed_out, hipStream_t st);

@@ -78,12 +78,12 @@ __global__ __launch_bounds__(256) void aoa_unpack_rows_kernel(const float* __res
     *reinterpret_cast<f32x4*>(padded + (size_t)rowmap[row] * n + c) = *reinterpret_cast<const f32x4*>(packed + row * n + c);
 }
 
-// y = drop(relu(x)) in place (feature projection epilogue, AoA_Model.py:661-665)
-__global__ __launch_bounds__(256) void relu_drop_kernel(float* __restrict__ x, size_t n, DropP dp, RegionRows rr, int Hd) {
+// y = drop(relu(x)) (feature projection epilogue, AoA_Model.py:661-665); y may be x
+__global__ __launch_bounds__(256) void relu_drop_kernel(const float* x, float* y, size_t n, DropP dp, RegionRows rr, int Hd) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
     const size_t row = i / Hd;
-    x[i] = dp.apply(fmaxf(x[i], 0.f), rr.padded(row) * Hd + i % Hd);
+    y[i] = dp.apply(fmaxf(x[i], 0.f), rr.padded(row) * Hd + i % Hd);
 }
 
 // Custom LayerNorm (AoA_Model.py:14-25): y = gain * (x - mean) / (std_unbiased + eps) + bias.  One wave per row; the row is

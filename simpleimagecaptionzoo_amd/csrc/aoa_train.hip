@@ -287,16 +287,27 @@ AoaStepIO Aoa::train_io(int rows, int t, bool train) {
     return s;
 }
 
-int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
+// everything of a sampled rollout that is host state or must not sit inside a captured graph: buffers, the Philox seed in device
+// memory, what the backward pass will read back
+int Aoa::sample_prelude(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
     ICZ_REQUIRE(feats && seq_out && logp_out && r && B > 0 && B <= dims.max_rows && T > 0, "aoa sample: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     ICZ_TRY(ensure_train(B, T));
-    use_bank(1);
     rng = *r;
     hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, d_seed, rng.seed, (float*)nullptr, 0.f);
     mode = 1; cur_B = B; cur_T = T; cur_train = true; cur_seq = seq_out; cur_logp = logp_out;
     rows_t.assign(T, B);
-    ICZ_TRY(refine(feats, B, true, st));
+    return ICZ_OK;
+}
+
+int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_TRY(sample_prelude(feats, B, T, r, seq_out, logp_out, st));
+    return sample_impl(feats, B, T, seq_out, logp_out, st);
+}
+
+int Aoa::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj) {
+    use_bank(1);
+    ICZ_TRY(refine(feats, B, true, st, proj));
     const size_t sH = (size_t)B * dims.Hd;
     ICZ_CHECK_HIP(hipMemsetAsync(th, 0, sizeof(float) * sH, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tm, 0, sizeof(float) * sH, st));
@@ -332,19 +343,41 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
     return ICZ_OK;
 }
 
+static bool aoa_explicit_rng(const icz_aoa_rng& r) {
+    return r.uniforms || r.proj_mask || r.ref_att_mask || r.ref_aoa_mask || r.ref_sc_mask || r.emb_mask || r.ctx_mask || r.att_mask || r.out_mask;
+}
+
 // Greedy baseline (evaluation mode, bank 0, side stream) and sampled rollout (training mode, bank 1) of one SCST step
-// (Engine.py:256-261) enqueued as two concurrent chains; identical to greedy() followed by sample().
+// (Engine.py:256-261) enqueued as two concurrent chains; identical to greedy() followed by sample().  Round 5: the feature projection
+// (2048 -> 1024 over B x 36 rows, 9.7 GFLOP at B = 64) is the same product in both passes up to its ReLU / dropout epilogue
+// (AoA_Model.py:661-665, 712-713): computed once in front of the fork; and with option "graphs" the pair is ONE captured hipGraph
+// (fixed region counts, Philox randomness), replayed like the BUTD pair.
 int Aoa::rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    ICZ_REQUIRE(ids_out, "aoa rollouts: null argument");
     if (!side_st) {
         ICZ_CHECK_HIP(hipStreamCreateWithFlags(&side_st, hipStreamNonBlocking));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     }
+    ICZ_TRY(sample_prelude(feats, B, T, r, seq_out, logp_out, st));
+    if (!lens && !proj_shared) ICZ_TRY(alloc((void**)&proj_shared, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.Hd));
+    if (!use_graphs || lens || aoa_explicit_rng(rng)) return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, st);
+    const std::vector<uintptr_t> key = {1, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)T, (uintptr_t)cur_R, (uintptr_t)ids_out, (uintptr_t)seq_out,
+                                        (uintptr_t)logp_out};
+    return gc.run(key, st, [&](hipStream_t s) { return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, s); });
+}
+
+int Aoa::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st) {
+    const float* proj = nullptr;
+    if (!lens) {                        // (an 'adaptive' batch packs its rows per bank: each pass projects its own)
+        ICZ_TRY(project(feats, B, proj_shared, st));
+        proj = proj_shared;
+    }
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
-    const int sg = greedy(feats, B, T, ids_out, side_st);
-    const int ss = sg == ICZ_OK ? sample(feats, B, T, r, seq_out, logp_out, st) : sg;
-    ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));
+    const int sg = greedy(feats, B, T, ids_out, side_st, proj);
+    const int ss = sg == ICZ_OK ? sample_impl(feats, B, T, seq_out, logp_out, st, proj) : sg;
+    ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));       // always join, also on error (a capture must be closed)
     ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     return ss;
 }
@@ -352,13 +385,29 @@ int Aoa::rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_
 int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st) {
     ICZ_REQUIRE(mode == 1, "aoa: no rollout stored (call icz_aoa_sample first)");
     ICZ_REQUIRE(reward && G, "aoa sample_backward: null argument");
-    const int B = cur_B, T = cur_T;
     if (msum_global >= 0.f)      // < 0: keep the device value handed over by icz_aoa_set_norm_global
         hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
+    mode = 0;
+    if (!low_st) {          // the side stream of bptt: created here, outside any capture
+        ICZ_CHECK_HIP(hipStreamCreateWithFlags(&low_st, hipStreamNonBlocking));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+    }
+    // with a DP callback the hook must fire on every call: eager launches (a replayed graph would not call it)
+    if (!use_graphs || lens || grad_cb || aoa_explicit_rng(rng)) return sample_backward_impl(reward, *G, loss_out, msum_out, st);
+    std::vector<uintptr_t> key = {2, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)msum_out, (uintptr_t)cur_B, (uintptr_t)cur_T, (uintptr_t)cur_R,
+                                  (uintptr_t)cur_seq, (uintptr_t)cur_logp};
+    const float* const* gp = reinterpret_cast<const float* const*>(G);
+    for (size_t i = 0; i < sizeof(icz_aoa_params) / sizeof(float*); ++i) key.push_back((uintptr_t)gp[i]);
+    const icz_aoa_params Gc = *G;
+    return gc.run(key, st, [&](hipStream_t s) { return sample_backward_impl(reward, Gc, loss_out, msum_out, s); });
+}
+
+int Aoa::sample_backward_impl(const float* reward, const icz_aoa_params& G, float* loss_out, float* msum_out, hipStream_t st) {
+    const int B = cur_B, T = cur_T;
     hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum, coef, loss_out, msum_out);
     hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, draw, lse, coef, B, T);
-    mode = 0;
-    return bptt(*G, st);
+    return bptt(G, st);
 }
 
 int Aoa::xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_aoa_rng* r, int train,
@@ -519,6 +568,8 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     }
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + 2 * dh + 128 + 4);
     DropCfg off = {0, nullptr, nullptr, 0, 0};
+    // the reverse-time loop in a lambda: whatever it returns, the side stream is joined behind it (a capture must be closed)
+    auto loop = [&]() -> int {
     int cur = 0, nsx = 1, bnext = 0;
     for (int t = T - 1; t >= 0; --t) {
         const int bt = rows_t[t];
@@ -549,7 +600,11 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         bnext = bt;
         cur ^= 1;
     }
+    return ICZ_OK;
+    };
+    const int s_loop = loop();
     if (side) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join2, 0));      // the predict branch has long finished beside the loop
+    if (s_loop != ICZ_OK) return s_loop;
     // ---- embedding gradient
     ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st));
     {

@@ -185,6 +185,56 @@ struct Butd {
 void gemm_set_capturing(bool on);
 bool gemm_prof_on();                  // gemm_f32.hip: event timing active (graphs captured now contain event nodes)
 
+// The same hipGraph cache as Butd::run_cached for the other decoders (AoA): capture on first use of a key, replay afterwards.
+struct GraphCache {
+    struct Entry { std::vector<uintptr_t> key; hipGraphExec_t exec; uint64_t last_use; };
+    std::vector<Entry> graphs;
+    hipStream_t cap_st = nullptr;
+    uint64_t tick = 0;
+    void clear() {
+        for (auto& e : graphs) (void)hipGraphExecDestroy(e.exec);
+        graphs.clear();
+    }
+    ~GraphCache() {
+        clear();
+        if (cap_st) (void)hipStreamDestroy(cap_st);
+    }
+    template <class F>
+    int run(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& fn) {
+        ++tick;
+        std::vector<uintptr_t> key = key_in;
+        key.push_back(gemm_prof_on() ? 1 : 0);
+        for (auto& e : graphs)
+            if (e.key == key) {
+                e.last_use = tick;
+                ICZ_CHECK_HIP(hipGraphLaunch(e.exec, st));
+                return ICZ_OK;
+            }
+        if (!cap_st) ICZ_CHECK_HIP(hipStreamCreateWithFlags(&cap_st, hipStreamNonBlocking));
+        ICZ_CHECK_HIP(hipStreamBeginCapture(cap_st, hipStreamCaptureModeThreadLocal));
+        gemm_set_capturing(true);
+        const int status = fn(cap_st);
+        gemm_set_capturing(false);
+        hipGraph_t g = nullptr;
+        hipError_t ce = hipStreamEndCapture(cap_st, &g);
+        if (status != ICZ_OK) { if (g) (void)hipGraphDestroy(g); return status; }
+        if (ce != hipSuccess || !g) { set_error("hipStreamEndCapture failed: %s", hipGetErrorString(ce)); return ICZ_ERR_HIP; }
+        hipGraphExec_t exec = nullptr;
+        hipError_t ie = hipGraphInstantiate(&exec, g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (ie != hipSuccess) { set_error("hipGraphInstantiate failed: %s", hipGetErrorString(ie)); return ICZ_ERR_HIP; }
+        if (graphs.size() >= 16) {      // evict the least recently used entry
+            size_t lru = 0;
+            for (size_t i = 1; i < graphs.size(); ++i) if (graphs[i].last_use < graphs[lru].last_use) lru = i;
+            (void)hipGraphExecDestroy(graphs[lru].exec);
+            graphs.erase(graphs.begin() + lru);
+        }
+        graphs.push_back({key, exec, tick});
+        ICZ_CHECK_HIP(hipGraphLaunch(exec, st));
+        return ICZ_OK;
+    }
+};
+
 template <class F>
 int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& fn) {
     if (!use_graphs) return fn(st);

@@ -185,3 +185,40 @@ def test_merged_chain_at_32_images_rides_the_64_row_kernel_and_matches_the_oracl
     from test_gpu_round3 import _butd_scst_case
     rep, _ = _butd_scst_case(32, 20, seed=132, options={"merge_small": 32})
     assert max(v[0] for v in rep.values()) < 2e-2, rep
+
+
+# ---- AoA: hipGraph replay of the SCST rollout pair and of the backward pass, shared feature projection -------------------------
+def test_aoa_rollouts_and_backward_under_graph_replay_equal_eager_launches(golden_dir):
+    """AoADetection SCST step (AoA_Model.py:698-753 behind Engine.py:256-270) at full width: the rollout pair and the REINFORCE
+    backward as replayed hipGraphs against eager launches -- same Philox seeds, same inputs: tokens, log-probs, loss and every
+    decoder gradient bit for bit; and the greedy ids / sampled rollout of rollouts() (ONE feature projection for both refiner
+    passes) equal greedy() + sample() (each with its own)."""
+    import os
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, make_aoa_rng
+    B, T = 16, 20
+    torch.manual_seed(7)
+    cap = AoADetection_Captioner(vocab_size=V, num_heads=8, hidden_dim=H, embed_dim=E, device="cuda:0", num_regions=36, enc_dim=D,
+                                 max_batch=B)
+    cap.to("cuda:0")
+    feats = torch.relu(torch.randn(B, 36, D, device="cuda"))
+    out = {}
+    for graphs in (False, True):
+        h = cap._handle()
+        h.enable_graphs(graphs)
+        res = []
+        grads = h.new_grads()
+        rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
+        for rep in range(3):                                       # the first call captures, the others replay
+            ids, seq, lp = h.rollouts(feats, T, make_aoa_rng(500 + rep))
+            loss, _ = h.sample_backward(rew, grads)
+            res.append((ids.clone(), seq.clone(), lp.clone(), loss.clone(), {k: v.clone() for k, v in grads.items()}))
+        out[graphs] = res
+    for a, b in zip(out[False], out[True]):
+        assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) and torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k]), k
+    h = cap._handle()
+    h.enable_graphs(False)
+    ids0 = h.greedy(feats, T)
+    seq0, lp0 = h.sample(feats, T, make_aoa_rng(500))
+    assert torch.equal(ids0, out[False][0][0]) and torch.equal(seq0, out[False][0][1]) and torch.equal(lp0, out[False][0][2])

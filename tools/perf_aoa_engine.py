@@ -22,11 +22,19 @@ def run(n):
     eng.SCST_training_epoch([batches[i % 2] for i in range(n)], opt, None, tqdm_visible=False)
 
 
-run(3)
-torch.cuda.synchronize()
-t0 = time.perf_counter()
+for rnd in range(3):
+    for graphs in (False, True):          # alternating legs in one process (round 5: hipGraph replay of the rollout pair and the backward pass)
+        eng.use_graphs = graphs
+        run(3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(10)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        t2 = time.perf_counter()
+        print("AoA SCST step through the Engine, graphs=%-5s host issue %.2f ms, wall %.2f ms -> %.0f captions/s"
+              % (graphs, (t1 - t0) / 10 * 1e3, (t2 - t0) / 10 * 1e3, B * 10 / (t2 - t0)), flush=True)
+eng.phase_events = []
 run(10)
-t1 = time.perf_counter()
 torch.cuda.synchronize()
-t2 = time.perf_counter()
-print("AoA SCST step through the Engine: host issue %.2f ms, wall %.2f ms -> %.0f captions/s" % ((t1 - t0) / 10 * 1e3, (t2 - t0) / 10 * 1e3, B * 10 / (t2 - t0)))
+print("phases (ms):", {k: round(v, 3) for k, v in eng.phase_times(skip=2).items()})
