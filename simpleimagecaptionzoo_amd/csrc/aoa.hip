@@ -193,44 +193,44 @@ int Aoa::step(const AoaStepIO& s, hipStream_t st) {
     g.seg[0] = {s.emb, P.lstm_w_ih, E, E + Hd, E, nullptr};
     g.seg[1] = {s.u, P.lstm_w_ih + E, Hd, E + Hd, Hd, nullptr};
     g.seg[2] = {s.h_in, P.lstm_w_hh, Hd, Hd, Hd, nullptr};
-    g.M = rows; g.N = 4 * Hd; g.out = ws; g.ldo = 4 * Hd;
+    g.M = rows; g.N = 4 * Hd; g.out = ws; g.ldo = 4 * Hd; g.live = s.live;
     g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "aoa: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
-    LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd};
+    LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.lstm_b_ih, P.lstm_b_hh, s.m_in, s.h_out, s.m_out, s.gates_out, nullptr, rows, Hd, s.live};
     DropCfg off = {0, nullptr, nullptr, 0, 0};
     launch_lstm_point(a, off, st);
-    hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats);
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(rows), dim3(64), 0, st, s.h_out, P.dec.ln_g, P.dec.ln_b, s.qn, rows, Hd, s.ln_stats, s.live);
     const size_t lds = sizeof(float) * (2 * R * (dh + 1) + dh + 128 + 4);
     {   // query projection; when it is split over K its slabs go straight to the attention kernel, which sums them
         GemmArgs qg = {};
         qg.nseg = 1;
         qg.seg[0] = {s.qn, P.dec.q_w, Hd, Hd, Hd, nullptr};
-        qg.M = rows; qg.N = Hd; qg.ldo = Hd;
+        qg.M = rows; qg.N = Hd; qg.ldo = Hd; qg.live = s.live;
         qg.nsplit = gemm_fit_split(GEMM_NT, qg, gemm_pick_split(qg, STEP_WGS), ws_floats);
         if (qg.nsplit == 1) {
             qg.out = s.Qp; qg.bias = P.dec.q_b;
             ICZ_TRY(gemm_f32(GEMM_NT, qg, st));
             hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, s.Qp, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out, R, Hd, NH,
-                               region_rows(), s.d_att);
+                               region_rows(), s.d_att, 1, (size_t)0, (const float*)nullptr, (float*)nullptr, s.live);
         } else {
             qg.out = ws;
             ICZ_TRY(gemm_f32(GEMM_NT, qg, st));
             hipLaunchKernelGGL(aoa_dec_attn_kernel, dim3(rows, NH), dim3(256), lds, st, (const float*)ws, Kd, Vd, s.img_of_row, s.xatt, s.P_out, s.Pd_out,
-                               R, Hd, NH, region_rows(), s.d_att, qg.nsplit, (size_t)rows * Hd, (const float*)P.dec.q_b, s.Qp);
+                               R, Hd, NH, region_rows(), s.d_att, qg.nsplit, (size_t)rows * Hd, (const float*)P.dec.q_b, s.Qp, s.live);
         }
     }
     GemmArgs zg = {};
     zg.nseg = 2;
     zg.seg[0] = {s.xatt, P.dec.aoa_w, Hd, 2 * Hd, Hd, nullptr};
     zg.seg[1] = {s.qn, P.dec.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
-    zg.M = rows; zg.N = 2 * Hd; zg.out = ws; zg.ldo = 2 * Hd;
+    zg.M = rows; zg.N = 2 * Hd; zg.out = ws; zg.ldo = 2 * Hd; zg.live = s.live;
     zg.nsplit = gemm_fit_split(GEMM_NT, zg, gemm_pick_split(zg, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(zg.M, zg.N, zg.nsplit) <= ws_floats, "aoa: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, zg, st));
     hipLaunchKernelGGL(aoa_glu_kernel, dim3(eb), dim3(256), 0, st, ws, zg.nsplit, P.dec.aoa_b, s.z_out, s.ctx_out, s.ctxdrop, rows, Hd, s.d_out,
-                       (const float*)meanf, s.img_of_row, s.u_next, s.d_ctx_next);
-    if (!s.skip_predict) ICZ_TRY(gemm_predict(s.ctxdrop, Hd, w_pred, P.predict_b, rows, dims.V, Vp, s.logits, Vp, ws, ws_floats, s.pred_nsplit, st));
+                       (const float*)meanf, s.img_of_row, s.u_next, s.d_ctx_next, s.live);
+    if (!s.skip_predict) ICZ_TRY(gemm_predict(s.ctxdrop, Hd, w_pred, P.predict_b, rows, dims.V, Vp, s.logits, Vp, ws, ws_floats, s.pred_nsplit, st, s.live));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -255,14 +255,18 @@ static int zero_state(Aoa& a, int rows, hipStream_t st) {
 }
 
 // AoA_Decoder.sample (AoA_Model.py:289-345) behind AoADetection_Captioner.sampler (:698-714)
-int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj) {
+// scst = true (the baseline of an SCST step, rollouts_impl): once EVERY row has emitted <end> the kernels of the remaining steps return
+// at entry and their ids are 0 -- nothing behind a row's <end> reaches the reward (Utils.py:354); icz_aoa_greedy never does this
+int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj, bool scst) {
     ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && T > 0, "aoa greedy: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     use_bank(0);
     ICZ_TRY(refine(feats, B, false, st, proj));
     ICZ_TRY(zero_state(*this, B, st));
-    hipLaunchKernelGGL(fill_i64_kernel, dim3(cdiv(B, 256)), dim3(256), 0, st, it, (int64_t)1, B);
+    int* const gn = (scst && early_out && gnunf && tcap_T >= T && tcap_B >= B) ? gnunf : nullptr;
+    hipLaunchKernelGGL(greedy_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, it, B, gn, T);
     int cur = 0;
+    bool track = false;
     for (int t = 0; t < T; ++t) {
         AoaStepIO s = scratch_io(*this, B, nullptr, cur);
         s.emb_ready = t > 0;
@@ -270,10 +274,13 @@ int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t 
         if (t + 1 < T) { s.u_next = u; s.d_ctx_next = s.d_ctx; }
         int pns = 1;
         s.pred_nsplit = &pns;
+        if (track && t > 0) s.live = gn + (t - 1);
         ICZ_TRY(step(s, st));
+        if (t == 0) track = gn && pns > 1;       // the one-launch select keeps the count (the two-kernel argmax of <= 32 rows does not)
         if (pns > 1)         // 33 - 64 rows: slabs of the vocabulary projection -> token + next embedding in one launch
             hipLaunchKernelGGL(greedy_select_kernel, dim3(B), dim3(1024), 0, st, (const float*)ws, dims.V, Vp, pns, (size_t)B * Vp,
-                               (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, T, t, 1);
+                               (const float*)P.predict_b, P.embed_weight, dims.E, emb, it, ids_out, T, t, 1,
+                               track ? gunf : (uint8_t*)nullptr, track ? gn : (int*)nullptr);
         else {
             hipLaunchKernelGGL(argmax_part_kernel, dim3(B, ARGMAX_PARTS), dim3(256), 0, st, logits, dims.V, Vp, ARGMAX_PARTS, amax_val, amax_idx);
             hipLaunchKernelGGL(embed_argmax_kernel, dim3(cdiv(dims.E, 1024), B), dim3(256), 0, st, amax_val, amax_idx, ARGMAX_PARTS,
@@ -381,6 +388,7 @@ int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value) {
     ICZ_REQUIRE(h && name, "icz_aoa_set_option: null argument");
     Aoa* n = reinterpret_cast<Aoa*>(h);
     if (strcmp(name, "graphs") == 0) { n->use_graphs = value != 0; return ICZ_OK; }
+    if (strcmp(name, "early_out") == 0) { n->early_out = value != 0; n->gc.clear(); return ICZ_OK; }
     set_error("icz_aoa_set_option: unknown option '%s'", name);
     return ICZ_ERR_INVALID;
 }

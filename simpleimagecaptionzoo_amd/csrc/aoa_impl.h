@@ -33,6 +33,8 @@ struct AoaStepIO {
     DropP d_ctx_next;                // the next step's ctx dropout
     int* pred_nsplit;                // non-null: the caller's consumer sums split-K slabs of the predict GEMM (gemm_predict)
     bool skip_predict;               // teacher-forced XE forward: the vocabulary projection of all time steps is one GEMM after the loop
+    const int* live;                 // rollouts: the count of unfinished rows after the previous step; 0 = every kernel of this step returns at
+                                     // entry (step_dead, icz_common.h: the reference's break, AoA_Model.py:400)
 };
 
 struct Aoa {
@@ -89,6 +91,8 @@ struct Aoa {
           *dVd = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *X2 = nullptr, *dWp = nullptr, *prod = nullptr;
     float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr;
     int32_t* draw = nullptr; uint8_t* unf = nullptr; int* nunf = nullptr; int* pack_idx = nullptr;
+    uint8_t* gunf = nullptr; int* gnunf = nullptr; int* live_rows = nullptr;      // SCST baseline's counters; (steps the sampled rollout ran) x B
+    bool early_out = true, bptt_early_out = false;
     size_t xfloats = 0;
     icz_aoa_rng rng = {};
     int mode = 0, cur_B = 0, cur_T = 0, cur_L = 0, n_tokens = 0;
@@ -139,7 +143,7 @@ struct Aoa {
     int refine(const float* feats, int n_img, bool train, hipStream_t st, const float* proj = nullptr);
     int project(const float* feats, int n_img, float* out, hipStream_t st);
     int step(const AoaStepIO& s, hipStream_t st);
-    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj = nullptr);
+    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj = nullptr, bool scst = false);
     int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
@@ -168,8 +172,10 @@ struct Aoa {
     int xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, float n_tokens_global, hipStream_t st);
     int bptt(const icz_aoa_params& G, hipStream_t st);
     int colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st);
-    int nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* slab_out, size_t cap, int* ns, int target, hipStream_t st);
-    int tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st);
+    int nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* slab_out, size_t cap, int* ns, int target, hipStream_t st,
+           const int* live = nullptr, const int* rows_live = nullptr);
+    int tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st,
+           const int* rows_live = nullptr);
 };
 
 }  // namespace icz

@@ -91,7 +91,8 @@ __global__ __launch_bounds__(256) void relu_drop_kernel(const float* x, float* y
 // Optionally stores (mean, 1/(std+eps)) per row for the backward pass.
 __global__ __launch_bounds__(256) void layer_norm_kernel(const float* __restrict__ x, const float* __restrict__ gain,
                                                          const float* __restrict__ bias, float* __restrict__ y, int rows, int n,
-                                                         float* __restrict__ stats) {
+                                                         float* __restrict__ stats, const int* __restrict__ live = nullptr) {
+    if (step_dead(live)) return;               // a rollout step behind the reference's break (icz_common.h)
     const int lane = threadIdx.x & 63;
     const int row = blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);      // one wave per row
     if (row >= rows) return;
@@ -360,8 +361,9 @@ __global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restri
                                                            float* __restrict__ xatt, float* __restrict__ P_out, float* __restrict__ Pd_out,
                                                            int R, int Hd, int NH, RegionRows rr, DropP dp,
                                                            int qns = 1, size_t q_stride = 0, const float* __restrict__ q_bias = nullptr,
-                                                           float* __restrict__ Qp_store = nullptr) {
+                                                           float* __restrict__ Qp_store = nullptr, const int* __restrict__ live = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm_da[];    // K tile [R][d+1], V tile [R][d+1], q [d], p [128], red [4]
+    if (step_dead(live)) return;               // a rollout step behind the reference's break (icz_common.h)
     const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_da;
@@ -425,7 +427,9 @@ __global__ __launch_bounds__(256) void aoa_dec_attn_kernel(const float* __restri
 __global__ __launch_bounds__(256) void aoa_glu_kernel(const float* __restrict__ zslab, int ns, const float* __restrict__ zbias,
                                                       float* __restrict__ z_out, float* __restrict__ ctx, float* __restrict__ ctxdrop,
                                                       int rows, int Hd, DropP dp, const float* __restrict__ meanf,
-                                                      const int32_t* __restrict__ img_of_row, float* __restrict__ u_next, DropP dp_u) {
+                                                      const int32_t* __restrict__ img_of_row, float* __restrict__ u_next, DropP dp_u,
+                                                      const int* __restrict__ live = nullptr) {
+    if (step_dead(live)) return;               // a rollout step behind the reference's break (icz_common.h)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * Hd) return;
     const size_t row = i / Hd;

@@ -15,7 +15,10 @@ namespace {
 //   z = [a | b], ctx = a * sigmoid(b):  da = dctx * s,  db = dctx * a * s * (1 - s)
 __global__ __launch_bounds__(256) void aoa_glu_bwd_kernel(const float* __restrict__ dCd, DropP d_out, const float* __restrict__ du_next, int ns,
                                                           int rows_next, DropP d_ctx_next, const float* __restrict__ z, float* __restrict__ dz,
-                                                          int rows, int Hd) {
+                                                          int rows, int Hd, const int* __restrict__ live = nullptr,
+                                                          const int* __restrict__ carry_live = nullptr) {
+    if (step_dead(live)) return;               // the step never ran (icz_common.h); its dz rows were zeroed in front of the loop
+    if (step_dead(carry_live)) du_next = nullptr;      // the step behind this one never ran: no carry
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)rows * Hd) return;
     const size_t row = i / Hd;
@@ -41,8 +44,9 @@ __global__ __launch_bounds__(256) void aoa_dec_attn_bwd_kernel(const float* __re
                                                                const float* __restrict__ Pdm, const float* __restrict__ Qp,
                                                                const float* __restrict__ Kd, const float* __restrict__ Vd,
                                                                float* __restrict__ dQp, float* __restrict__ dS_out, float* __restrict__ dx_out, int R, int Hd,
-                                                               int NH, RegionRows rr, float keep_scale) {
+                                                               int NH, RegionRows rr, float keep_scale, const int* __restrict__ live = nullptr) {
     extern __shared__ __attribute__((aligned(16))) float sm_db[];    // K tile, V tile [R][d+1], q [d], dx [d], dS [128], red [4]
+    if (step_dead(live)) return;
     const int row = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int d = Hd / NH, ld = d + 1;
     float* sk = sm_db;
@@ -137,9 +141,11 @@ __global__ __launch_bounds__(256) void aoa_dkv_kernel(const float* __restrict__ 
 //   dxh = dy inv + dstd xh / (std (n-1));  dx = dxh - mean(dxh)
 __global__ __launch_bounds__(256) void aoa_ln_bwd_kernel(const float* __restrict__ dq_a, int ns_a, const float* __restrict__ dq_b, int ns_b, int rows,
                                                          const float* __restrict__ x, const float* __restrict__ stats,
-                                                         const float* __restrict__ gain, float* __restrict__ dq_tot, float* __restrict__ dx, int n) {
+                                                         const float* __restrict__ gain, float* __restrict__ dq_tot, float* __restrict__ dx, int n,
+                                                         const int* __restrict__ live = nullptr) {
     // one workgroup per row; a thread keeps its columns (4 adjacent ones per 1024) in registers between the two passes
     __shared__ float sm_red[4];
+    if (step_dead(live)) return;
     constexpr int NV = 4;                         // n <= 4096, n % 4 == 0 (checked by the host)
     const int row = blockIdx.x, tid = threadIdx.x;
     const float mean = stats[2 * row], inv = stats[2 * row + 1];
@@ -264,6 +270,9 @@ int Aoa::ensure_train(int Bq, int Tq) {
     ICZ_TRY(alloc((void**)&draw, sizeof(int32_t) * TB));
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
+    ICZ_TRY(alloc((void**)&gunf, B));
+    ICZ_TRY(alloc((void**)&gnunf, sizeof(int) * T));
+    ICZ_TRY(alloc((void**)&live_rows, 16));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
     tcap_B = Bq; tcap_T = Tq;
     return ICZ_OK;
@@ -323,8 +332,11 @@ int Aoa::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* 
         if (t + 1 < T) { const AoaStepIO nx = train_io(B, t + 1, true); io.u_next = nx.u; io.d_ctx_next = nx.d_ctx; }
         int pns = 1;
         io.pred_nsplit = &pns;
+        // step t > 0 is dead when step t - 1 left no row unfinished (the reference breaks out of its loop there, AoA_Model.py:400)
+        if (t > 0 && early_out) io.live = nunf + (t - 1);
         ICZ_TRY(step(io, st));
         SampleSelArgs a = {};
+        a.live_rows = live_rows;
         a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
         if (pns > 1) {          // the predict GEMM left split-K slabs in the bank's workspace
             a.logits = ws; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b; a.logits_store = tlogit + slot * Vp;
@@ -375,7 +387,7 @@ int Aoa::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64
     }
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
-    const int sg = greedy(feats, B, T, ids_out, side_st, proj);
+    const int sg = greedy(feats, B, T, ids_out, side_st, proj, true);
     const int ss = sg == ICZ_OK ? sample_impl(feats, B, T, seq_out, logp_out, st, proj) : sg;
     ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));       // always join, also on error (a capture must be closed)
     ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
@@ -388,6 +400,7 @@ int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* lo
     if (msum_global >= 0.f)      // < 0: keep the device value handed over by icz_aoa_set_norm_global
         hipLaunchKernelGGL(set_scalars_kernel, dim3(1), dim3(1), 0, st, (uint64_t*)nullptr, (uint64_t)0, d_msum, msum_global);
     mode = 0;
+    bptt_early_out = true;
     if (!low_st) {          // the side stream of bptt: created here, outside any capture
         ICZ_CHECK_HIP(hipStreamCreateWithFlags(&low_st, hipStreamNonBlocking));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
@@ -490,6 +503,7 @@ int Aoa::xe_backward(float smoothing, const icz_aoa_params* G, float* loss_out, 
     }
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     mode = 0;
+    bptt_early_out = false;
     return bptt(*G, st);
 }
 
@@ -500,9 +514,10 @@ int Aoa::colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t 
 
 // slabs [ns][M][N] = A[M,K] . B[K,N]  (ns == 1: the dense product); `cap` = capacity of slab_out in floats
 int Aoa::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* slab_out, size_t cap, int* ns_out, int target,
-            hipStream_t st) {
+            hipStream_t st, const int* live, const int* rows_live) {
     GemmArgs g = {};
     g.nseg = 1;
+    g.live = live; g.rows_live = rows_live;
     g.seg[0] = {A, Bm, lda, ldb, K, nullptr};
     g.M = M; g.N = N; g.out = slab_out; g.ldo = N;
     g.nsplit = M <= 64 ? gemm_pick_split(g, target, GEMM_NN) : gemm_pick_split_balanced(g, GEMM_NN, cap);
@@ -512,9 +527,11 @@ int Aoa::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int
     return ICZ_OK;
 }
 
-int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st) {
+int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st,
+            const int* rows_live) {
     GemmArgs g = {};
     g.nseg = 1;
+    g.rows_live = rows_live;
     g.seg[0] = {dY, Xm, ldy, ldx, K, nullptr};
     g.M = M; g.N = N; g.out = out; g.ldo = ldo; g.nsplit = 1; g.accumulate = accumulate;
     return gemm_f32(GEMM_TN, g, st);
@@ -526,8 +543,12 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     const int TB = T * B;
     const size_t sH = (size_t)B * Hd;
     int ns = 1;
+    // backward of a sampled rollout: the steps behind the reference's break (AoA_Model.py:400) never ran -- their kernels return at
+    // entry (the buffers the batched GEMMs read are zeroed in front of the loop) and the GEMMs over all (t, b) stop behind the last live step
+    const bool eo = bptt_early_out && early_out;
+    const int* const rl = eo ? live_rows : nullptr;
     // ---- predict layer over all time steps: d(dropped ctx), weight-norm gradients
-    ICZ_TRY(nn(tlogit, Vp, TB, Vp, w_pred, Hd, Hd, X, xfloats, &ns, TARGET_WGS, st));
+    ICZ_TRY(nn(tlogit, Vp, TB, Vp, w_pred, Hd, Hd, X, xfloats, &ns, TARGET_WGS, st, nullptr, rl));
     {
         const size_t MN = (size_t)TB * Hd;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, Hd, (const float*)nullptr, dCd);
@@ -549,7 +570,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork2, 0));
         ps = low_st;
     }
-    const int s_tn = tn(tlogit, Vp, Vp, tcd, Hd, Hd, TB, dWp, Hd, 0, ps);
+    const int s_tn = tn(tlogit, Vp, Vp, tcd, Hd, Hd, TB, dWp, Hd, 0, ps, rl);
     if (s_tn == ICZ_OK) {
         (void)colsum(tlogit, TB, V, Vp, G.predict_b, ps);
         hipLaunchKernelGGL(weight_norm_bwd_kernel, dim3(cdiv(V, 4)), dim3(256), 0, ps, dWp, Hd, P.predict_v, P.predict_g, n_pred, G.predict_v,
@@ -558,7 +579,7 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     if (side) ICZ_CHECK_HIP(hipEventRecord(ev_join2, low_st));
     if (s_tn != ICZ_OK) { if (side) (void)hipStreamWaitEvent(st, ev_join2, 0); return s_tn; }
     if (grad_cb) grad_cb(grad_cb_user, 0);      // predict.* complete in stream order: reduced beside the reverse-time loop
-    if (rows_t[T - 1] < B) {      // ragged batch: rows that are inactive at step t contribute exact zeros to the batched GEMMs
+    if (rows_t[T - 1] < B || eo) {      // ragged batch / steps that never ran: those rows contribute exact zeros to the batched GEMMs
         ICZ_CHECK_HIP(hipMemsetAsync(dZ, 0, sizeof(float) * (size_t)TB * 2 * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dQp, 0, sizeof(float) * (size_t)TB * Hd, st));
         ICZ_CHECK_HIP(hipMemsetAsync(dQn, 0, sizeof(float) * (size_t)TB * Hd, st));
@@ -577,15 +598,17 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         const AoaStepIO io = train_io(bt, t, cur_train);
         const AoaStepIO io_next = train_io(bnext, t + 1 < T ? t + 1 : t, cur_train);
         const unsigned eb = (unsigned)(((size_t)bt * Hd + 255) / 256);
+        const int* const live = (eo && t > 0) ? nunf + (t - 1) : nullptr;
+        const int* const carry_live = (eo && t + 1 < T) ? nunf + t : nullptr;
         hipLaunchKernelGGL(aoa_glu_bwd_kernel, dim3(eb), dim3(256), 0, st, dCd + s0 * Hd, io.d_out, bnext ? (const float*)X : nullptr, nsx, bnext,
-                           io_next.d_ctx, tz + s0 * 2 * Hd, dZ + s0 * 2 * Hd, bt, Hd);
+                           io_next.d_ctx, tz + s0 * 2 * Hd, dZ + s0 * 2 * Hd, bt, Hd, live, carry_live);
         int ns2 = 1, nsq = 1;
-        ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st));
+        ICZ_TRY(nn(dZ + s0 * 2 * Hd, 2 * Hd, bt, 2 * Hd, P.dec.aoa_w, 2 * Hd, 2 * Hd, X2, xfloats, &ns2, STEP_WGS, st, live));
         hipLaunchKernelGGL(aoa_dec_attn_bwd_kernel, dim3(bt, NH), dim3(256), lds, st, X2, ns2, bt, tP + s0 * NH * R, tPd + s0 * NH * R,
-                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, region_rows(), io.d_att.mode ? io.d_att.scale : 1.0f);
-        ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st));
+                           tQp + s0 * Hd, Kd, Vd, dQp + s0 * Hd, tdS + s0 * NH * R, tdX + s0 * Hd, R, Hd, NH, region_rows(), io.d_att.mode ? io.d_att.scale : 1.0f, live);
+        ICZ_TRY(nn(dQp + s0 * Hd, Hd, bt, Hd, P.dec.q_w, Hd, Hd, ws, ws_floats, &nsq, STEP_WGS, st, live));
         hipLaunchKernelGGL(aoa_ln_bwd_kernel, dim3(bt), dim3(256), 0, st, ws, nsq, X2, ns2, bt, th + (s0 + B) * Hd, tstats + s0 * 2,
-                           P.dec.ln_g, dQn + s0 * Hd, dHln, Hd);
+                           P.dec.ln_g, dQn + s0 * Hd, dHln, Hd, live);
         LstmBwdArgs a = {};
         a.dh_a = bnext ? X + Hd : nullptr; a.ns_a = nsx; a.lda_a = 2 * Hd; a.rows_a = bnext;
         a.dh_b = dHln; a.ns_b = 1; a.lda_b = Hd; a.rows_b = bt;
@@ -593,10 +616,10 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         a.gates = tg + s0 * 4 * Hd;
         a.c_prev = tm + s0 * Hd; a.c_cur = tm + (s0 + B) * Hd;
         a.dgates = dG + s0 * 4 * Hd; a.dc_prev = dcb[cur ^ 1];
-        a.rows = bt; a.H = Hd;
+        a.rows = bt; a.H = Hd; a.live = live; a.carry_live = carry_live;
         hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(Hd, 256), bt), dim3(256), 0, st, a, off);
         // [du_t | dh_{t-1}] = dgates_t . [W_ih[:, E:] | W_hh]
-        if (t > 0) ICZ_TRY(nn(dG + s0 * 4 * Hd, 4 * Hd, bt, 4 * Hd, w_rec, 2 * Hd, 2 * Hd, X, xfloats, &nsx, STEP_WGS, st));
+        if (t > 0) ICZ_TRY(nn(dG + s0 * 4 * Hd, 4 * Hd, bt, 4 * Hd, w_rec, 2 * Hd, 2 * Hd, X, xfloats, &nsx, STEP_WGS, st, live));
         bnext = bt;
         cur ^= 1;
     }
@@ -606,23 +629,23 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     if (side) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join2, 0));      // the predict branch has long finished beside the loop
     if (s_loop != ICZ_OK) return s_loop;
     // ---- embedding gradient
-    ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st));
+    ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st, nullptr, rl));
     {
         const size_t MN = (size_t)TB * E;
         hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, X, ns, MN, E, (const float*)nullptr, dEmb);
     }
-    ICZ_CHECK_HIP(embed_grad_launch(st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1));
+    ICZ_CHECK_HIP(embed_grad_launch(st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     // ---- weight gradients: one TN GEMM each over all (t, b) rows
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st));
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st));
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st));
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st, rl));
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st, rl));
+    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st, rl));
     ICZ_TRY(colsum(dG, TB, 4 * Hd, 4 * Hd, G.lstm_b_ih, st));
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lstm_b_hh, G.lstm_b_ih, sizeof(float) * 4 * Hd, hipMemcpyDeviceToDevice, st));
     if (grad_cb) grad_cb(grad_cb_user, 1);      // embed + lstm.*: reduced beside the attention block's weight gradients
-    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st));
-    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st));
+    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st, rl));
+    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st, rl));
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
-    ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st));
+    ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st, rl));
     ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));
     {
         const int tc_fit = (int)(48 * 1024 / (sizeof(float) * 2 * (R + dh))), tc = T < tc_fit ? T : tc_fit;

@@ -222,3 +222,47 @@ def test_aoa_rollouts_and_backward_under_graph_replay_equal_eager_launches(golde
     ids0 = h.greedy(feats, T)
     seq0, lp0 = h.sample(feats, T, make_aoa_rng(500))
     assert torch.equal(ids0, out[False][0][0]) and torch.equal(seq0, out[False][0][1]) and torch.equal(lp0, out[False][0][2])
+
+
+@pytest.mark.parametrize("B,bias", [(4, 4.0), (48, 7.0)])
+def test_aoa_early_out_equals_running_every_step(golden_dir, B, bias):
+    """AoA_Decoder.sample_rl's break (AoA_Model.py:400) on the device: with the steps behind it returning at entry (default) and with
+    every step run as rounds 1 - 4 did (option early_out = 0; that form is pinned by the reference goldens in test_gpu_aoa.py):
+    greedy prefix, sampled ids, log-probs, loss and the decoder gradients agree (the batched GEMMs stop behind the last live step:
+    trailing all-zero rows dropped from the same sums)."""
+    import os
+    from simpleimagecaptionzoo_amd.aoa import AoaHandle, make_aoa_rng
+    g = dict(np.load(os.path.join(golden_dir, "aoa_tiny.npz")))
+    _, Rr, Dd, Hd, Ee, Vv, NH = [int(x) for x in g["dims"]]
+    sd = {k[3:]: v.copy() for k, v in g.items() if k.startswith("sd.")}
+    sd["decoder.predict.bias"][2] = bias
+    params = {k: torch.tensor(np.asarray(v), dtype=torch.float32, device="cuda") for k, v in sd.items()}
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(B)
+    feats = torch.relu(torch.randn(B, Rr, Dd, generator=gen)).cuda()
+    T = 20
+    out = {}
+    for eo in (0, 1):
+        h = AoaHandle(Rr, Dd, Hd, Ee, Vv, NH, B, T)
+        h.bind(params)
+        check = __import__("simpleimagecaptionzoo_amd._lib", fromlist=["check"])
+        check.check(check.lib().icz_aoa_set_option(h._h, b"early_out", eo))
+        ids, seq, lp = h.rollouts(feats, T, make_aoa_rng(77))
+        grads = h.new_grads()
+        for v in grads.values():
+            v.fill_(float("nan"))
+        rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
+        loss, _ = h.sample_backward(rew, grads)
+        out[eo] = (ids.cpu().numpy(), seq.cpu().numpy(), lp.cpu().numpy(), loss.item(), {k: v.cpu().numpy() for k, v in grads.items()})
+        h.close()
+    a, b = out[1], out[0]
+    assert (b[1][:, -1] == 0).all() and (b[1][:, 0] != 0).any()          # every sampled row ended before the last step
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]
+    for r in range(B):
+        e = np.nonzero(b[0][r] == 2)[0]
+        n = e[0] + 1 if e.size else T
+        assert np.array_equal(a[0][r, :n], b[0][r, :n]), r
+    for k in a[4]:
+        assert np.isfinite(a[4][k]).all(), k
+        scale = float(np.abs(b[4][k]).max()) + 1e-12
+        assert float(np.abs(a[4][k] - b[4][k]).max()) <= 1e-5 * scale, (k, float(np.abs(a[4][k] - b[4][k]).max()), scale)
