@@ -198,6 +198,10 @@ int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* capti
 int icz_nic_xe_backward(icz_nic_t* h, float smoothing, const icz_nic_params* grads, float* dfeatures_out, float* loss_out,
                         float n_tokens_global, void* stream);
 int icz_nic_set_norm_global(icz_nic_t* h, const float* norm_dev, void* stream);
+/* Option "early_out" (default 1; also icz_butd_set_option / icz_aoa_set_option): the kernels of the rollout / BPTT steps behind
+ * sample_rl's break (NIC_Model.py:150: every row has finished) return at entry; 0 = run them as rounds 1 - 4 did (A/B switch: the
+ * results are the same). */
+int icz_nic_set_option(icz_nic_t* h, const char* name, int32_t value);
 /* Scheduled sampling for the following icz_nic_xe_forward calls (NIC_Model.py:77-89): see icz_butd_set_scheduled_sampling. */
 int icz_nic_set_scheduled_sampling(icz_nic_t* h, float ss_prob, const float* gate_uniforms, const float* draw_uniforms);
 /* DecoderRNN.beam_search_sample, NIC_Model.py:153-212 (batched over images) */

@@ -154,6 +154,7 @@ def lib():
         "icz_aoa_refresh_weights": (C.c_int, [vp, vp]),
         "icz_aoa_set_regions": (C.c_int, [vp, i32, vp, vp, i32]),
         "icz_aoa_set_option": (C.c_int, [vp, C.c_char_p, i32]),
+        "icz_nic_set_option": (C.c_int, [vp, C.c_char_p, i32]),
         "icz_aoa_refine": (C.c_int, [vp, vp, i32, vp, vp]),
         "icz_aoa_greedy": (C.c_int, [vp, vp, i32, i32, vp, vp]),
         "icz_aoa_beam_search": (C.c_int, [vp, vp, i32, i32, i32, vp, vp, vp]),

@@ -97,7 +97,9 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* __restric
 // ---------------------------------------------------------------------------------------------------------
 // Embedding -> ReLU -> Dropout (:77-81):  emb[row,:] = relu(E[it[row],:]) * keep * 2
 __global__ __launch_bounds__(256) void embed_kernel(const float* __restrict__ table, const int64_t* __restrict__ it,
-                                                    float* __restrict__ emb, int rows, int E, DropCfg dc, int relu = 1) {
+                                                    float* __restrict__ emb, int rows, int E, DropCfg dc, int relu = 1,
+                                                    const int* __restrict__ live = nullptr) {
+    if (step_dead(live)) return;               // a rollout step behind the reference's break (icz_common.h)
     const int row = blockIdx.y;
     const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
     if (e >= E) return;

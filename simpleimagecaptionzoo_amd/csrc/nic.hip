@@ -58,7 +58,9 @@ struct Nic {
     int refresh(hipStream_t st);
     int image_step(const float* feats, int rows, float* h_out, float* c_out, float* gates_out, hipStream_t st);
     int token_step(int rows, const int64_t* tokens, bool emb_ready, const float* h_in, const float* c_in, float* h_out, float* c_out,
-                   float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit = nullptr);
+                   float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit = nullptr,
+                   const int* live = nullptr);
+    bool early_out = true, bptt_early_out = false;      // rollout / BPTT steps behind sample_rl's break (NIC_Model.py:150) return at entry
     int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st);
     int ensure_train(int B, int T);
     int sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
@@ -68,7 +70,8 @@ struct Nic {
     int xe_backward(float smoothing, const icz_nic_params* G, float* dfeats, float* loss_out, float n_tokens_global, hipStream_t st);
     int bptt(const icz_nic_params& G, float* dfeats, hipStream_t st);
     int colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t st);
-    int nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* out, int* ns, int target, hipStream_t st);
+    int nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* out, int* ns, int target, hipStream_t st,
+           const int* live = nullptr);
     int tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st);
     int beam_search(const float* feats, int n_img, int k, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
 };
@@ -126,22 +129,25 @@ int Nic::image_step(const float* feats, int rows, float* h_out, float* c_out, fl
 }
 
 // embed -> LSTMCell -> predict(dropout(h))   (NIC_Model.py:112-114)
+// live: step_dead (icz_common.h) -- every kernel of a rollout step behind the reference's break returns at entry
 int Nic::token_step(int rows, const int64_t* tokens, bool emb_ready, const float* h_in, const float* c_in, float* h_out, float* c_out,
-                    float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit) {
+                    float* emb_out, float* gates_out, float* hdrop_out, float* logits_out, DropCfg drop_out, hipStream_t st, int* pred_nsplit,
+                    const int* live) {
     const int H = dims.H, E = dims.E, V = dims.V;
     DropCfg off = {0, nullptr, nullptr, 0, 0};
-    if (!emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, tokens, emb_out, rows, E, off, 0);
+    if (!emb_ready) hipLaunchKernelGGL(embed_kernel, dim3(cdiv(E, 1024), rows), dim3(256), 0, st, P.embed_weight, tokens, emb_out, rows, E, off, 0, live);
     GemmArgs g = {};
     g.nseg = 2;
+    g.live = live;
     g.seg[0] = {emb_out, P.w_ih, E, E, E, nullptr};
     g.seg[1] = {h_in, P.w_hh, H, H, H, nullptr};
     g.M = rows; g.N = 4 * H; g.out = ws; g.ldo = 4 * H;
     g.nsplit = gemm_fit_split(GEMM_NT, g, gemm_pick_split(g, STEP_WGS), ws_floats);
     ICZ_REQUIRE(gemm_slab_floats(g.M, g.N, g.nsplit) <= ws_floats, "nic: workspace too small");
     ICZ_TRY(gemm_f32(GEMM_NT, g, st));
-    LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, c_in, h_out, c_out, gates_out, hdrop_out, rows, H};
+    LstmPointArgs a = {ws, g.nsplit, nullptr, nullptr, P.b_ih, P.b_hh, c_in, h_out, c_out, gates_out, hdrop_out, rows, H, live};
     launch_lstm_point(a, drop_out, st);
-    ICZ_TRY(gemm_predict(hdrop_out, H, w_pred, P.predict_b, rows, V, Vp, logits_out, Vp, ws, ws_floats, pred_nsplit, st));
+    ICZ_TRY(gemm_predict(hdrop_out, H, w_pred, P.predict_b, rows, V, Vp, logits_out, Vp, ws, ws_floats, pred_nsplit, st, live));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -241,7 +247,7 @@ int Nic::sample(const float* feats, int B, int T, const icz_rng* r, int64_t* seq
         int pns = 1;
         ICZ_TRY(token_step(B, tok + slot, false, th + (slot + B) * H, tc + (slot + B) * H, th + (slot + 2 * B) * H, tc + (slot + 2 * B) * H,
                            temb + slot * E, tg + (slot + B) * 4 * H, thd + slot * H, tlogit + slot * Vp,
-                           nic_drop(d_seed, true, rng.out_mask, sH, t), st, &pns));
+                           nic_drop(d_seed, true, rng.out_mask, sH, t), st, &pns, (t > 0 && early_out) ? nunf + (t - 1) : nullptr));
         SampleSelArgs a = {};
         a.logits = tlogit + slot * Vp; a.V = dims.V; a.ldl = Vp;
         if (pns > 1) { a.logits = ws; a.ns = pns; a.slab_stride = (size_t)B * Vp; a.bias = P.predict_b; a.logits_store = tlogit + slot * Vp; }
@@ -265,6 +271,7 @@ int Nic::sample_backward(const float* reward, const icz_nic_params* G, float* df
     hipLaunchKernelGGL(reinforce_loss_kernel, dim3(1), dim3(256), 0, st, cur_logp, cur_seq, reward, B, T, (const float*)d_msum, coef, loss_out, msum_out);
     hipLaunchKernelGGL(reinforce_dlogits_kernel, dim3(cdiv(Vp, 256), T * B), dim3(256), 0, st, tlogit, dims.V, Vp, draw, lse, coef, B, T);
     mode = 0;
+    bptt_early_out = true;
     return bptt(*G, dfeats, st);
 }
 
@@ -347,6 +354,7 @@ int Nic::xe_backward(float smoothing, const icz_nic_params* G, float* dfeats, fl
     }
     if (loss_out) hipLaunchKernelGGL(sum_scale_kernel, dim3(1), dim3(256), 0, st, loss_rows, T * B, 1.0f / n, n_dev, loss_out);
     mode = 0;
+    bptt_early_out = false;
     return bptt(*G, dfeats, st);
 }
 
@@ -356,9 +364,11 @@ int Nic::colsum(const float* Xm, int K, int N, int ldx, float* out, hipStream_t 
 }
 
 // out (dense [M,N]) = A[M,K] . B[K,N]; split-K slabs go to `ws`/`X` and are reduced into `out` unless ns is requested
-int Nic::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* out, int* ns_out, int target, hipStream_t st) {
+int Nic::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int N, float* out, int* ns_out, int target, hipStream_t st,
+            const int* live) {
     GemmArgs g = {};
     g.nseg = 1;
+    g.live = live;
     g.seg[0] = {A, Bm, lda, ldb, K, nullptr};
     g.M = M; g.N = N; g.out = out; g.ldo = N;
     g.nsplit = M <= 64 ? gemm_pick_split(g, target, GEMM_NN) : gemm_pick_split_balanced(g, GEMM_NN, ns_out ? xfloats : ws_floats);
@@ -409,9 +419,13 @@ int Nic::bptt(const icz_nic_params& G, float* dfeats, hipStream_t st) {
         a.c_prev = tc + slot * H; a.c_cur = tc + (slot + B) * H;
         a.dgates = dG + slot * 4 * H; a.dc_prev = dcb[cur ^ 1];
         a.rows = bt; a.H = H;
+        // backward of a sampled rollout: a step behind the reference's break (NIC_Model.py:150) never ran -- zero d gates, no carry
+        const bool eo = bptt_early_out && early_out;
+        const int* const live = (eo && t > 0) ? nunf + (t - 1) : nullptr;
+        a.live = live; a.carry_live = (eo && t >= 0 && t + 1 < T) ? nunf + t : nullptr;
         DropCfg d = t >= 0 ? nic_drop(d_seed, cur_train, rng.out_mask, sH, t) : off;
         hipLaunchKernelGGL(lstm_bwd_point_kernel, dim3(cdiv(H, 256), bt), dim3(256), 0, st, a, d);
-        if (t >= 0) ICZ_TRY(nn(dG + slot * 4 * H, 4 * H, bt, 4 * H, P.w_hh, H, H, X, &nsx, STEP_WGS, st));   // d h_{t-1}
+        if (t >= 0) ICZ_TRY(nn(dG + slot * 4 * H, 4 * H, bt, 4 * H, P.w_hh, H, H, X, &nsx, STEP_WGS, st, live));   // d h_{t-1}
         bnext = bt;
         cur ^= 1;
     }
@@ -541,6 +555,12 @@ int icz_nic_xe_forward(icz_nic_t* h, const float* features, const int64_t* capti
                        const icz_rng* rng, int32_t train, float* packed_logits_out, void* stream) {
     ICZ_REQUIRE(h, "null handle");
     return reinterpret_cast<Nic*>(h)->xe_forward(features, captions, B, L, lengths_host, rng, train, packed_logits_out, (hipStream_t)stream);
+}
+int icz_nic_set_option(icz_nic_t* h, const char* name, int32_t value) {
+    ICZ_REQUIRE(h && name, "icz_nic_set_option: null argument");
+    if (strcmp(name, "early_out") == 0) { reinterpret_cast<Nic*>(h)->early_out = value != 0; return ICZ_OK; }
+    set_error("icz_nic_set_option: unknown option '%s'", name);
+    return ICZ_ERR_INVALID;
 }
 int icz_nic_set_norm_global(icz_nic_t* h, const float* norm_dev, void* stream) {
     ICZ_REQUIRE(h && norm_dev, "icz_nic_set_norm_global: null argument");

@@ -266,3 +266,41 @@ def test_aoa_early_out_equals_running_every_step(golden_dir, B, bias):
         assert np.isfinite(a[4][k]).all(), k
         scale = float(np.abs(b[4][k]).max()) + 1e-12
         assert float(np.abs(a[4][k] - b[4][k]).max()) <= 1e-5 * scale, (k, float(np.abs(a[4][k] - b[4][k]).max()), scale)
+
+
+@pytest.mark.parametrize("B", [5, 40])
+def test_nic_early_out_equals_running_every_step(B):
+    """NIC DecoderRNN.sample_rl's break (NIC_Model.py:150) on the device, against every step run (option early_out = 0, the form the
+    reference goldens in test_gpu_nic.py pin): sampled ids, log-probs, loss, decoder gradients and the gradient w.r.t. the image
+    embedding agree."""
+    from simpleimagecaptionzoo_amd._lib import check, lib
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.nic import NicHandle
+    from simpleimagecaptionzoo_amd.synth import random_nic_params
+    E_, H_, V_, T = 512, 512, 2543, 20
+    params = random_nic_params(E_, H_, V_, "cuda", seed=9)
+    params["predict.weight_g"][2] = 0.0
+    params["predict.bias"][2] = 8.0
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(B)
+    feats = torch.randn(B, E_, generator=gen).cuda()
+    out = {}
+    for eo in (0, 1):
+        h = NicHandle(E_, H_, V_, B, T)
+        h.bind(params)
+        check(lib().icz_nic_set_option(h._h, b"early_out", eo))
+        seq, lp = h.sample(feats, T, make_rng(31))
+        grads = h.new_grads()
+        rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
+        res = h.sample_backward(rew, grads, want_dfeats=True)
+        out[eo] = (seq.cpu().numpy(), lp.cpu().numpy(), res[0].item(), {k: v.cpu().numpy() for k, v in grads.items()},
+                   [res[1].cpu().numpy(), res[2].cpu().numpy()])
+        h.close()
+    a, b = out[1], out[0]
+    assert (b[0][:, -1] == 0).all() and (b[0][:, 0] != 0).any()          # every row ended before the last step
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    for k in a[3]:
+        scale = float(np.abs(b[3][k]).max()) + 1e-12
+        assert np.isfinite(a[3][k]).all() and float(np.abs(a[3][k] - b[3][k]).max()) <= 1e-5 * scale, k
+    for x, y in zip(a[4], b[4]):
+        assert np.allclose(x, y, rtol=0, atol=1e-5 * (float(np.abs(y).max()) + 1e-12))
