@@ -66,6 +66,7 @@ int Aoa::init(const icz_aoa_dims& d) {
     ICZ_TRY(alloc((void**)&amax_idx, sizeof(int) * rows * ARGMAX_PARTS));
     ICZ_TRY(alloc((void**)&d_seed, 16));
     ICZ_TRY(alloc((void**)&d_msum, 16));
+    ICZ_CHECK_HIP(hipDeviceSynchronize());      // alloc() zero-fills on the NULL stream; callers use non-blocking streams (see ensure_train)
     return ICZ_OK;
 }
 
@@ -133,7 +134,10 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st, const
     const float* xin = feats;
     if (lens && !proj) {      // 'adaptive' features: the refiner runs on the valid rows only (packed)
         if (!bank[0].featp)
+        {
             for (int b = 0; b < 2; ++b) ICZ_TRY(alloc((void**)&bank[b].featp, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.D));
+            ICZ_CHECK_HIP(hipDeviceSynchronize());      // alloc() zero-fills on the NULL stream (see ensure_train)
+        }
         float* featp = bank[cur_bank].featp;
         hipLaunchKernelGGL(aoa_offsets_kernel, dim3(1), dim3(256), 0, st, lens, n_img, R, off, rowmap);
         const size_t n4 = (size_t)rows * (dims.D / 4);
@@ -316,6 +320,7 @@ int Aoa::beam_search(const float* feats, int n_img, int kb, int max_steps, float
         ICZ_TRY(alloc((void**)&bm.cand_val, sizeof(float) * R_ * BEAM_MAX_K));
         ICZ_TRY(alloc((void**)&bm.cand_idx, sizeof(int) * R_ * BEAM_MAX_K));
         ICZ_CHECK_HIP(hipHostMalloc((void**)&bm.n_live_host, sizeof(int) * 4, 0));
+        ICZ_CHECK_HIP(hipDeviceSynchronize());      // alloc() zero-fills on the NULL stream (see ensure_train)
         bm.cap_rows = (int)R_;
         bm.cap_L = (int)L_;
     }

@@ -274,6 +274,10 @@ int Aoa::ensure_train(int Bq, int Tq) {
     ICZ_TRY(alloc((void**)&gnunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&live_rows, 16));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
+    // The hipMemset calls above run on the NULL stream; callers enqueue on NON-BLOCKING streams (torch's), which are not ordered behind
+    // it: without this, a kernel of the first call after a (re)allocation could run BEFORE the zero-fill of its buffer and then be
+    // wiped by it (round 5: sample_init_kernel's unfinished flags, seen as an all-zero rollout in 1 of 3 five-rank runs).
+    ICZ_CHECK_HIP(hipDeviceSynchronize());
     tcap_B = Bq; tcap_T = Tq;
     return ICZ_OK;
 }
@@ -372,7 +376,10 @@ int Aoa::rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join, hipEventDisableTiming));
     }
     ICZ_TRY(sample_prelude(feats, B, T, r, seq_out, logp_out, st));
-    if (!lens && !proj_shared) ICZ_TRY(alloc((void**)&proj_shared, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.Hd));
+    if (!lens && !proj_shared) {
+        ICZ_TRY(alloc((void**)&proj_shared, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.Hd));
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+    }
     if (!use_graphs || lens || aoa_explicit_rng(rng)) return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, st);
     const std::vector<uintptr_t> key = {1, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)T, (uintptr_t)cur_R, (uintptr_t)ids_out, (uintptr_t)seq_out,
                                         (uintptr_t)logp_out};

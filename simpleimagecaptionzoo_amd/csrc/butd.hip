@@ -75,6 +75,10 @@ int Butd::init(const icz_butd_dims& d) {
         if (need > ws_floats) ws_floats = need;
     }
     ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
+    // defaults of the options "early_out" / "merge_small" from the environment (A/B runs of whole programs; icz_butd_set_option overrides)
+    ICZ_CHECK_HIP(hipDeviceSynchronize());      // the zero-fills above ran on the NULL stream; callers use non-blocking streams (see ensure_train)
+    if (const char* e = getenv("ICZ_EARLY_OUT")) early_out = atoi(e) != 0;
+    if (const char* e = getenv("ICZ_MERGE_SMALL")) { const int n = atoi(e); if (n >= 0 && n <= 32) merge_small = n; }
     return ICZ_OK;
 }
 

@@ -104,6 +104,10 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.scalars_i, sizeof(int) * 2 * T));
     tb.scalars_i_cap = 2 * T;
     (void)V;
+    // The hipMemset calls above run on the NULL stream; callers enqueue on NON-BLOCKING streams (torch's), which are not ordered behind
+    // it: without this, a kernel of the first call after a (re)allocation could run BEFORE the zero-fill of its buffer and then be
+    // wiped by it (round 5: sample_init_kernel's unfinished flags, seen as an all-zero rollout in 1 of 3 five-rank runs).
+    ICZ_CHECK_HIP(hipDeviceSynchronize());
     tb.B = B;
     tb.T = T;
     return ICZ_OK;

@@ -101,6 +101,7 @@ int Nic::init(const icz_nic_dims& d) {
         if (need > ws_floats) ws_floats = need;
     }
     ICZ_TRY(alloc((void**)&ws, sizeof(float) * ws_floats));
+    ICZ_CHECK_HIP(hipDeviceSynchronize());      // alloc() zero-fills on the NULL stream; callers use non-blocking streams (see ensure_train)
     return ICZ_OK;
 }
 
@@ -215,6 +216,10 @@ int Nic::ensure_train(int Bq, int Tq) {
     ICZ_TRY(alloc((void**)&unf, B));
     ICZ_TRY(alloc((void**)&nunf, sizeof(int) * T));
     ICZ_TRY(alloc((void**)&pack_idx, sizeof(int) * 2 * T));
+    // The hipMemset calls above run on the NULL stream; callers enqueue on NON-BLOCKING streams (torch's), which are not ordered behind
+    // it: without this, a kernel of the first call after a (re)allocation could run BEFORE the zero-fill of its buffer and then be
+    // wiped by it (round 5: sample_init_kernel's unfinished flags, seen as an all-zero rollout in 1 of 3 five-rank runs).
+    ICZ_CHECK_HIP(hipDeviceSynchronize());
     tcap_B = Bq; tcap_T = Tq;
     return ICZ_OK;
 }
@@ -467,6 +472,7 @@ int Nic::beam_search(const float* feats, int n_img, int k, int max_steps, float*
         ICZ_TRY(alloc((void**)&bm.cand_idx, sizeof(int) * R_ * BEAM_MAX_K));
         ICZ_TRY(alloc((void**)&bm.feat_rows, sizeof(float) * R_ * dims.E));
         ICZ_CHECK_HIP(hipHostMalloc((void**)&bm.n_live_host, sizeof(int) * 4, 0));
+        ICZ_CHECK_HIP(hipDeviceSynchronize());      // alloc() zero-fills on the NULL stream (see ensure_train)
         bm.cap_rows = (int)R_;
         bm.cap_L = (int)L_;
     }
