@@ -338,3 +338,23 @@ def test_library_tokeniser_equals_str_split_and_falls_back_for_non_ascii():
     assert ck._word_id("newword") == ck._word_id("newword") >= 120
     k = ck.cook_images([["newword"]])[0][1]
     assert k[0, 0] == ck._word_id("newword")
+
+
+def test_bench_launcher_reports_dead_ranks_instead_of_hanging():
+    """`python bench.py --gpus 2` with no launcher on a box without a GPU: both child ranks die at once (no device); the parent
+    must not wait for a rendezvous -- it polls its children, collects their output, prints every rank's tail and exits non-zero
+    within seconds, with no JSON line on stdout (bench.py: spawn_ranks)."""
+    import subprocess
+    import sys
+    import time
+    if __import__("torch").cuda.is_available():
+        pytest.skip("needs a box without a GPU (the GPU variant is tests/test_gpu_round3.py::test_bench_launcher_kills_the_other_ranks_when_one_dies)")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["ICZ_BENCH_RANK_TIMEOUT"] = "120"
+    t0 = time.time()
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--headline-only"],
+                       env=env, capture_output=True, text=True, timeout=300, cwd=root)
+    assert r.returncode != 0 and time.time() - t0 < 200
+    assert "rank exit codes" in r.stderr and "---- rank 0" in r.stderr and "---- rank 1" in r.stderr and "No HIP GPUs" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
