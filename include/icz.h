@@ -68,7 +68,15 @@ int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
 /* Options.  "graphs" = 1: greedy / sample / sample_backward are captured into hipGraphs on first use and replayed
  * afterwards; the cache is keyed by every pointer and size in the call, so enable it only when buffers are reused.
  * "concurrent" = 0: independent chains (greedy vs sampled rollout, predict gradients vs BPTT) run on ONE stream instead
- * of side streams (default 1); used by bench.py to time single kernels with events. */
+ * of side streams (default 1); used by bench.py to time single kernels with events.
+ * "early_out" (default 1, ICZ_EARLY_OUT): DecoderRNN.sample_rl breaks out of its loop once no row is unfinished
+ * (BUTD_Model.py:233); on the device every kernel of a rollout step behind that point -- and of its BPTT step -- returns at entry
+ * (a per-step count of unfinished rows in device memory, written by the token-choice kernel), the GEMMs over all (t, b) rows stop
+ * there, and the greedy baseline of icz_butd_scst_rollouts stops once EVERY row has emitted <end>.  0 = run every step as rounds
+ * 1 - 4 did: the same results, an A/B switch.
+ * "merge_small" = n (default 8, 0..32, ICZ_MERGE_SMALL): icz_butd_scst_rollouts of <= n images runs the greedy baseline and the
+ * sampled rollout as ONE chain of 2 B decoder rows (evaluation-mode rows in front: per-row dropout / argmax-vs-multinomial in the
+ * kernels), so that the weights are streamed once per step pair; same tokens, log-probs, loss as the two chains. */
 int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
 /* Data-parallel overlap hook (no reference counterpart: the reference is single-process).  While a backward call is
  * being enqueued, `cb(user, stage)` is invoked each time a group of gradient tensors is complete in stream order:
@@ -111,6 +119,8 @@ int icz_butd_sample(icz_butd_t* h, const float* feats, int32_t B, int32_t max_le
 /* Both rollouts of one SCST step (Engine.py:258-262: greedy baseline in eval mode + sampled rollout in train mode)
  * in one call; the two decode chains share the per-image prologue and run concurrently on two streams.  Results are
  * identical to icz_butd_greedy + icz_butd_sample. */
+/* (greedy_ids_out: the reference's greedy ids up to and including every row's first <end> -- all the reward reads, Utils.py:354;
+ * columns behind the step at which the LAST row emitted it are 0, see option "early_out".) */
 int icz_butd_scst_rollouts(icz_butd_t* h, const float* feats, int32_t B, int32_t max_len, const icz_rng* rng,
                            int64_t* greedy_ids_out, int64_t* seq_out, float* logprobs_out, void* stream);
 
