@@ -91,7 +91,10 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
 int icz_butd_set_mask_sum_global(icz_butd_t* h, const float* mask_sum_global_dev, void* stream);
 typedef void (*icz_grad_ready_cb)(void* user, int32_t stage);
 int icz_butd_set_grad_callback(icz_butd_t* h, icz_grad_ready_cb cb, void* user);
-/* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update. */
+/* Re-materialise w = g * v / ||v|| for the four weight-normed layers; call after every parameter update.  The transposed copies of
+ * the LSTM weights that the per-step dgrad products of BPTT read (117 MB at the BASELINE sizes, 33 us) are NOT rebuilt here but by the
+ * first backward call after it (icz_butd_sample_backward / icz_butd_xe_backward*, in front of their captured graph): evaluation
+ * loops refresh per batch and never need them. */
 int icz_butd_refresh_weights(icz_butd_t* h, void* stream);
 
 /* DecoderRNN.sample (BUTD_Model.py:153-189): greedy decode.
