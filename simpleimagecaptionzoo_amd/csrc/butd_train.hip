@@ -750,17 +750,33 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st, rl));             // h2_{t-1}
+    // (round 5) the three products over all (t, b) share d gates: one launch over the column groups [h2 | emb | h1] (4096 x 3072 at the
+    // BASELINE sizes: 183 us against 3 x 85, gemm_big_x3.hip); shapes it does not take go one by one
+    const GemmColGroup td_groups[3] = {{tb.h2, H, H, G.td_w_ih, ldtd},                       // h2_{t-1}
+                                       {tb.emb, E, E, G.td_w_ih + H + D, ldtd},              // embedding
+                                       {tb.h1, H, H, G.td_w_hh, H}};                         // h1_{t-1}
+    const bool td_grouped = gemm_tn_grouped_fits(4 * H, TB, td_groups, 3);
+    if (td_grouped) ICZ_TRY(gemm_tn_grouped(tb.dGtd, 4 * H, 4 * H, TB, td_groups, 3, rl, st));
+    else ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st, rl));
     hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)Bs * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)Bs * 4 * H, tb.dGsum);
     ICZ_TRY(wgrad(tb.dGsum + (size_t)roff * 4 * H, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));      // mean features
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st, rl));     // embedding
-    ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st, rl));                 // h1_{t-1}
+    if (!td_grouped) {
+        ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st, rl));
+        ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st, rl));
+    }
     }   // phase 1
     if ((phases & 2) && grad_cb && fire_cb) grad_cb(grad_cb_user, 1);
     if (phases & 4) {
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st, rl));             // ctx_t
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st, rl));     // h1_t
-    ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st, rl));                 // h2_{t-1}
+    const GemmColGroup lm_groups[3] = {{tb.ctx, D, D, G.lm_w_ih, ldlm},                      // ctx_t
+                                       {tb.h1 + sH, H, H, G.lm_w_ih + D, ldlm},              // h1_t
+                                       {tb.h2, H, H, G.lm_w_hh, H}};                         // h2_{t-1}
+    if (gemm_tn_grouped_fits(4 * H, TB, lm_groups, 3)) {
+        ICZ_TRY(gemm_tn_grouped(tb.dGlm, 4 * H, 4 * H, TB, lm_groups, 3, rl, st));            // 4096 x 4096: 227 us against 123 + 2 x 85
+    } else {
+        ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.ctx, D, D, TB, G.lm_w_ih, ldlm, st, rl));
+        ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h1 + sH, H, H, TB, G.lm_w_ih + D, ldlm, st, rl));
+        ICZ_TRY(wgrad(tb.dGlm, 4 * H, 4 * H, tb.h2, H, H, TB, G.lm_w_hh, H, st, rl));
+    }
     }   // phase 2
     if ((phases & 4) && grad_cb && fire_cb) grad_cb(grad_cb_user, 2);
     if (phases & 8) {

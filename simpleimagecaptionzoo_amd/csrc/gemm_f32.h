@@ -92,11 +92,25 @@ int gemm_resident_x3_pair(const GemmArgs& a, const GemmArgs& b, hipStream_t stre
 int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, int rows, int V, int Vp, float* logits, int ldl,
                  float* ws, size_t ws_cap_floats, int* pred_nsplit, hipStream_t st, const int* live = nullptr);
 
+// gemm_big_x3.hip: the many-row split-precision products on large tiles, one barrier per 16-deep k-step (cfg 1: 256 x 256 / eight waves,
+// 2: 128 x 256, 3: 256 x 128, 4: 128 x 128 three workgroups per CU, 5: 256 x 256 with the two wave halves half a step apart);
+// `a` prepared as for the 128 x 128 kernel (nsplit, chunks_per_split in 128-deep chunks).  gemm_big_cfg picks per shape (0: the
+// 128 x 128 two-barrier kernel); gemm_f32 routes through it.
+int gemm_big_x3(GemmLayout layout, const GemmArgs& a, int cfg, hipStream_t stream);
+int gemm_big_cfg(GemmLayout layout, const GemmArgs& a);
+// Weight gradients that share d y:  out_j[M x cols_j] = dY^T X_j  over K rows, j < ngroups <= 4, as ONE launch (column groups of one
+// output space; cols_j % 256 == 0).  rows_live as in GemmArgs.  _fits: the shape is taken (else the caller issues the products one by one).
+constexpr int GEMM_MAX_COLGROUPS = 4;
+struct GemmColGroup { const float* B; int ldb; int cols; float* out; int ldo; };
+bool gemm_tn_grouped_fits(int M, int K, const GemmColGroup* groups, int ngroups);
+int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* groups, int ngroups, const int* rows_live, hipStream_t stream);
+
 // Library switches, read from the environment once at first use (defaults = the product configuration): ICZ_GEMM_TN_X3,
 // ICZ_GEMM_NN_X3, ICZ_GEMM_NT_X3BIG, ICZ_GEMM_RESIDENT_X3 (0: the fp32-input MFMA kernels -- bench.py's fp32_mfma_gemms leg),
 // ICZ_GEMM_RESIDENT_M128 (0: 65..128 rows go to the 128 x 128-tile kernel instead of the 128-row resident kernel),
-// ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch).
-struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs; unsigned prof_every; };
+// ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch),
+// ICZ_GEMM_BIG (unset / -1: gemm_big_cfg's choice per shape; 0: the 128 x 128 two-barrier kernel everywhere; 1..5: that large-tile configuration everywhere).
+struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs; unsigned prof_every; int big_cfg; };
 const GemmSwitches& gemm_switches();
 
 }  // namespace icz

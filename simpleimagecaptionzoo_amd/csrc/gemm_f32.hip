@@ -1,6 +1,9 @@
 // fp32 MFMA GEMMs (see gemm_f32.h for the tiling rationale).  gfx950 only.
 #include <stdlib.h>
 
+#include <array>
+#include <mutex>
+#include <set>
 #include <vector>
 
 #include "gemm_f32.h"
@@ -927,6 +930,8 @@ const GemmSwitches& gemm_switches() {
         s.resident_x3 = on("ICZ_GEMM_RESIDENT_X3"); s.resident_m128 = on("ICZ_GEMM_RESIDENT_M128"); s.predict_slabs = on("ICZ_PREDICT_SLABS");
         const char* e = getenv("ICZ_PROF_EVERY");
         s.prof_every = e && atoi(e) > 1 ? (unsigned)atoi(e) : 1u;
+        const char* b = getenv("ICZ_GEMM_BIG");
+        s.big_cfg = b ? atoi(b) : -1;
         return s;
     }();
     return sw;
@@ -1025,7 +1030,9 @@ int gemm_pick_split(const GemmArgs& a, int target_wgs, GemmLayout layout) {
 int gemm_pick_split_balanced(const GemmArgs& a, GemmLayout layout, size_t slab_capacity_floats) {
     if (layout == GEMM_NN && nn_x3(a)) {      // 128 x 128 tiles: about two workgroups per CU, at least 8 chunks of 128 per split
         const int tiles = cdiv(a.N, 128) * cdiv(a.M, 128), tot = a.seg[0].K / 128;
-        int s = 512 / (tiles > 0 ? tiles : 1);
+        GemmArgs probe = a;
+        probe.nsplit = 1;
+        int s = (gemm_big_cfg(GEMM_NN, probe) == 4 ? 768 : 512) / (tiles > 0 ? tiles : 1);      // three workgroups per CU there
         if (s > tot / 8) s = tot / 8;
         if (s < 1) s = 1;
         while (s > 1 && (size_t)s * a.M * a.N > slab_capacity_floats) --s;
@@ -1088,6 +1095,19 @@ static int check_args(GemmLayout layout, const GemmArgs& a) {
     return ICZ_OK;
 }
 
+// ICZ_GEMM_LOG=1: every distinct shape that reaches the 128 x 128 / large-tile split-precision kernels, once, on stderr (tuning aid)
+static void log_big_shape(GemmLayout layout, const GemmArgs& a) {
+    static const bool on = [] { const char* e = getenv("ICZ_GEMM_LOG"); return e && atoi(e) > 0; }();
+    if (!on) return;
+    static std::mutex mu;
+    static std::set<std::array<int, 6>> seen;
+    int K = 0;
+    for (int s = 0; s < a.nseg; ++s) K += a.seg[s].K;
+    std::lock_guard<std::mutex> lk(mu);
+    if (seen.insert({(int)layout, a.M, a.N, K, a.nseg, a.nsplit}).second)
+        fprintf(stderr, "[icz gemm] %s M=%d N=%d K=%d nseg=%d nsplit=%d rows_live=%d\n", layout == GEMM_NT ? "nt" : (layout == GEMM_NN ? "nn" : "tn"), a.M, a.N, K, a.nseg, a.nsplit, a.rows_live ? 1 : 0);
+}
+
 int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
     GemmArgs a = a_in;
     ICZ_TRY(check_args(layout, a));
@@ -1107,6 +1127,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
             }
             // chunks_per_split was computed in NT stage units (128 here, the predicate guarantees it) -- the kernel's unit too
             const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), a.nsplit);
+            log_big_shape(layout, a);
+            if (const int bc = gemm_big_cfg(layout, a)) return gemm_big_x3(layout, a, bc, stream);
             if ((int)(g128.x * g128.y * g128.z) > 256) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4, true, true>), g128, block, t3_lds(1), stream, a);
             else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8, true, true>), g128, dim3(512), t3_lds(2), stream, a);
             ICZ_CHECK_HIP(hipGetLastError());
@@ -1151,6 +1173,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
                 attr = true;
             }
             const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), a.nsplit);
+            log_big_shape(layout, a);
+            if (const int bc = gemm_big_cfg(layout, a)) return gemm_big_x3(layout, a, bc, stream);
             if ((int)(g128.x * g128.y * g128.z) > 256) hipLaunchKernelGGL((gemm_tn128_x3_kernel<1, 4, true>), g128, block, t3_lds(1), stream, a);
             else hipLaunchKernelGGL((gemm_tn128_x3_kernel<2, 8, true>), g128, dim3(512), t3_lds(2), stream, a);
         }
@@ -1169,6 +1193,8 @@ int gemm_f32(GemmLayout layout, const GemmArgs& a_in, hipStream_t stream) {
             }
             const dim3 g128(cdiv(a.N, 128), cdiv(a.M, 128), 1);
             const int tiles = (int)(g128.x * g128.y);
+            log_big_shape(layout, a);
+            if (const int bc = x3 ? gemm_big_cfg(layout, a) : 0) return gemm_big_x3(layout, a, bc, stream);
             if (!x3) hipLaunchKernelGGL(gemm_tn128_kernel, g128, block, 0, stream, a);
             // measured (4096 x {1024, 3072, 4096} x 1280, 10112 x 1024 x 1280): more than one round of tiles -> one LDS buffer and
             // two workgroups per CU (251 us / 171 TFLOP/s-equivalent at 4096 x 4096 against 369 us for the fp32 kernel); one
