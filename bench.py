@@ -188,7 +188,7 @@ def secondary(eng, opt, words, device, B):
     # BASELINE config 3's dominant kernel: the 128 x 128 split-precision NT GEMM on the three big products of a beam step at 640
     # rows (TD gates K = 3072, LM gates K = 4096 -- both N = 4096 -- and the vocabulary projection 10112 x 1024)
     out["beam5_b128"]["roofline"] = csv_roofline(
-        "beam5_b128_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
+        "beam5_b128_kernel_stats.csv", NT_BIG_KERNELS,
         "TD gates, LM gates and vocabulary projection of a beam step at 640 rows: 50.8 GFLOP over three launches",
         flops_per_launch=2.0 * 640 * (4096 * 3072 + 4096 * 4096 + 10112 * 1024) / 3.0)
     # BASELINE config 2's: the resident split-precision kernel (forward LSTM gates of the steps with more than 32 active rows, LM-input
@@ -308,7 +308,7 @@ def aoa_scst(words, device, B):
         out["beam5"] = {"captions_per_s": B / bdt, "ms": bdt * 1e3, "batch": B, "steps": 20,
                         "note": "AoADetection beam 5 (refiner + 20 steps at 5 x %d decoder rows), eager launches" % B,
                         "roofline": csv_roofline(
-                            "aoa_beam5_b64_kernel_stats.csv", "gemm_tn128_x3_kernel<1, 4, true, true>",
+                            "aoa_beam5_b64_kernel_stats.csv", NT_BIG_KERNELS,
                             "per decode 13 refiner GEMMs at 2304 rows (projection 2048 -> 1024, six layers of Q/K/V 1024 -> 3072 and AoA linear "
                             "2048 -> 2048) + the LSTM-gate GEMM (320 x 4096 x 3072) of the 19 beam steps at 5 x 64 rows: 356 GFLOP over 32 launches",
                             flops_per_launch=(2.0 * B * R * (2048 * 1024 + 6 * (3072 * 1024 + 2048 * 2048)) + 19 * 2.0 * 5 * B * 4096 * 3072) / 32.0)}
@@ -326,14 +326,19 @@ def aoa_roofline(B, steps_in_profile=13):
         path = _profile_path("aoa_scst_kernel_stats.csv")
         rows = list(csv.DictReader(open(path)))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        k = [r for r in rows if "gemm_tn128_x3_kernel<1, 4, true, true>" in r["Name"]][0]
+        ks = [r for r in rows if any(_name_match(f, r["Name"]) for f in NT_BIG_KERNELS)]
+        k = {"Calls": sum(int(r["Calls"]) for r in ks), "TotalDurationNs": sum(float(r["TotalDurationNs"]) for r in ks)}
         M = B * R
         flops_step = 2.0 * (2.0 * M * 1024 * 2048 + 6 * (2.0 * M * 3072 * 1024 + 2.0 * M * 2048 * 2048))
+        # SCST steps in the profile = launches of the clamp + Adam kernel (one per step); the argument is only the fallback
+        adam = [r for r in rows if "adam_clamp_multi_kernel" in r["Name"]]
+        if adam:
+            steps_in_profile = int(adam[0]["Calls"])
         launches = float(k["Calls"]) / steps_in_profile
-        us = float(k["AverageNs"]) / 1e3
+        us = k["TotalDurationNs"] / k["Calls"] / 1e3
         tf = flops_step / launches / (us * 1e-6) / 1e12
         peak = 2500.0 / 6.0
-        return {"kernel": "gemm_tn128_x3_kernel<1,4,true,true> (refiner GEMMs, split precision)", "bound": "mfma", "achieved": tf,
+        return {"kernel": " + ".join(NT_BIG_KERNELS) + " (refiner GEMMs, split precision)", "bound": "mfma", "achieved": tf,
                 "peak": peak, "unit": "TFLOP/s", "frac": tf / peak, "traffic": None, "avg_launch_us": us, "launches_per_step": launches,
                 "share_of_kernel_time": float(k["TotalDurationNs"]) / tot, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS,
                 "source": "profiles/%s (rocprofv3 --kernel-trace --stats of tools/perf_aoa_engine.py at the "
@@ -366,6 +371,15 @@ def trace_avg_us(kernel):
         return None, None
 
 
+def _name_match(frag, name):
+    """A kernel-name fragment with '*' wildcards against a rocprofv3 kernel name."""
+    import re
+    return re.search(".*".join(re.escape(p) for p in frag.split("*")), name) is not None
+
+
+NT_BIG_KERNELS = ("gemm_tn128_x3_kernel<1, 4, true, true>", "gemm_big_x3_kernel<*true, true>")      # many-row NT products (split precision)
+
+
 def csv_roofline(suffix, kernel, what, flops_per_launch=None, bytes_per_launch=None, mfma_peak=2500.0 / 6.0):
     """Roofline entry of one kernel from a COMMITTED rocprofv3 kernel-stats summary (profiles/), not from this run: average
     launch duration from the trace, algorithmic flops / bytes per launch from the shapes named in `what`."""
@@ -374,10 +388,15 @@ def csv_roofline(suffix, kernel, what, flops_per_launch=None, bytes_per_launch=N
         path = _profile_path(suffix)
         rows = list(csv.DictReader(open(path)))
         tot = sum(float(r["TotalDurationNs"]) for r in rows)
-        k = [r for r in rows if kernel in r["Name"]][0]
-        us = float(k["AverageNs"]) / 1e3
-        out = {"kernel": kernel, "what": what, "avg_launch_us": us, "calls_in_profile": int(k["Calls"]),
-               "share_of_kernel_time": float(k["TotalDurationNs"]) / tot,
+        # `kernel`: one name fragment, or several (the shapes of one entry can sit on two kernels since round 5: the 128 x 128
+        # two-barrier kernel and the large-tile kernel of gemm_big_x3.hip) -- calls and time are summed over all rows that match any
+        frags = [kernel] if isinstance(kernel, str) else list(kernel)
+        ks = [r for r in rows if any(_name_match(f, r["Name"]) for f in frags)]
+        calls = sum(int(r["Calls"]) for r in ks)
+        ktot = sum(float(r["TotalDurationNs"]) for r in ks)
+        us = ktot / calls / 1e3
+        out = {"kernel": kernel if isinstance(kernel, str) else " + ".join(frags), "what": what, "avg_launch_us": us, "calls_in_profile": calls,
+               "share_of_kernel_time": ktot / tot,
                "source": "profiles/%s (rocprofv3 --kernel-trace --stats at the committed code, NOT this run)" % os.path.basename(path)}
         t_mfma = flops_per_launch / (mfma_peak * 1e12) if flops_per_launch else 0.0
         t_hbm = bytes_per_launch / (HBM_PEAK_GBS * 1e9) if bytes_per_launch else 0.0

@@ -381,6 +381,17 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
                  float* C, int32_t ldc, int32_t M, int32_t N, int32_t K, int32_t nsplit, float* workspace,
                  size_t workspace_floats, void* stream);
 size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
+/* Which kernel the many-row split-precision products (>= 128 rows: weight gradients, dgrad over all steps, beam / refiner / XE forward
+ * GEMMs) run on: -1 = chosen per shape (default; the environment's ICZ_GEMM_BIG sets the same switch), 0 = the 128 x 128 two-barrier
+ * kernel everywhere, 1..5 = one large-tile configuration of gemm_big_x3.hip everywhere, -2 = back to the environment's value.
+ * Process-wide; meant for tests and A/B measurements, not for use while other threads launch. */
+int icz_gemm_set_big_cfg(int32_t cfg);
+/* Weight gradients that share d y as ONE launch: out_j[M, cols_j] (row stride ldo_j) = dY[K, M]^T X_j[K, cols_j], j < ngroups <= 4,
+ * cols_j % 256 == 0, M * sum(cols_j) >= 256 tiles of 128 x 128 (else ICZ_ERR: issue them one by one through icz_gemm_f32).
+ * rows_live: optional device count of leading rows of K that matter (rounded up to 32).  What Butd::bptt does for the
+ * LSTM weight gradients (BUTD_Model.py:137-145 under loss.backward(), Engine.py:186,270). */
+int icz_gemm_tn_grouped(const float* dY, int32_t ldy, int32_t M, int32_t K, int32_t ngroups, const float* const* X, const int32_t* ldx,
+                        const int32_t* cols, float* const* out, const int32_t* ldo, const int32_t* rows_live, void* stream);
 /* Live timing of the dominant kernel (the forward GEMMs of a decoder step at 33..64 rows: gemm_resident_x3_kernel, or
  * gemm_nt_kernel<4, ...> with ICZ_GEMM_RESIDENT_X3=0; see icz_prof_select) with HIP events on its launch stream, for bench.py's
  * roofline line.  Between begin and end every launch is bracketed by an event

@@ -264,3 +264,23 @@ def gemm(layout, X, W, bias=None, nsplit=0):
     check(lib().icz_gemm_f32(code, ptr(X), X.stride(0), ptr(W), W.stride(0), ptr(bias), ptr(out), N, M, N, K,
                              nsplit, ptr(ws), ws.numel(), stream_ptr()))
     return out
+
+
+def gemm_set_big_cfg(cfg):
+    """icz_gemm_set_big_cfg: -1 per shape (default), 0 the 128 x 128 two-barrier kernel, 1..5 one large-tile configuration, -2 environment."""
+    check(lib().icz_gemm_set_big_cfg(int(cfg)))
+
+
+def gemm_tn_grouped(dY, Xs, outs=None, rows_live=None):
+    """Test/bench entry for icz_gemm_tn_grouped: out_j = dY[K,M]^T Xs[j][K,cols_j] in one launch.  Returns the list of outputs."""
+    K, M = dY.shape
+    n = len(Xs)
+    if outs is None:
+        outs = [torch.empty(M, x.shape[1], device=dY.device, dtype=torch.float32) for x in Xs]
+    xp = (C.c_void_p * n)(*[x.data_ptr() for x in Xs])
+    op = (C.c_void_p * n)(*[o.data_ptr() for o in outs])
+    ldx = (C.c_int32 * n)(*[x.stride(0) for x in Xs])
+    cols = (C.c_int32 * n)(*[x.shape[1] for x in Xs])
+    ldo = (C.c_int32 * n)(*[o.stride(0) for o in outs])
+    check(lib().icz_gemm_tn_grouped(ptr(dY), dY.stride(0), M, K, n, xp, ldx, cols, op, ldo, ptr(rows_live), stream_ptr()))
+    return outs

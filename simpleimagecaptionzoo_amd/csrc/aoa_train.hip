@@ -643,14 +643,25 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     }
     ICZ_CHECK_HIP(embed_grad_launch(st, tok, TB, dEmb, 1, (size_t)0, temb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     // ---- weight gradients: one TN GEMM each over all (t, b) rows
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st, rl));
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st, rl));
-    ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st, rl));
+    // (round 5) products that share d y go as one launch over column groups where the shape is taken (gemm_big_x3.hip)
+    const GemmColGroup lstm_groups[3] = {{temb, E, E, G.lstm_w_ih, E + Hd}, {tu, Hd, Hd, G.lstm_w_ih + E, E + Hd}, {th, Hd, Hd, G.lstm_w_hh, Hd}};
+    if (gemm_tn_grouped_fits(4 * Hd, TB, lstm_groups, 3)) {
+        ICZ_TRY(gemm_tn_grouped(dG, 4 * Hd, 4 * Hd, TB, lstm_groups, 3, rl, st));
+    } else {
+        ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, temb, E, E, TB, G.lstm_w_ih, E + Hd, 0, st, rl));
+        ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, tu, Hd, Hd, TB, G.lstm_w_ih + E, E + Hd, 0, st, rl));
+        ICZ_TRY(tn(dG, 4 * Hd, 4 * Hd, th, Hd, Hd, TB, G.lstm_w_hh, Hd, 0, st, rl));
+    }
     ICZ_TRY(colsum(dG, TB, 4 * Hd, 4 * Hd, G.lstm_b_ih, st));
     ICZ_CHECK_HIP(hipMemcpyAsync(G.lstm_b_hh, G.lstm_b_ih, sizeof(float) * 4 * Hd, hipMemcpyDeviceToDevice, st));
     if (grad_cb) grad_cb(grad_cb_user, 1);      // embed + lstm.*: reduced beside the attention block's weight gradients
-    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st, rl));
-    ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st, rl));
+    const GemmColGroup aoa_groups[2] = {{txatt, Hd, Hd, G.dec.aoa_w, 2 * Hd}, {tqn, Hd, Hd, G.dec.aoa_w + Hd, 2 * Hd}};
+    if (gemm_tn_grouped_fits(2 * Hd, TB, aoa_groups, 2)) {
+        ICZ_TRY(gemm_tn_grouped(dZ, 2 * Hd, 2 * Hd, TB, aoa_groups, 2, rl, st));
+    } else {
+        ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, txatt, Hd, Hd, TB, G.dec.aoa_w, 2 * Hd, 0, st, rl));
+        ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st, rl));
+    }
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
     ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st, rl));
     ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));

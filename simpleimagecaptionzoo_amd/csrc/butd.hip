@@ -483,5 +483,19 @@ int icz_gemm_f32(int32_t layout, const float* X, int32_t ldx, const float* W, in
     return gemm_f32((GemmLayout)layout, g, st);
 }
 
+int icz_gemm_set_big_cfg(int32_t cfg) {
+    ICZ_REQUIRE(cfg >= -2 && cfg <= 5, "icz_gemm_set_big_cfg: %d", cfg);
+    gemm_set_big_cfg(cfg);
+    return ICZ_OK;
+}
+
+int icz_gemm_tn_grouped(const float* dY, int32_t ldy, int32_t M, int32_t K, int32_t ngroups, const float* const* X, const int32_t* ldx,
+                        const int32_t* cols, float* const* out, const int32_t* ldo, const int32_t* rows_live, void* stream) {
+    ICZ_REQUIRE(ngroups >= 1 && ngroups <= GEMM_MAX_COLGROUPS && X && ldx && cols && out && ldo, "icz_gemm_tn_grouped: bad arguments");
+    GemmColGroup g[GEMM_MAX_COLGROUPS];
+    for (int j = 0; j < ngroups; ++j) g[j] = {X[j], ldx[j], cols[j], out[j], ldo[j]};
+    ICZ_REQUIRE(gemm_tn_grouped_fits(M, K, g, ngroups), "icz_gemm_tn_grouped: shape not taken (M %d, K %d)", M, K);
+    return gemm_tn_grouped(dY, ldy, M, K, g, ngroups, rows_live, (hipStream_t)stream);
+}
 
 }  // extern "C"

@@ -358,7 +358,7 @@ int gemm_big_x3(GemmLayout layout, const GemmArgs& a, int cfg, hipStream_t st) {
 }
 
 bool gemm_tn_grouped_fits(int M, int K, const GemmColGroup* groups, int ngroups) {
-    if (!gemm_switches().tn_x3 || gemm_switches().big_cfg == 0 || ngroups < 1 || ngroups > GEMM_MAX_COLGROUPS || M % 4 || K % 32 || K < 64) return false;
+    if (!gemm_switches().tn_x3 || gemm_big_switch() == 0 || ngroups < 1 || ngroups > GEMM_MAX_COLGROUPS || M % 4 || K % 32 || K < 64) return false;
     int N = 0;
     for (int j = 0; j < ngroups; ++j) {
         if (groups[j].cols <= 0 || groups[j].cols % 256) return false;
@@ -385,7 +385,7 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
     a.seg[0] = {dY, groups[0].B, ldy, ldmax, K, nullptr};
     a.M = M; a.N = N; a.out = groups[0].out; a.ldo = groups[0].ldo; a.nsplit = 1; a.chunks_per_split = cdiv(K, 128);
     a.rows_live = rows_live;
-    const int cfg = gemm_switches().big_cfg > 0 ? gemm_switches().big_cfg : gemm_big_cfg(GEMM_TN, a);
+    const int cfg = gemm_big_cfg(GEMM_TN, a);
     ICZ_TRY(big_check(a, cfg ? cfg : 4));
     return launch_cfg<false, false>(a, cfg ? cfg : 4, cg, st);
 }
@@ -398,7 +398,7 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
 //   NT 1280 x 10112 x 1024: 172 / 139 / 175    NT 2304 x 2048 x 2048: 146 / 139 (2) / 132 (4)   NT 2304 x 1024 x 1024: 47 / 58 (4) / 50 (4)
 //   NT 640 x 4096 x 4096 (beam step): 132 (3) / 142 (5) / 132 (3);  in beam search itself the three-per-CU kernel is 1 - 4 % slower
 int gemm_big_cfg(GemmLayout layout, const GemmArgs& a) {
-    const int sw = gemm_switches().big_cfg;
+    const int sw = gemm_big_switch();
     if (sw >= 0) return sw;
     for (int s = 0; s < a.nseg; ++s)
         if (a.seg[s].K % BX_KS) return 0;

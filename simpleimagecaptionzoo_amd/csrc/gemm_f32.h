@@ -98,6 +98,8 @@ int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, 
 // 128 x 128 two-barrier kernel); gemm_f32 routes through it.
 int gemm_big_x3(GemmLayout layout, const GemmArgs& a, int cfg, hipStream_t stream);
 int gemm_big_cfg(GemmLayout layout, const GemmArgs& a);
+int gemm_big_switch();               // ICZ_GEMM_BIG, or what gemm_set_big_cfg put in its place (-1: per shape, 0: off, 1..5: forced)
+void gemm_set_big_cfg(int cfg);      // -2: back to the environment's value
 // Weight gradients that share d y:  out_j[M x cols_j] = dY^T X_j  over K rows, j < ngroups <= 4, as ONE launch (column groups of one
 // output space; cols_j % 256 == 0).  rows_live as in GemmArgs.  _fits: the shape is taken (else the caller issues the products one by one).
 constexpr int GEMM_MAX_COLGROUPS = 4;

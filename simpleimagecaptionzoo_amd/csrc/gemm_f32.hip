@@ -937,6 +937,11 @@ const GemmSwitches& gemm_switches() {
     return sw;
 }
 
+// runtime override of ICZ_GEMM_BIG (tests sweep the tile configurations in one process); -2 = none
+static int g_big_override = -2;
+void gemm_set_big_cfg(int cfg) { g_big_override = cfg; }
+int gemm_big_switch() { return g_big_override != -2 ? g_big_override : gemm_switches().big_cfg; }
+
 // NT pipeline-stage depth: 128 when every segment's K is a multiple of 128 and the tile is full height (MT = 4)
 static int nt_stage_k(const GemmArgs& a) {
     if (gemm_resident_x3_fits(a)) return 64;

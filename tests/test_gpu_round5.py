@@ -304,3 +304,89 @@ def test_nic_early_out_equals_running_every_step(B):
         assert np.isfinite(a[3][k]).all() and float(np.abs(a[3][k] - b[3][k]).max()) <= 1e-5 * scale, k
     for x, y in zip(a[4], b[4]):
         assert np.allclose(x, y, rtol=0, atol=1e-5 * (float(np.abs(y).max()) + 1e-12))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# Large-tile split-precision GEMM (csrc/gemm_big_x3.hip): every tile configuration against float64 and against the 128 x 128 kernel
+def _gemm_operands(layout, M, N, K, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    if layout == "nt":
+        return torch.randn(M, K, device="cuda", generator=g), torch.randn(N, K, device="cuda", generator=g)
+    if layout == "nn":
+        return torch.randn(M, K, device="cuda", generator=g), torch.randn(K, N, device="cuda", generator=g)
+    return torch.randn(K, M, device="cuda", generator=g), torch.randn(K, N, device="cuda", generator=g)
+
+
+def _gemm_ref64(layout, X, W):
+    X, W = X.double(), W.double()
+    return X @ W.t() if layout == "nt" else (X @ W if layout == "nn" else X.t() @ W)
+
+
+BIG_SHAPES = [("nt", 700, 4100, 1024, 1), ("nt", 700, 4100, 1024, 2), ("nt", 640, 1024, 1024, 4), ("nt", 2304, 1024, 1024, 1),
+              ("nt", 129, 8200, 1152, 3), ("nt", 1280, 10102, 1024, 1),
+              ("nn", 300, 260, 128, 1), ("nn", 1280, 1028, 2176, 4), ("nn", 130, 516, 2176, 1), ("nn", 1280, 1024, 4096, 2),
+              ("tn", 2052, 2060, 96, 1), ("tn", 4096, 1024, 320, 1), ("tn", 2048, 2048, 64, 1), ("tn", 4100, 2044, 304, 1)]
+
+
+@pytest.mark.parametrize("cfg", [1, 2, 3, 4, 5])
+def test_large_tile_gemm_configurations_against_float64_and_the_128_tile_kernel(cfg):
+    """Same arithmetic in the same order per accumulator: for one split-K decomposition every tile configuration returns the bits of
+    gemm_tn128_x3_kernel; all of them within 3e-6 of max|C| of the float64 product (the bound of tests/test_gpu_butd.py)."""
+    from simpleimagecaptionzoo_amd.butd import gemm, gemm_set_big_cfg
+    try:
+        for (lay, M, N, K, ns) in BIG_SHAPES:
+            X, W = _gemm_operands(lay, M, N, K, 17 * M + N + K)
+            gemm_set_big_cfg(0)
+            base = gemm(lay, X, W, None, ns)
+            gemm_set_big_cfg(cfg)
+            out = gemm(lay, X, W, None, ns)
+            ref = _gemm_ref64(lay, X, W)
+            err = ((out.double() - ref).abs().max() / ref.abs().max()).item()
+            assert err < 3e-6, (lay, M, N, K, ns, cfg, err)
+            assert torch.equal(out, base), (lay, M, N, K, ns, cfg, (out - base).abs().max().item())
+    finally:
+        gemm_set_big_cfg(-2)
+
+
+def test_large_tile_gemm_with_bias_and_per_shape_choice():
+    """The routed default (cfg -1) with a bias on the direct path, the shapes of an XE step's vocabulary projection and of the refiner."""
+    from simpleimagecaptionzoo_amd.butd import gemm
+    for (M, N, K) in ((1280, 10102, 1024), (2304, 2048, 2048), (1088, 10102, 1024)):
+        X, W = _gemm_operands("nt", M, N, K, M + N)
+        b = torch.randn(N, device="cuda")
+        out = gemm("nt", X, W, b, 1)
+        ref = X.double() @ W.double().t() + b.double()
+        assert ((out.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+
+
+@pytest.mark.parametrize("cfg", [-1, 1, 4])
+def test_grouped_weight_gradients_equal_the_separate_products(cfg):
+    """icz_gemm_tn_grouped (the LSTM weight gradients of Butd::bptt as one launch over column groups) = the products one by one, bit for
+    bit, into strided outputs (W_ih column blocks and W_hh), also with the row limit of an early-ended rollout."""
+    from simpleimagecaptionzoo_amd.butd import gemm, gemm_set_big_cfg, gemm_tn_grouped
+    H, K = 1024, 640
+    g = torch.Generator(device="cuda").manual_seed(5)
+    dY = torch.randn(K, 4 * H, device="cuda", generator=g)
+    Xs = [torch.randn(K, 2 * H, device="cuda", generator=g), torch.randn(K, H, device="cuda", generator=g), torch.randn(K, H, device="cuda", generator=g)]
+    try:
+        gemm_set_big_cfg(cfg)
+        w_ih = torch.full((4 * H, 3 * H + 8), 7.0, device="cuda")        # [ctx | h1] and 8 columns nobody may touch
+        w_hh = torch.zeros(4 * H, H, device="cuda")
+        outs = [w_ih[:, :2 * H], w_ih[:, 2 * H:3 * H], w_hh]
+        gemm_tn_grouped(dY, Xs, outs)
+        assert torch.all(w_ih[:, 3 * H:] == 7.0)
+        for x, o in zip(Xs, outs):
+            ref = dY.double().t() @ x.double()
+            assert ((o.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+        if cfg > 0:
+            for x, o in zip(Xs, outs):
+                # the same kernel on the product alone (4096 x 2048 and 4096 x 1024 both have >= 256 tiles of 128 x 128)
+                assert torch.equal(o.contiguous(), gemm("tn", dY, x, None, 1))
+        # rows behind the live count hold finite values whose products must not be read: the sum stops at 200 -> 224 rows
+        live = torch.tensor([200], device="cuda", dtype=torch.int32)
+        outs2 = gemm_tn_grouped(dY, Xs, None, live)
+        for x, o in zip(Xs, outs2):
+            ref = dY[:224].double().t() @ x[:224].double()
+            assert ((o.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
+    finally:
+        gemm_set_big_cfg(-2)
