@@ -269,7 +269,13 @@ int icz_aoa_set_regions(icz_aoa_t* h, int32_t regions, const int32_t* counts_dev
 /* Option "graphs" = 1 (round 5): icz_aoa_scst_rollouts and icz_aoa_sample_backward are captured into hipGraphs on first use and
  * replayed afterwards, as icz_butd_set_option("graphs") does for the BUTD decoder; keyed by every pointer and size of the call, so
  * enable it only when buffers are reused.  Batches with per-image region counts (icz_aoa_set_regions), explicit randomness arrays
- * and a backward pass under a gradient-ready callback stay eager. */
+ * and a backward pass under a gradient-ready callback stay eager.
+ * Option "refine_pair" (default 1, round 5): icz_aoa_scst_rollouts runs the evaluation-mode refiner pass of the greedy baseline and the
+ * training-mode pass of the sampled rollout (AoA_Model.py:698-714 under Engine.py:256-262) as ONE pass over twice the rows -- same
+ * bits in both halves as the two passes when the GEMMs take the same split-K decomposition (they do at the BASELINE batch of 64;
+ * otherwise within fp32 rounding); 0 = two passes.  Fixed region counts only (a batch under icz_aoa_set_regions runs two passes).
+ * Option "mha_mfma" (default 1, round 5): the refiner's self-attention (AoA_Model.py:41-69) on the fp32 matrix pipe for up to 64
+ * regions; 0 = the register-blocked kernel of rounds 1 - 4 (which larger region sets use anyway). */
 int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value);
 /* eval-mode refined features [B,regions,Hd] (AoADetection_Captioner.sampler's first two lines, :712-713) -- for tests.  With
  * region counts the refiner runs on the packed valid rows; rows past an image's count come back as zeros. */

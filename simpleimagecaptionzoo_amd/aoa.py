@@ -86,6 +86,10 @@ class AoaHandle:
         self._persistent = bool(on)
         check(lib().icz_aoa_set_option(self._h, b"graphs", 1 if on else 0))
 
+    def set_option(self, name, value):
+        """icz_aoa_set_option: "early_out", "refine_pair" (include/icz.h)."""
+        check(lib().icz_aoa_set_option(self._h, name.encode(), int(value)))
+
     def _buf(self, name, shape, dtype):
         if not self._persistent:
             return torch.zeros(shape, dtype=dtype, device=self.device)

@@ -51,6 +51,7 @@ int Aoa::init(const icz_aoa_dims& d) {
         ICZ_TRY(alloc((void**)&s.off, sizeof(int32_t) * (rows + 1)));
         ICZ_TRY(alloc((void**)&s.rowmap, sizeof(int32_t) * RR));
     }
+    own[0] = bank[0]; own[1] = bank[1];
     use_bank(0);
     for (int i = 0; i < 2; ++i) {
         ICZ_TRY(alloc((void**)&h[i], sizeof(float) * rows * Hd));
@@ -113,6 +114,15 @@ static int aoa_linear(Aoa& a, GemmArgs& g, const float* bias, float* out, hipStr
     return ICZ_OK;
 }
 
+// refiner self-attention of one layer over n_img images: the matrix-pipe kernel up to 64 regions, the register-blocked one beyond
+void Aoa::launch_mha_self(int n_img, int R, int qc, size_t lds, const RegionRows& rr, const float* qkv_, float* o_, const DropP& dp, hipStream_t st) {
+    const int Hd = dims.Hd, NH = dims.NH;
+    if (mha_mfma && R <= 64 && (Hd / NH) % 64 == 0)
+        hipLaunchKernelGGL(mha_self_mfma_kernel, dim3(n_img, NH), dim3(256), sizeof(float) * 64 * 68, st, qkv_, qkv_ + Hd, qkv_ + 2 * Hd, o_, R, Hd, NH, rr, dp, 3 * Hd);
+    else
+        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, qkv_, qkv_ + Hd, qkv_ + 2 * Hd, o_, R, Hd, NH, qc, rr, dp, 3 * Hd);
+}
+
 int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, int N, float* out, hipStream_t st) {
     GemmArgs g = {};
     g.nseg = 1;
@@ -125,6 +135,7 @@ int Aoa::lin(const float* A, int M, int K, const float* W, const float* bias, in
 // decoder block's linear_K / linear_V of it (time-invariant, hoisted out of the decoding loop)
 // proj != null: img_feats_porjection(feats) has been computed (Aoa::project, packed rows for 'adaptive' batches): only its ReLU / dropout runs
 int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st, const float* proj) {
+    point_bank_at_own(cur_bank);          // (a pass of its own never writes into the halves of a paired pass another chain may still read)
     const int R = cur_R, Hd = dims.Hd, NH = dims.NH;
     ICZ_REQUIRE(!lens || lens_n == n_img, "aoa: region counts were set for %d images, the batch has %d (icz_aoa_set_regions)", lens_n, n_img);
     const int rows = (int)region_row_count(n_img);
@@ -155,8 +166,7 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st, const
         const icz_aoa_block& b = P.layer[l];
         hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows, 4)), dim3(256), 0, st, cur, b.ln_g, b.ln_b, ln, rows, Hd, (float*)nullptr);
         ICZ_TRY(lin(ln, rows, Hd, w_qkv[l], b_qkv[l], 3 * Hd, qkv, st));         // linear_Q | linear_K | linear_V in one GEMM
-        hipLaunchKernelGGL(mha_self_kernel, dim3(n_img, NH), dim3(256), lds, st, qkv, qkv + Hd, qkv + 2 * Hd, o, R, Hd, NH, qc, rr,
-                           dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f), 3 * Hd);
+        launch_mha_self(n_img, R, qc, lds, rr, qkv, o, dropp(train, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f), st);
         const float *xo = o, *xn = ln;
         if (train) {
             hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, o, ln, od, nd, (size_t)rows, Hd, rr,
@@ -177,6 +187,52 @@ int Aoa::refine(const float* feats, int n_img, bool train, hipStream_t st, const
     hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n_img), dim3(256), 0, st, refined, meanf, Hd, rr);
     ICZ_TRY(lin(refined, rows, Hd, P.dec.k_w, P.dec.k_b, Hd, Kd, st));
     ICZ_TRY(lin(refined, rows, Hd, P.dec.v_w, P.dec.v_b, Hd, Vd, st));
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+// The two refiner passes of an SCST step -- evaluation mode for the greedy baseline (Engine.py:256-258), training mode for the sampled
+// rollout (:259-262) -- as ONE pass over [evaluation rows; training rows] (fixed region counts): every Linear is one GEMM of twice the rows
+// (at 2 x 2304: the fused Q/K/V projection fills 216 tiles of 256 x 256 and runs on the eight-wave kernel), every small kernel one launch;
+// dropout applies to the second half only, with the indices a pass of its own would use (DropP::idx0), so both halves hold the bits of
+// the separate passes.  proj = img_feats_porjection(feats) before ReLU / dropout (Aoa::project), shared by both halves.
+int Aoa::refine_pair(int n_img, hipStream_t st, const float* proj) {
+    ICZ_REQUIRE(!lens && proj && dual.xa, "aoa refine_pair: fixed region counts, a shared projection and the pair buffers are needed");
+    const int R = cur_R, Hd = dims.Hd, NH = dims.NH;
+    const int rows = n_img * R, rows2 = 2 * rows, n2 = 2 * n_img;
+    const RegionRows rr = region_rows();
+    const size_t nel = (size_t)rows * Hd;
+    const unsigned eb = (unsigned)((nel + 255) / 256), eb2 = (unsigned)((2 * nel + 255) / 256);
+    const Bank& w = dual;
+    auto second = [&](DropP d, size_t elems_first) { d.idx0 = elems_first; return d; };
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, proj, w.xa, nel, dropp(false, nullptr, 0, AOA_RNG_PROJ, 0, 0.5f), rr, Hd);
+    hipLaunchKernelGGL(relu_drop_kernel, dim3(eb), dim3(256), 0, st, proj, w.xa + nel, nel, dropp(true, rng.proj_mask, 0, AOA_RNG_PROJ, 0, 0.5f), rr, Hd);
+    const int qc = self_qc(R);
+    const size_t lds = self_lds(R, qc);
+    float *cur = w.xa, *nxt = w.xb;
+    for (int l = 0; l < NL; ++l) {
+        const icz_aoa_block& b = P.layer[l];
+        hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows2, 4)), dim3(256), 0, st, cur, b.ln_g, b.ln_b, w.ln, rows2, Hd, (float*)nullptr);
+        ICZ_TRY(lin(w.ln, rows2, Hd, w_qkv[l], b_qkv[l], 3 * Hd, w.qkv, st));
+        launch_mha_self(n2, R, qc, lds, rr, w.qkv, w.o,
+                        second(dropp(true, rng.ref_att_mask, (size_t)l * n_img * NH * R * R, AOA_RNG_REF_ATT, l, 0.1f), (size_t)n_img * NH * R * R), st);
+        // dropout of [attention output | normed input] for the training half, in place (each thread rewrites the element it read)
+        hipLaunchKernelGGL(drop_concat_kernel, dim3(eb), dim3(256), 0, st, w.o + nel, w.ln + nel, w.o + nel, w.ln + nel, (size_t)rows, Hd, rr,
+                           dropp(true, rng.ref_aoa_mask, (size_t)l * n_img * R * 2 * Hd, AOA_RNG_REF_AOA, l, 0.3f));
+        GemmArgs g = {};
+        g.nseg = 2;
+        g.seg[0] = {w.o, b.aoa_w, Hd, 2 * Hd, Hd, nullptr};
+        g.seg[1] = {w.ln, b.aoa_w + Hd, Hd, 2 * Hd, Hd, nullptr};
+        g.M = rows2; g.N = 2 * Hd;
+        ICZ_TRY(aoa_linear(*this, g, b.aoa_b, w.z, st));
+        hipLaunchKernelGGL(glu_residual_kernel, dim3(eb2), dim3(256), 0, st, w.z, cur, nxt, (size_t)rows2, Hd, rr,
+                           second(dropp(true, rng.ref_sc_mask, (size_t)l * n_img * R * Hd, AOA_RNG_REF_SC, l, 0.1f), nel));
+        float* t_ = cur; cur = nxt; nxt = t_;
+    }
+    hipLaunchKernelGGL(layer_norm_kernel, dim3(cdiv(rows2, 4)), dim3(256), 0, st, cur, P.ref_ln_g, P.ref_ln_b, w.refined, rows2, Hd, (float*)nullptr);
+    hipLaunchKernelGGL(mean_rows_kernel, dim3(cdiv(Hd, 256), n2), dim3(256), 0, st, w.refined, w.meanf, Hd, rr);
+    ICZ_TRY(lin(w.refined, rows2, Hd, P.dec.k_w, P.dec.k_b, Hd, w.Kd, st));
+    ICZ_TRY(lin(w.refined, rows2, Hd, P.dec.v_w, P.dec.v_b, Hd, w.Vd, st));
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -261,11 +317,11 @@ static int zero_state(Aoa& a, int rows, hipStream_t st) {
 // AoA_Decoder.sample (AoA_Model.py:289-345) behind AoADetection_Captioner.sampler (:698-714)
 // scst = true (the baseline of an SCST step, rollouts_impl): once EVERY row has emitted <end> the kernels of the remaining steps return
 // at entry and their ids are 0 -- nothing behind a row's <end> reaches the reward (Utils.py:354); icz_aoa_greedy never does this
-int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj, bool scst) {
+int Aoa::greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj, bool scst, bool refined_ready) {
     ICZ_REQUIRE(feats && ids_out && B > 0 && B <= dims.max_rows && T > 0, "aoa greedy: bad arguments");
     ICZ_REQUIRE(fresh, "aoa: call icz_aoa_refresh_weights after binding/updating parameters");
     use_bank(0);
-    ICZ_TRY(refine(feats, B, false, st, proj));
+    if (!refined_ready) ICZ_TRY(refine(feats, B, false, st, proj));
     ICZ_TRY(zero_state(*this, B, st));
     int* const gn = (scst && early_out && gnunf && tcap_T >= T && tcap_B >= B) ? gnunf : nullptr;
     hipLaunchKernelGGL(greedy_init_kernel, dim3(cdiv(B > T ? B : T, 256)), dim3(256), 0, st, it, B, gn, T);
@@ -394,6 +450,8 @@ int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value) {
     Aoa* n = reinterpret_cast<Aoa*>(h);
     if (strcmp(name, "graphs") == 0) { n->use_graphs = value != 0; return ICZ_OK; }
     if (strcmp(name, "early_out") == 0) { n->early_out = value != 0; n->gc.clear(); return ICZ_OK; }
+    if (strcmp(name, "refine_pair") == 0) { n->pair_refine = value != 0; n->gc.clear(); return ICZ_OK; }
+    if (strcmp(name, "mha_mfma") == 0) { n->mha_mfma = value != 0; n->gc.clear(); return ICZ_OK; }
     set_error("icz_aoa_set_option: unknown option '%s'", name);
     return ICZ_ERR_INVALID;
 }

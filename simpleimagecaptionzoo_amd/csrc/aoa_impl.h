@@ -53,6 +53,21 @@ struct Aoa {
     struct Bank { float *xa, *xb, *ln, *qkv, *o, *od, *nd, *z, *refined, *meanf, *Kd, *Vd, *ws; int32_t *off, *rowmap; float* featp; };
     Bank bank[2] = {};
     int cur_bank = 0;
+    // (round 5) the two refiner passes of an SCST step as ONE pass over [evaluation rows; training rows] (refine_pair): buffers of twice the
+    // rows; while a pair is current, the banks' result pointers (refined, meanf, Kd, Vd) point at its halves, own[] keeps the banks' own
+    Bank dual = {};
+    Bank own[2] = {};
+    bool pair_refine = true;             // icz_aoa_set_option("refine_pair")
+    void point_banks_at_pair(int n_img) {
+        const size_t nel = (size_t)n_img * cur_R * dims.Hd, nm = (size_t)n_img * dims.Hd;
+        bank[0].refined = dual.refined; bank[0].meanf = dual.meanf; bank[0].Kd = dual.Kd; bank[0].Vd = dual.Vd;
+        bank[1].refined = dual.refined + nel; bank[1].meanf = dual.meanf + nm; bank[1].Kd = dual.Kd + nel; bank[1].Vd = dual.Vd + nel;
+        use_bank(cur_bank);
+    }
+    void point_bank_at_own(int b) {
+        bank[b].refined = own[b].refined; bank[b].meanf = own[b].meanf; bank[b].Kd = own[b].Kd; bank[b].Vd = own[b].Vd;
+        use_bank(cur_bank);
+    }
     void use_bank(int b) {
         cur_bank = b;
         const Bank& s = bank[b];
@@ -141,9 +156,12 @@ struct Aoa {
     // out[M,N] = A[M,K] W[N,K]^T + bias  (split-K through `ws` when the launch would be too small)
     int lin(const float* A, int M, int K, const float* W, const float* bias, int N, float* out, hipStream_t st);
     int refine(const float* feats, int n_img, bool train, hipStream_t st, const float* proj = nullptr);
+    int refine_pair(int n_img, hipStream_t st, const float* proj);
+    bool mha_mfma = true;                // icz_aoa_set_option("mha_mfma"): refiner self-attention on the fp32 matrix pipe (<= 64 regions)
+    void launch_mha_self(int n_img, int R, int qc, size_t lds, const RegionRows& rr, const float* qkv_, float* o_, const DropP& dp, hipStream_t st);
     int project(const float* feats, int n_img, float* out, hipStream_t st);
     int step(const AoaStepIO& s, hipStream_t st);
-    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj = nullptr, bool scst = false);
+    int greedy(const float* feats, int B, int T, int64_t* ids_out, hipStream_t st, const float* proj = nullptr, bool scst = false, bool refined_ready = false);
     int rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* ids_out, int64_t* seq_out, float* logp_out, hipStream_t st);
     int beam_search(const float* feats, int n_img, int kb, int max_steps, float* seqs_out, int32_t* lens_out, hipStream_t st);
@@ -164,7 +182,7 @@ struct Aoa {
     AoaStepIO train_io(int rows, int t, bool train);
     int sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
     int sample_prelude(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t* seq_out, float* logp_out, hipStream_t st);
-    int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj = nullptr);
+    int sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj = nullptr, bool refined_ready = false);
     int sample_backward_impl(const float* reward, const icz_aoa_params& G, float* loss_out, float* msum_out, hipStream_t st);
     int sample_backward(const float* reward, const icz_aoa_params* G, float* loss_out, float* msum_out, float msum_global, hipStream_t st);
     int xe_forward(const float* feats, const int64_t* captions, int B, int L, const int32_t* lengths, const icz_aoa_rng* r, int train,

@@ -14,8 +14,10 @@ struct DropP {
     uint32_t stream, step;
     uint32_t thresh;          // floor(p * 2^32)
     float scale;              // 1 / (1 - p)
+    uint64_t idx0;            // elements in front of idx0 pass unchanged and the rest count from it: the evaluation-mode half of a paired refiner pass
     __device__ __forceinline__ float apply(float x, uint64_t idx) const {
-        if (mode == 0) return x;
+        if (mode == 0 || idx < idx0) return x;
+        idx -= idx0;
         bool keep;
         if (mode == 1) keep = mask[idx] != 0;
         else {
@@ -162,6 +164,81 @@ __host__ __device__ __forceinline__ int aoa_pitch(int n) {
 // Both products are register-blocked: a thread owns a 4 x 4 block of S (rows q, q + nq/4, ...; keys r, r + len/4, ...) or a
 // 4 x 4 block of O (4 strided rows x 4 adjacent columns) and walks the reduction dimension four at a time with 16-byte LDS
 // reads -- 8 reads per 64 FMAs, where one element per thread needs 2 reads per FMA and leaves the kernel LDS-bound.
+// (round 5) The same attention on the fp32 matrix pipe for region counts up to 64 (36 boxes, the 7 x 7 grid): the register-blocked kernel
+// above keeps 81 of 256 threads busy in S = Q K^T at 36 regions and took 29 us per refiner layer at 64 images (58 us for the paired pass of
+// an SCST step) for 75 MB of traffic.  Here a wave owns 16 x 16 tiles: S tiles with v_mfma_f32_16x16x4_f32 (exact fp32 products) straight
+// from 16-byte row loads of Q and K (lane (i, g) holds row i, k = 16 j + 4 g + e -- the k order of a fragment is free as long as both
+// operands use it), the scaled scores through a small LDS tile for the row softmax (one key per lane) and dropout, then O = P V with P
+// fragments from LDS and V fragments as dword loads along the head dimension.  LDS: RP x (RP + 4) floats (10 KB at 36 regions).
+// Same index for the dropout draw of P[q][k] as above.  d = Hd / NH must be a multiple of 16.
+__global__ __launch_bounds__(256) void mha_self_mfma_kernel(const float* __restrict__ Q, const float* __restrict__ K, const float* __restrict__ V,
+                                                            float* __restrict__ O, int R, int Hd, int NH, RegionRows rr, DropP dp, int ldi) {
+    extern __shared__ __attribute__((aligned(16))) float sm_mha2[];
+    const int img = blockIdx.x, hd = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 15, lg = lane >> 4;
+    const int d = Hd / NH;
+    const int len = rr.count(img);
+    const int nrow = rr.off ? len : R;                       // query rows of this image
+    const int nt = (max(len, nrow) + 15) >> 4, RP = nt * 16, lp = RP + 4;
+    float* sp = sm_mha2;                                     // [RP][lp]
+    const size_t base = rr.first(img) * Hd + (size_t)hd * d;
+    const size_t ibase = rr.first(img) * ldi + (size_t)hd * d;
+    const float scale = 1.0f / sqrtf((float)d);
+    // ---- S = Q K^T / sqrt(d): tile (qt, kt) = tile index / nt, % nt
+    for (int tile = wave; tile < nt * nt; tile += 4) {
+        const int qt = tile / nt, kt = tile % nt;
+        const float* qp = Q + ibase + (size_t)min(qt * 16 + li, nrow - 1) * ldi + 4 * lg;      // rows behind the last one repeat it: never stored
+        const float* kp = K + ibase + (size_t)min(kt * 16 + li, len - 1) * ldi + 4 * lg;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j0 = 0; j0 < d; j0 += 64) {
+            f32x4 qf[4], kf[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                qf[j] = *reinterpret_cast<const f32x4*>(qp + j0 + 16 * j);
+                kf[j] = *reinterpret_cast<const f32x4*>(kp + j0 + 16 * j);
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(qf[j][e], kf[j][e], acc, 0, 0, 0);
+        }
+        // acc[r] <-> query qt * 16 + 4 lg + r, key kt * 16 + li
+#pragma unroll
+        for (int r = 0; r < 4; ++r) sp[(qt * 16 + 4 * lg + r) * lp + kt * 16 + li] = acc[r] * scale;
+    }
+    __syncthreads();
+    // ---- softmax over the valid keys of every query row (one wave per row, one key per lane), dropout, zeros behind the last key
+    for (int q = wave; q < RP; q += 4) {
+        const float v = lane < len ? sp[q * lp + lane] : -INFINITY;
+        const float mx = wave_max(v);
+        const float e = lane < len ? expf(v - mx) : 0.f;
+        const float sum = wave_sum(e);
+        const uint64_t idx = (((uint64_t)img * NH + hd) * R + q) * R;
+        if (lane < RP) sp[q * lp + lane] = (lane < len && q < nrow) ? dp.apply(e / sum, idx + lane) : 0.f;
+    }
+    __syncthreads();
+    // ---- O = P V: tile (qt, dt), dt over the head dimension in blocks of 16
+    const int ndt = d >> 4;
+    for (int tile = wave; tile < nt * ndt; tile += 4) {
+        const int qt = tile / ndt, dt = tile % ndt;
+        const float* pp = sp + (qt * 16 + li) * lp + 4 * lg;
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < nt; ++j) {
+            const f32x4 pf = *reinterpret_cast<const f32x4*>(pp + 16 * j);
+            float vf[4];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) vf[e] = V[ibase + (size_t)min(16 * j + 4 * lg + e, len - 1) * ldi + dt * 16 + li];      // P is zero behind the last key
+#pragma unroll
+            for (int e = 0; e < 4; ++e) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(pf[e], vf[e], acc, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int q = qt * 16 + 4 * lg + r;
+            if (q < nrow) O[base + (size_t)q * Hd + dt * 16 + li] = acc[r];
+        }
+    }
+}
+
 // The three projections of a refiner layer as one [3 Hd, Hd] weight and one [3 Hd] bias (one GEMM of N = 3 Hd instead of three
 // of N = Hd, which leave half of the CUs idle): copied from the bound parameters at every weight refresh.
 constexpr int AOA_QKV_MAX_LAYERS = 8;

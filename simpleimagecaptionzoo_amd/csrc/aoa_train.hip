@@ -318,9 +318,9 @@ int Aoa::sample(const float* feats, int B, int T, const icz_aoa_rng* r, int64_t*
     return sample_impl(feats, B, T, seq_out, logp_out, st);
 }
 
-int Aoa::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj) {
+int Aoa::sample_impl(const float* feats, int B, int T, int64_t* seq_out, float* logp_out, hipStream_t st, const float* proj, bool refined_ready) {
     use_bank(1);
-    ICZ_TRY(refine(feats, B, true, st, proj));
+    if (!refined_ready) ICZ_TRY(refine(feats, B, true, st, proj));
     const size_t sH = (size_t)B * dims.Hd;
     ICZ_CHECK_HIP(hipMemsetAsync(th, 0, sizeof(float) * sH, st));
     ICZ_CHECK_HIP(hipMemsetAsync(tm, 0, sizeof(float) * sH, st));
@@ -380,6 +380,17 @@ int Aoa::rollouts(const float* feats, int B, int T, const icz_aoa_rng* r, int64_
         ICZ_TRY(alloc((void**)&proj_shared, sizeof(float) * (size_t)dims.max_rows * dims.R * dims.Hd));
         ICZ_CHECK_HIP(hipDeviceSynchronize());
     }
+    if (!lens && pair_refine && !dual.xa) {      // the pair buffers: twice the rows of a bank's
+        const size_t RR2 = (size_t)2 * dims.max_rows * dims.R, Hd = dims.Hd;
+        float** ref[] = {&dual.xa, &dual.xb, &dual.ln, &dual.o, &dual.refined, &dual.Kd, &dual.Vd};
+        for (float** p : ref) ICZ_TRY(alloc((void**)p, sizeof(float) * RR2 * Hd));
+        ICZ_TRY(alloc((void**)&dual.qkv, sizeof(float) * RR2 * 3 * Hd));
+        ICZ_TRY(alloc((void**)&dual.z, sizeof(float) * RR2 * 2 * Hd));
+        ICZ_TRY(alloc((void**)&dual.meanf, sizeof(float) * (size_t)2 * dims.max_rows * Hd));
+        ICZ_CHECK_HIP(hipDeviceSynchronize());
+    }
+    // (host state, outside any captured graph: a replayed rollout pair leaves the banks where this call's batch size puts them)
+    if (!lens && pair_refine) point_banks_at_pair(B); else { point_bank_at_own(0); point_bank_at_own(1); }
     if (!use_graphs || lens || aoa_explicit_rng(rng)) return rollouts_impl(feats, B, T, ids_out, seq_out, logp_out, st);
     const std::vector<uintptr_t> key = {1, (uintptr_t)feats, (uintptr_t)B, (uintptr_t)T, (uintptr_t)cur_R, (uintptr_t)ids_out, (uintptr_t)seq_out,
                                         (uintptr_t)logp_out};
@@ -392,10 +403,12 @@ int Aoa::rollouts_impl(const float* feats, int B, int T, int64_t* ids_out, int64
         ICZ_TRY(project(feats, B, proj_shared, st));
         proj = proj_shared;
     }
+    const bool pair = proj && pair_refine && dual.xa;
+    if (pair) ICZ_TRY(refine_pair(B, st, proj));          // both refiner passes in one, in front of the fork
     ICZ_CHECK_HIP(hipEventRecord(ev_fork, st));
     ICZ_CHECK_HIP(hipStreamWaitEvent(side_st, ev_fork, 0));
-    const int sg = greedy(feats, B, T, ids_out, side_st, proj, true);
-    const int ss = sg == ICZ_OK ? sample_impl(feats, B, T, seq_out, logp_out, st, proj) : sg;
+    const int sg = greedy(feats, B, T, ids_out, side_st, proj, true, pair);
+    const int ss = sg == ICZ_OK ? sample_impl(feats, B, T, seq_out, logp_out, st, proj, pair) : sg;
     ICZ_CHECK_HIP(hipEventRecord(ev_join, side_st));       // always join, also on error (a capture must be closed)
     ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join, 0));
     return ss;

@@ -221,7 +221,10 @@ def test_aoa_rollouts_and_backward_under_graph_replay_equal_eager_launches(golde
     h.enable_graphs(False)
     ids0 = h.greedy(feats, T)
     seq0, lp0 = h.sample(feats, T, make_aoa_rng(500))
-    assert torch.equal(ids0, out[False][0][0]) and torch.equal(seq0, out[False][0][1]) and torch.equal(lp0, out[False][0][2])
+    # (since the paired refiner pass: at 16 images its GEMMs of 2 x 576 rows take another split-K decomposition than the single passes of
+    # greedy() / sample() -- tokens equal, log-probs within fp32 rounding; test_aoa_paired_refiner_pass_equals_the_two_passes has the bits)
+    assert torch.equal(ids0, out[False][0][0]) and torch.equal(seq0, out[False][0][1])
+    assert (lp0 - out[False][0][2]).abs().max().item() < 1e-4
 
 
 @pytest.mark.parametrize("B,bias", [(4, 4.0), (48, 7.0)])
@@ -390,3 +393,65 @@ def test_grouped_weight_gradients_equal_the_separate_products(cfg):
             assert ((o.double() - ref).abs().max() / ref.abs().max()).item() < 3e-6
     finally:
         gemm_set_big_cfg(-2)
+
+
+@pytest.mark.parametrize("B", [64, 16])
+def test_aoa_paired_refiner_pass_equals_the_two_passes(golden_dir, B):
+    """icz_aoa_scst_rollouts with both refiner passes as ONE pass over [evaluation rows; training rows] (option refine_pair, default)
+    against two passes: greedy ids and sampled ids equal; at the BASELINE batch (64 images: every GEMM of the pair takes the split-K
+    decomposition of the single passes) log-probs, loss and every decoder gradient bit for bit, at 16 images within fp32 rounding."""
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, make_aoa_rng
+    T = 20
+    torch.manual_seed(11)
+    cap = AoADetection_Captioner(vocab_size=V, num_heads=8, hidden_dim=H, embed_dim=E, device="cuda:0", num_regions=36, enc_dim=D,
+                                 max_batch=B)
+    cap.to("cuda:0")
+    feats = torch.relu(torch.randn(B, 36, D, device="cuda"))
+    rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
+    out = {}
+    for pair in (0, 1):
+        h = cap._handle()
+        h.enable_graphs(False)
+        h.set_option("refine_pair", pair)
+        grads = h.new_grads()
+        ids, seq, lp = h.rollouts(feats, T, make_aoa_rng(900))
+        loss, _ = h.sample_backward(rew, grads)
+        out[pair] = (ids.clone(), seq.clone(), lp.clone(), loss.clone(), {k: v.clone() for k, v in grads.items()})
+    a, b = out[0], out[1]
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    if B == 64:
+        assert torch.equal(a[2], b[2]) and torch.equal(a[3], b[3])
+        for k in a[4]:
+            assert torch.equal(a[4][k], b[4][k]), k
+    else:
+        assert (a[2] - b[2]).abs().max().item() < 1e-4 and abs(a[3].item() - b[3].item()) < 1e-5
+        for k in a[4]:
+            d = (a[4][k] - b[4][k]).abs().max().item()
+            assert d <= 2e-5 * max(a[4][k].abs().max().item(), 1e-3), (k, d)
+    cap._handle().set_option("refine_pair", 1)
+
+
+@pytest.mark.parametrize("R,counts", [(36, None), (49, None), (36, "ragged"), (64, "ragged")])
+def test_aoa_refiner_self_attention_on_the_matrix_pipe_equals_the_blocked_kernel(golden_dir, R, counts):
+    """mha_self_mfma_kernel (option mha_mfma, default for <= 64 regions) against the register-blocked kernel that the reference goldens
+    of test_gpu_aoa.py / test_gpu_aoa_adaptive.py pinned in rounds 1 - 4: refined regions of six layers within 2e-5 of max|x|, with fixed
+    region sets (36 boxes, 7 x 7 grid) and with per-image counts (packed rows, masked keys)."""
+    from simpleimagecaptionzoo_amd.aoa import AoADetection_Captioner, RegionBatch
+    B = 12
+    torch.manual_seed(3)
+    cap = AoADetection_Captioner(vocab_size=V, num_heads=8, hidden_dim=H, embed_dim=E, device="cuda:0", num_regions=R, enc_dim=D, max_batch=B)
+    cap.to("cuda:0")
+    feats = torch.relu(torch.randn(B, R, D, device="cuda"))
+    batch = feats
+    if counts == "ragged":
+        c = [R, 10, R - 1, 17, 16, 15, 1, 33 if R > 33 else R, R, 12, 20, 2]
+        m = (torch.arange(R, device="cuda").unsqueeze(0) < torch.tensor(c, device="cuda").unsqueeze(1))
+        batch = RegionBatch(feats * m.unsqueeze(2), c)
+    h = cap._handle()
+    out = {}
+    for on in (0, 1):
+        h.set_option("mha_mfma", on)
+        out[on] = h.refine(batch).clone()
+    h.set_option("mha_mfma", 1)
+    assert torch.isfinite(out[1]).all()
+    assert (out[0] - out[1]).abs().max().item() <= 2e-5 * out[0].abs().max().item()

@@ -25,6 +25,12 @@ def run(n):
 for rnd in range(3):
     for graphs in (False, True):          # alternating legs in one process (round 5: hipGraph replay of the rollout pair and the backward pass)
         eng.use_graphs = graphs
+        if os.environ.get("ICZ_PERF_OPT_AB"):       # any 0 / 1 option of icz_aoa_set_option: off on the "eager" leg, on on the "graphs" leg
+            eng.use_graphs = True
+            eng.model._handle().set_option(os.environ["ICZ_PERF_OPT_AB"], 1 if graphs else 0)
+        elif os.environ.get("ICZ_PERF_PAIR_AB"):      # second switch of round 5: both refiner passes as one (graphs leg) against two (eager leg)
+            eng.use_graphs = True
+            eng.model._handle().set_option("refine_pair", 1 if graphs else 0)
         run(3)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
