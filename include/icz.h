@@ -76,7 +76,10 @@ int icz_butd_bind_params(icz_butd_t* h, const icz_butd_params* params);
  * 1 - 4 did: the same results, an A/B switch.
  * "merge_small" = n (default 8, 0..32, ICZ_MERGE_SMALL): icz_butd_scst_rollouts of <= n images runs the greedy baseline and the
  * sampled rollout as ONE chain of 2 B decoder rows (evaluation-mode rows in front: per-row dropout / argmax-vs-multinomial in the
- * kernels), so that the weights are streamed once per step pair; same tokens, log-probs, loss as the two chains. */
+ * kernels), so that the weights are streamed once per step pair; same tokens, log-probs, loss as the two chains.
+ * "small_nt" (default 1): BPTT steps of <= 32 rows (small batches, the short tail of an XE batch) take their per-step dgrad products on
+ * the transposed LSTM weight copies through the fp32 NT kernel instead of NN products on the weights (which stream at half the rate
+ * at so few rows); 0 = the NN products of rounds 1 - 4.  Gradients agree to fp32 rounding. */
 int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value);
 /* Data-parallel overlap hook (no reference counterpart: the reference is single-process).  While a backward call is
  * being enqueued, `cb(user, stage)` is invoked each time a group of gradient tensors is complete in stream order:

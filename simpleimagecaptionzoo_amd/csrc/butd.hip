@@ -393,6 +393,7 @@ int icz_butd_set_option(icz_butd_t* h, const char* name, int32_t value) {
     if (strcmp(name, "graphs") == 0) { b->use_graphs = value != 0; return ICZ_OK; }
     if (strcmp(name, "concurrent") == 0) { b->concurrent = value != 0; return ICZ_OK; }
     if (strcmp(name, "early_out") == 0) { b->early_out = value != 0; return ICZ_OK; }
+    if (strcmp(name, "small_nt") == 0) { b->small_nt = value != 0; return ICZ_OK; }
     if (strcmp(name, "merge_small") == 0) {
         ICZ_REQUIRE(value >= 0 && value <= 32, "icz_butd_set_option: merge_small %d outside 0..32", value);
         b->merge_small = value;

@@ -148,6 +148,7 @@ struct Butd {
                                          // (a merged chain stores 2 B rows per step, the sampled rollout's are rows B .. 2 B - 1)
     bool early_out = true;               // option "early_out": 0 = run the steps behind the reference's break as rounds 1 - 4 did (A/B)
     bool bptt_early_out = false;         // backward of a sampled rollout: steps behind the reference's break return at entry (bptt)
+    bool small_nt = true;                // option "small_nt": BPTT steps of <= 32 rows take their dgrad products on the transposed weight copies (fp32 NT kernel)
 
     // beam search (butd_beam.hip)
     BeamBuf bm;
@@ -240,7 +241,7 @@ int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& f
     if (!use_graphs) return fn(st);
     ++tick;
     std::vector<uintptr_t> key = key_in;
-    key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0) + 4 * merge_small);          // flags that change the captured launch sequence
+    key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0) + 4 * merge_small + (small_nt ? 256 : 0));          // flags that change the captured launch sequence
     key.push_back(gemm_prof_on() ? 1 : 0);
     for (auto& e : graphs)
         if (e.key == key) {

@@ -640,6 +640,9 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         // with D = 2048 already -- take the NN path below, whose split is fitted to the buffer)
         const bool rdg = wt_lm_ih && wt_fresh && bt > 32 && bt <= 64 && gemm_slab_floats(bt, D + H, 4 * H / 256) <= tb.xfloats &&
                          gemm_slab_floats(bt, H, 2 * (4 * H / 256)) <= tb.xfloats;
+        // <= 32 rows (small batches, the tail of a ragged XE batch): the NN kernel streams W[k][n] at ~2 TB/s there, the fp32 NT kernel
+        // the transposed copies at 3.4 - 4.4 (profiles/r05_scst_b8_*: 12 us for 26 MB against 12 us for 40 MB)
+        const bool tdg = small_nt && wt_lm_ih && wt_fresh && bt <= 32;
         if (rdg) {   // X1 = dG_lm . W_ih_lm   [bt, D+H]
             GemmArgs g = {};
             g.nseg = 1;
@@ -648,6 +651,12 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             g.nsplit = ns1 = gemm_resident_x3_nsplit(g);
             ICZ_REQUIRE(gemm_slab_floats(bt, D + H, ns1) <= tb.xfloats, "butd: slab buffer too small for the dgrad slabs");
             ICZ_TRY(gemm_f32(GEMM_NT, g, st));
+        } else if (tdg) {   // <= 32 rows: the same product on the transposed copy through the fp32 NT kernel
+            GemmArgs g = {};
+            g.nseg = 1;
+            g.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_ih, 4 * H, 4 * H, 4 * H, nullptr};
+            g.M = bt; g.N = D + H; g.out = tb.X[0]; g.ldo = D + H; g.live = live;
+            ICZ_TRY(gemm_auto(GEMM_NT, g, tb.X[0], tb.xfloats, &ns1, st));
         } else {
             GemmArgs g = {};
             g.nseg = 1;
@@ -691,6 +700,22 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             ns3 = gemm_resident_x3_nsplit(g3); ns4 = gemm_resident_x3_nsplit(g4);
             ICZ_REQUIRE(gemm_slab_floats(bt, H, ns3) <= tb.xfloats, "butd: slab buffer too small for the dgrad slabs");
             ICZ_TRY(gemm_resident_x3_pair(g3, g4, st));
+        } else if (t > 0 && tdg) {
+            {
+                GemmArgs g = {};
+                g.nseg = 2;
+                g.seg[0] = {tb.dGlm + slot * 4 * H, wt_lm_hh, 4 * H, 4 * H, 4 * H, nullptr};
+                g.seg[1] = {tb.dGtd + slot * 4 * H, wt_td_ih_h2, 4 * H, 4 * H, 4 * H, nullptr};
+                g.M = bt; g.N = H; g.out = tb.X[2]; g.ldo = H; g.live = live;
+                ICZ_TRY(gemm_auto(GEMM_NT, g, tb.X[2], tb.xfloats, &ns3, st));
+            }
+            {
+                GemmArgs g = {};
+                g.nseg = 1;
+                g.seg[0] = {tb.dGtd + slot * 4 * H, wt_td_hh, 4 * H, 4 * H, 4 * H, nullptr};
+                g.M = bt; g.N = H; g.out = tb.X[3]; g.ldo = H; g.live = live;
+                ICZ_TRY(gemm_auto(GEMM_NT, g, tb.X[3], tb.xfloats, &ns4, st));
+            }
         } else if (t > 0) {
             {   // X3 = dG_lm . W_hh_lm + dG_td . W_ih_td[:, :H]   -> d h2_{t-1}
                 GemmArgs g = {};

@@ -120,7 +120,7 @@ def test_early_break_under_graph_replay_equals_eager_launches():
 
 
 # ---- merged greedy + sampled chain of a small SCST batch (Butd::sample_chain with row0 = B) ---------------------------------------
-def _small_case(B, merged, params, feats, seed, end_bias=None):
+def _small_case(B, merged, params, feats, seed, end_bias=None, small_nt=1):
     from simpleimagecaptionzoo_amd.butd import ButdHandle, make_rng
     T = 20
     p = {k: v.clone() for k, v in params.items()}
@@ -130,6 +130,7 @@ def _small_case(B, merged, params, feats, seed, end_bias=None):
     h = ButdHandle(R, D, H, E, A, V, B, T)
     h.bind(p)
     h.set_option("merge_small", 32 if merged else 0)
+    h.set_option("small_nt", small_nt)
     rs = np.random.RandomState(seed)
     em, am, om = rs.rand(T, B, E) < 0.5, rs.rand(T, B, R, A) < 0.5, rs.rand(T, B, H) < 0.5
     u = rs.rand(T, B).astype(np.float32)
@@ -455,3 +456,23 @@ def test_aoa_refiner_self_attention_on_the_matrix_pipe_equals_the_blocked_kernel
     h.set_option("mha_mfma", 1)
     assert torch.isfinite(out[1]).all()
     assert (out[0] - out[1]).abs().max().item() <= 2e-5 * out[0].abs().max().item()
+
+
+@pytest.mark.parametrize("B,merged,end_bias", [(8, True, None), (16, False, None), (24, False, None), (16, True, 9.0)])
+def test_small_row_bptt_on_transposed_weights_equals_the_nn_kernel(B, merged, end_bias):
+    """BPTT steps of <= 32 rows take d[ctx | h1], d h2 and d h1 (BUTD_Model.py:137-145 under loss.backward()) as NT products on the
+    transposed weight copies (option small_nt, default) instead of NN products on the weights themselves: same rollout, loss
+    and mask sum; every gradient within fp32 rounding (another kernel, another blocking of the same sums)."""
+    from simpleimagecaptionzoo_amd.synth import random_butd_params
+    params = random_butd_params(R, D, H, E, A, V, "cuda", seed=700 + B)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(B + 1)
+    feats = torch.relu(torch.randn(B, R, D, generator=g)).cuda()
+    a = _small_case(B, merged, params, feats, 13, end_bias, small_nt=1)
+    b = _small_case(B, merged, params, feats, 13, end_bias, small_nt=0)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2])
+    assert a[3] == b[3] and a[4] == b[4]
+    for k in a[5]:
+        assert np.isfinite(a[5][k]).all(), k
+        scale = float(np.abs(b[5][k]).max()) + 1e-12
+        assert float(np.abs(a[5][k] - b[5][k]).max()) <= 2e-5 * scale, (k, float(np.abs(a[5][k] - b[5][k]).max()), scale)
