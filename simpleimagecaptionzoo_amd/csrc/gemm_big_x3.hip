@@ -8,7 +8,7 @@
 //
 //   * BM x BN tile, WM x WN waves, wave tile (BM / WM) x (BN / WN) in 32 x 32 MFMA blocks (v_mfma_f32_32x32x16_bf16, six per product);
 //   * a k-step is 16 deep.  Its LDS image is the planes experiment's: per operand, piece and 32-row block one KiB, row r / k half h
-//     at chunk 2 r + (h ^ ((r >> 3) & 1)) -- fragment reads (ds_read_b128, lane = (row, half)) and both staging maps below are
+//     at chunk 2 r + (h ^ bx_sw(r)) -- fragment reads (ds_read_b128, lane = (row, half)) and both staging maps below are
 //     conflict-free on it;
 //   * two LDS slots, ONE barrier per k-step: during step s (MFMAs on slot s & 1) a thread cuts its 8 + 8 fp32 values of step s + 1
 //     into three bf16 pieces and writes them to the other slot (free since the barrier that ended step s - 1), while its loads
@@ -43,6 +43,15 @@ __device__ __forceinline__ void bx_split3(float a, float b, uint32_t& p0, uint32
 }
 
 constexpr int BX_KS = 16;          // k-step depth
+
+// Which of its two 16-byte chunks (2 r, 2 r + 1) half h of row r takes inside the KiB of a 32-row block: h ^ bx_sw(r).  Three access
+// patterns must be conflict-free (MI355X_MICROARCH.md, LDS): the fragment read (ds_read_b128: lane groups {0-3, 12-15, 20-27} and
+// {4-11, 16-19, 28-31} of each half-wave, 64 banks: the two rows of a group with the same r mod 8 must differ in the bit), the
+// K-contiguous staging store (ds_write_b128: groups of 8 lanes = 4 rows x 2 halves: free for any bit) and the k-major staging store
+// (8 lanes = 8 consecutive rows of one half, 32 banks: rows r and r + 4 must differ).  Bit 2 ^ bit 4 of r is the solution; the planes
+// experiment's bit 3 left a two-way conflict on every k-major store (SQ_LDS_BANK_CONFLICT 0.29 - 0.33 of the LDS cycles on the
+// weight-gradient shapes, profiles/r05_gemm_big_pmc.txt).
+__device__ __forceinline__ int bx_sw(int r) { return ((r >> 2) ^ (r >> 4)) & 1; }
 
 // TN only: the columns of the output as up to four groups, each with its own B operand and its own output matrix (the weight gradients of
 // one LSTM: d gates^T [h2 | emb | h1] land in W_ih's column blocks and in W_hh) -- one launch with 3 - 4x the tiles of the separate products
@@ -101,7 +110,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_big_x3_kernel(GemmArgs
 #pragma unroll
             for (int q = 0; q < 16; ++q) acc[i][u][q] = 0.f;
 
-    const int fo = (2 * r + (h ^ ((r >> 3) & 1))) * 16;
+    const int fo = (2 * r + (h ^ bx_sw(r))) * 16;
     const int fa = (wm * FI) * 1024 + fo, fb = (PA + wn * FU) * 1024 + fo;
 
     auto run_segment = [&](const GemmSeg& g, int kbeg, int kend) {
@@ -118,7 +127,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_big_x3_kernel(GemmArgs
             if (mr > a.M - 1) mr = a.M - 1;                        // clamped rows feed only never-stored outputs
             ap[j] = AROW ? g.A + (size_t)mr * g.lda + kbeg + 8 * hh : g.A + (size_t)(kbeg + 8 * hh) * g.lda + mr;
             const int rr = row & 31;
-            da[j] = (row >> 5) * 1024 + (2 * rr + (hh ^ ((rr >> 3) & 1))) * 16;
+            da[j] = (row >> 5) * 1024 + (2 * rr + (hh ^ bx_sw(rr))) * 16;
         }
 #pragma unroll
         for (int j = 0; j < IB; ++j) {
@@ -130,7 +139,7 @@ __global__ __launch_bounds__(64 * WM * WN, WPE) void gemm_big_x3_kernel(GemmArgs
             const int ldbp = (!AROW && !BROW) ? ldb_g : g.ldb;
             bp[j] = BROW ? Bp + (size_t)nr * ldbp + kbeg + 8 * hh : Bp + (size_t)(kbeg + 8 * hh) * ldbp + nr;
             const int rr = row & 31;
-            db[j] = PA * 1024 + (row >> 5) * 1024 + (2 * rr + (hh ^ ((rr >> 3) & 1))) * 16;
+            db[j] = PA * 1024 + (row >> 5) * 1024 + (2 * rr + (hh ^ bx_sw(rr))) * 16;
         }
         const int ldb_s = (!AROW && !BROW) ? ldb_g : g.ldb;
         const int astep = AROW ? BX_KS : BX_KS * g.lda, bstep = BROW ? BX_KS : BX_KS * ldb_s;          // floats per k-step (< 2^31 / steps: checked by the launcher)
