@@ -106,6 +106,10 @@ def lib():
     if not os.path.exists(LIB_PATH):
         raise IczError("libicz.so not found at %s -- the HIP extension is required (no fallback); run "
                        "__graft_entry__.build()" % LIB_PATH)
+    # torch first: its wheel carries its own libamdhip64.so, and libicz.so (linked against the same soname) must bind to THAT runtime --
+    # loaded the other way round the process holds two HIP runtimes and the second one finds no device ("no ROCm-capable device is
+    # detected" from the first hipMalloc; seen with __graft_entry__.build() followed by smoke() in one process)
+    import torch  # noqa: F401
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
     sig = {
