@@ -395,6 +395,10 @@ size_t icz_gemm_workspace_floats(int32_t M, int32_t N);
  * kernel everywhere, 1..5 = one large-tile configuration of gemm_big_x3.hip everywhere, -2 = back to the environment's value.
  * Process-wide; meant for tests and A/B measurements, not for use while other threads launch. */
 int icz_gemm_set_big_cfg(int32_t cfg);
+/* The tile configuration a many-row product of that shape is given (host logic only, no GPU needed): 0 = the 128 x 128 two-barrier
+ * kernel, 1 = 256 x 256 / eight waves, 4 = 128 x 128 three workgroups per CU; -1 = bad arguments.  Only meaningful for shapes that
+ * reach those kernels at all (>= 128 rows and columns, K in whole 128-deep chunks; TN: >= 256 tiles of 128 x 128). */
+int icz_gemm_big_cfg_for(int32_t layout, int32_t M, int32_t N, int32_t K, int32_t nsplit);
 /* Weight gradients that share d y as ONE launch: out_j[M, cols_j] (row stride ldo_j) = dY[K, M]^T X_j[K, cols_j], j < ngroups <= 4,
  * cols_j % 256 == 0, M * sum(cols_j) >= 256 tiles of 128 x 128 (else ICZ_ERR: issue them one by one through icz_gemm_f32).
  * rows_live: optional device count of leading rows of K that matter (rounded up to 32).  What Butd::bptt does for the

@@ -186,6 +186,7 @@ def lib():
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
         "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),
         "icz_gemm_set_big_cfg": (C.c_int, [i32]),
+        "icz_gemm_big_cfg_for": (C.c_int, [i32, i32, i32, i32, i32]),
         "icz_gemm_tn_grouped": (C.c_int, [vp, i32, i32, i32, i32, vp, vp, vp, vp, vp, vp, vp]),
     }
     for name, (res, args) in sig.items():

@@ -490,6 +490,15 @@ int icz_gemm_set_big_cfg(int32_t cfg) {
     return ICZ_OK;
 }
 
+int icz_gemm_big_cfg_for(int32_t layout, int32_t M, int32_t N, int32_t K, int32_t nsplit) {
+    if (layout < 0 || layout > 2 || M <= 0 || N <= 0 || K <= 0) return -1;
+    GemmArgs g = {};
+    g.nseg = 1;
+    g.seg[0].K = K;
+    g.M = M; g.N = N; g.nsplit = nsplit > 0 ? nsplit : 1;
+    return gemm_big_cfg((GemmLayout)layout, g);
+}
+
 int icz_gemm_tn_grouped(const float* dY, int32_t ldy, int32_t M, int32_t K, int32_t ngroups, const float* const* X, const int32_t* ldx,
                         const int32_t* cols, float* const* out, const int32_t* ldo, const int32_t* rows_live, void* stream) {
     ICZ_REQUIRE(ngroups >= 1 && ngroups <= GEMM_MAX_COLGROUPS && X && ldx && cols && out && ldo, "icz_gemm_tn_grouped: bad arguments");

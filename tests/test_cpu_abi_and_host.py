@@ -372,3 +372,20 @@ def test_bench_reads_its_committed_profiles_for_both_gemm_kernels():
     assert "error" not in a and 0.2 < a["frac"] < 0.7 and 10 <= a["launches_per_step"] <= 30, a
     us, src = bench.trace_avg_us("gemm_resident_x3_kernel")
     assert us and 10 < us < 30 and src.startswith("profiles/r05_")
+
+
+def test_routing_of_the_many_row_gemms_at_the_baseline_shapes():
+    """gemm_big_cfg (host logic of csrc/gemm_big_x3.hip) at the shapes the BASELINE configs issue, as measured in EXPERIMENTS round 5
+    section 6: the LSTM weight-gradient groups, predict's weight gradient, the XE vocabulary projection and the paired AoA Q/K/V
+    projection on 256 x 256 tiles (1); the dgrad products over all steps and the AoA linear on 128 x 128 three per CU (4); beam-search
+    steps and small outputs on the 128 x 128 two-barrier kernel (0)."""
+    from simpleimagecaptionzoo_amd._lib import lib
+    f = lib().icz_gemm_big_cfg_for
+    NT, NN, TN = 0, 1, 2
+    assert f(TN, 4096, 4096, 1280, 1) == 1 and f(TN, 4096, 3072, 1280, 1) == 1 and f(TN, 10112, 1024, 1280, 1) == 1
+    assert f(TN, 4096, 2048, 1280, 1) == 0 and f(TN, 4096, 1024, 1280, 1) == 0
+    assert f(NN, 1280, 1024, 10112, 8) == 4 and f(NN, 1280, 1024, 4096, 4) == 4 and f(NN, 640, 1024, 10112, 9) == 0
+    assert f(NT, 640, 4096, 4096, 3) == 0 and f(NT, 320, 4096, 3072, 5) == 0 and f(NT, 640, 10112, 1024, 1) == 0
+    assert f(NT, 1280, 10112, 1024, 1) == 1 and f(NT, 4608, 3072, 1024, 1) == 1
+    assert f(NT, 2304, 2048, 2048, 1) == 4 and f(NT, 4608, 2048, 2048, 1) == 4 and f(NT, 2304, 1024, 1024, 1) == 0
+    assert f(5, 1, 1, 1, 1) == -1
