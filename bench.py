@@ -351,11 +351,11 @@ def _profile_path(suffix):
     """The newest committed profiles/rNN_<suffix> (`suffix` may hold a `*` for a version number: the highest one wins)."""
     import glob
     import re
-    for rnd in ("r05", "r04", "r03", "r02"):
+    for rnd in ("r06", "r05", "r04", "r03", "r02"):
         hits = glob.glob(os.path.join(ROOT, "profiles", "%s_%s" % (rnd, suffix)))
         if hits:
             return max(hits, key=lambda q: [int(x) for x in re.findall(r"\d+", os.path.basename(q))])
-    return os.path.join(ROOT, "profiles", "r05_" + suffix)
+    return os.path.join(ROOT, "profiles", "r06_" + suffix)
 
 
 def trace_avg_us(kernel):
@@ -649,6 +649,10 @@ def main():
     ap.add_argument("--no-h2d", action="store_true", help="skip the PCIe-inclusive / cold-cache / secondary measurements")
     ap.add_argument("--headline-only", action="store_true", help="timed region + JSON line, nothing else (used by the fp32-GEMM child run)")
     ap.add_argument("--cpu-rows", type=int, default=64)
+    ap.add_argument("--dp-pieces", type=int, choices=(1, 4), default=4,
+                    help="N > 1: how the timed region exchanges gradients.  4 (default): the backward pass in four captured pieces, each gradient "
+                         "group's all-reduce started from the library's callback beside the rest; 1: ONE captured backward and one all-reduce of "
+                         "the flat buffer behind it.  Either way the line's `dp_overlap` carries both legs of the same invocation")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = args.no_h2d = True
@@ -662,6 +666,16 @@ def main():
     # ICZ_REHEARSE_ONE_GPU=1 (development only): every rank on cuda:0 with the gloo backend, to rehearse the N > 1 control
     # flow (normaliser all-reduce, gradient hook, barriers, rank-0 JSON) on a one-GPU box; the numbers mean nothing then
     rehearse = os.environ.get("ICZ_REHEARSE_ONE_GPU") == "1"
+    # N > 1 over RCCL: have rank 0's RCCL say what it chose (rings / trees, protocol, channels) into a file the line quotes
+    nccl_log = None
+    if (int(os.environ.get("WORLD_SIZE", "1")) > 1 or os.environ.get("ICZ_BENCH_NCCL_INFO") == "1") and not rehearse \
+            and os.environ.get("ICZ_BENCH_NCCL_INFO") != "0":
+        import tempfile
+        nccl_log = os.path.join(tempfile.gettempdir(), "icz_bench_rccl_rank%s_%d.log" % (os.environ.get("RANK", "0"), os.getpid()))
+        os.environ.setdefault("NCCL_DEBUG", "INFO")
+        os.environ.setdefault("NCCL_DEBUG_SUBSYS", "INIT,GRAPH,TUNING,ENV")
+        os.environ.setdefault("NCCL_DEBUG_FILE", nccl_log)
+        nccl_log = os.environ["NCCL_DEBUG_FILE"]
     rank, world, local = icz_dist.init_from_env("gloo" if rehearse else None)
     if rehearse:
         local = 0
@@ -692,6 +706,7 @@ def main():
     def run(loader):
         eng.SCST_training_epoch(loader, opt, None, tqdm_visible=False)
 
+    eng.dp_overlap = args.dp_pieces == 4
     run([batches[i] for i in range(args.warmup)] + [batches[0]])      # graph capture, allocator warm-up
     torch.cuda.synchronize()
     ranks_seen = world
@@ -736,17 +751,19 @@ def main():
                 torch.distributed.all_reduce(tt, op=torch.distributed.ReduceOp.MAX)
                 ph = dict(zip(names, tt.tolist()))
             return d, ph
-        d_on, phases = phase_pass()
-        phases["ms_per_step_with_events"] = d_on / args.steps * 1e3
+        d_head, phases = phase_pass()                           # the timed region's own mode (--dp-pieces)
+        phases["ms_per_step_with_events"] = d_head / args.steps * 1e3
         if world > 1:
-            eng.dp_overlap = False
-            run(batches[:2])                                  # the un-hooked backward is another captured graph: warm it
-            d_off, ph_off = phase_pass()
-            eng.dp_overlap = True
+            head_on = eng.dp_overlap
+            eng.dp_overlap = not head_on
+            run(batches[:2])                                  # the other backward is another set of captured graphs: warm it
+            d_other, ph_other = phase_pass()
+            eng.dp_overlap = head_on
             run(batches[:2])
+            (d_on, ph_on), (d_off, ph_off) = ((d_head, phases), (d_other, ph_other)) if head_on else ((d_other, ph_other), (d_head, phases))
             dp_overlap = {"on_ms": d_on / args.steps * 1e3, "off_ms": d_off / args.steps * 1e3,
-                          "allreduce_exposed_on_ms": phases["allreduce_exposed"], "allreduce_exposed_off_ms": ph_off["allreduce_exposed"],
-                          "backward_on_ms": phases["backward"], "backward_off_ms": ph_off["backward"],
+                          "allreduce_exposed_on_ms": ph_on["allreduce_exposed"], "allreduce_exposed_off_ms": ph_off["allreduce_exposed"],
+                          "backward_on_ms": ph_on["backward"], "backward_off_ms": ph_off["backward"],
                           "note": "on: each gradient group's all-reduce starts from the library's gradient-ready callback, beside the rest of "
                                   "the backward pass (engine.py: _reduce_grads_begin); off (ICZ_DP_OVERLAP=0): ONE all-reduce of the flat "
                                   "gradient buffer behind it.  allreduce_exposed = GPU time between the end of the backward pass and the start "
@@ -836,20 +853,113 @@ def main():
     }
     if allreduce_ms is not None:
         out["grad_allreduce_ms"] = allreduce_ms
+    if world > 1:
+        out["dp_pieces"] = args.dp_pieces
+        out["config"]["dp_pieces"] = args.dp_pieces
+    if nccl_log:
+        out["rccl"] = rccl_info(nccl_log)
     if phases is not None:
         out["phases_ms"] = phases
     if dp_overlap is not None:
         out["dp_overlap"] = dp_overlap
+    roofline_failure = None
     if not args.headline_only:
-        out["roofline"] = roofline_entry(avg_us.value, pair_us.value, bpl.value, fpl.value, nl.value)
+        roof = out["roofline"] = roofline_entry(avg_us.value, pair_us.value, bpl.value, fpl.value, nl.value)
         if world == 1 and not args.no_h2d:
-            out["roofline"]["level"] = weight_stream_level(device)
+            roof["level"] = weight_stream_level(device)
+        # what THIS box streams from HBM (the 8 TB/s of `peak` is the specification; MI355X_MICROARCH.md measures 6.29 TB/s for a copy)
+        pm = stream_rate(device)
+        roof["peak_measured"] = pm
+        if pm.get("value"):
+            roof["frac_of_measured"] = roof["hbm_gbs"] / pm["value"]
         out["roofline_small_kernels"] = small_kernel_rooflines(small, pair_us.value, B)
+        # the quantity north_star names -- the attention + LSTM decode step -- next to the dominant kernel's numbers
+        ds = extras.get("roofline_decode_step")
+        if ds:
+            roof["step_us"], roof["step_frac"], roof["step_bytes"] = ds["us_per_step"], ds["frac"], ds["bytes_per_step"]
+            roof["step_target_frac"] = 0.60
+            if pm.get("value"):
+                roof["step_frac_of_measured"] = ds["achieved"] / pm["value"]
+            roof["step_note"] = ("step_* = one greedy decode step of %d rows, the attention + LSTM step of north_star (roofline_decode_step below: "
+                                 "20 steps replayed as one hipGraph, wall clock / 20; SURVEY.md 8d bytes W + b S); `frac` / `achieved` above are "
+                                 "the dominant kernel's" % B)
+        # `frac` (live) must agree with the committed rocprofv3 trace of the same command: a bench whose two numbers part is not evidence
+        ct = roof.get("committed_trace")
+        tol = float(os.environ.get("ICZ_BENCH_ROOFLINE_TOL", "0.10"))
+        if ct and ct.get("frac"):
+            dev = abs(roof["frac"] - ct["frac"]) / ct["frac"]
+            roof["agreement_with_committed_trace"] = {"relative_deviation": dev, "tolerance": tol, "ok": dev <= tol}
+            if dev > tol:
+                roofline_failure = ("bench.py: roofline.frac %.3f (live event pairs) and the committed trace's %.3f (%s) differ by %.1f %% > %.0f %%: "
+                                    "re-profile (tools/r6_profiles.sh) or find out which of the two is wrong"
+                                    % (roof["frac"], ct["frac"], ct["source"], dev * 100, tol * 100))
     out.update(extras)
     if not args.no_cpu_baseline and world == 1:       # rank 0 at N = 1 only: the N > 1 runs share the host with the other ranks
         out["cpu_baseline"] = cpu_baseline(eng, batches[0], words, df, min(args.cpu_rows, B))
         out["vs_cpu_baseline_same_run"] = value / out["cpu_baseline"]["value"]
     print(json.dumps(out))
+    sys.stdout.flush()
+    if roofline_failure:        # the line above is complete; the exit status says its roofline is not to be trusted
+        sys.stderr.write(roofline_failure + "\n")
+        raise SystemExit(4)
+
+
+def rccl_info(path, keep=12):
+    """What rank 0's RCCL reported under NCCL_DEBUG=INFO (NCCL_DEBUG_FILE = `path`): channel count, the rings / trees it built, the
+    algorithm / protocol it tuned each all-reduce size to, and the environment overrides it saw.  Best effort: RCCL's wording differs
+    from release to release, so the matched lines are quoted next to what was parsed from them."""
+    import re
+    info = {"file": path, "channels": None, "algo_proto": {}, "env": [], "lines": []}
+    try:
+        text = open(path, errors="replace").read().splitlines()
+    except OSError as e:
+        info["error"] = repr(e)
+        return info
+    info["n_lines"] = len(text)
+    chans = set()
+    algos = {0: "Tree", 1: "Ring", 2: "CollnetDirect", 3: "CollnetChain", 4: "NVLS", 5: "NVLSTree"}
+    protos = {0: "LL", 1: "LL128", 2: "Simple"}
+    for ln in text:
+        body = ln.split("NCCL INFO", 1)[-1].strip()
+        m = re.search(r"Channel (\d+)/(\d+)", body)
+        if m:
+            chans.add(int(m.group(2)))
+        m = re.search(r"(\d+) coll channels", body)
+        if m:
+            info["coll_channels"] = int(m.group(1))
+        m = re.search(r"(\w+): (\d+) Bytes -> Algo (\d+) proto (\d+)", body)
+        if m:
+            key = "%s %s B" % (m.group(1), m.group(2))
+            info["algo_proto"][key] = "%s / %s" % (algos.get(int(m.group(3)), m.group(3)), protos.get(int(m.group(4)), m.group(4)))
+        if re.search(r"NCCL_\w+ set by environment|RCCL_\w+ set", body):
+            info["env"].append(body[:160])
+        if re.search(r"Init COMPLETE|Connected all (rings|trees)|nChannels|coll channels|Trees \[|Ring \d+ :|Using network|xgmi|XGMI|RCCL version|NCCL version", body) \
+                and len(info["lines"]) < keep:
+            info["lines"].append(body[:200])
+    if chans:
+        info["channels"] = max(chans)
+    return info
+
+
+def stream_rate(device, mib=1024, reps=10):
+    """The box's own HBM read rate: icz_prof_stream_rate over a 1 GiB buffer (4 x the Infinity Cache), 10 launches."""
+    from simpleimagecaptionzoo_amd._lib import lib
+    try:
+        buf = torch.empty(mib * 1024 * 1024 // 4, device=device).normal_()
+        gbs = C.c_double()
+        st = torch.cuda.current_stream(device)
+        best = 0.0
+        for _ in range(3):
+            rc = lib().icz_prof_stream_rate(C.c_void_p(buf.data_ptr()), C.c_size_t(buf.numel() * 4), reps, C.c_void_p(st.cuda_stream), C.byref(gbs))
+            if rc != 0:
+                raise RuntimeError(lib().icz_last_error().decode())
+            best = max(best, gbs.value)
+        return {"value": best, "unit": "GB/s", "frac_of_peak": best / HBM_PEAK_GBS,
+                "what": "read-only stream over %d MiB (4 x the 256 MB Infinity Cache), 2048 workgroups, sixteen 16-byte non-temporal loads in "
+                        "flight per lane, best of 3 x %d launches (icz_prof_stream_rate): what this box's HBM delivers to a kernel that does "
+                        "nothing else" % (mib, reps)}
+    except Exception as e:
+        return {"error": repr(e)}
 
 
 def small_kernel_rooflines(small, empty_pair, B):

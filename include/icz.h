@@ -426,6 +426,10 @@ int icz_prof_end(double* avg_us, double* bytes_per_launch, double* flops_per_lau
  * 3 = one LSTMCell's pointwise part (:82-83).  icz_kprof_end synchronises and reports the average pair time [us] and the count. */
 int icz_kprof_begin(void);
 int icz_kprof_end(int32_t group, double* avg_us, long long* pairs);
+/* What THIS box streams from HBM (bench.py's roofline.peak_measured, beside the 8 TB/s specification): a read-only kernel over
+ * `buf` (`bytes` a multiple of 65536, at least 64 MiB; take it well above the 256 MB Infinity Cache), 64 KB chunks dealt to workgroups, sixteen
+ * 16-byte loads in flight per lane, `reps` launches timed with one HIP event pair on `stream`; *gbs = bytes * reps / time. */
+int icz_prof_stream_rate(const void* buf, size_t bytes, int32_t reps, void* stream, double* gbs);
 
 #ifdef __cplusplus
 }

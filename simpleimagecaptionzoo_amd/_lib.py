@@ -182,6 +182,7 @@ def lib():
         "icz_prof_end": (C.c_int, [C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
         "icz_kprof_begin": (C.c_int, []),
         "icz_kprof_end": (C.c_int, [i32, C.POINTER(C.c_double), C.POINTER(C.c_longlong)]),
+        "icz_prof_stream_rate": (C.c_int, [vp, C.c_size_t, i32, vp, C.POINTER(C.c_double)]),
         "icz_adam_clamp_multi": (C.c_int, [i32, C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(vp), C.POINTER(i64), f32, f32, i32, vp]),
         "icz_gemm_f32": (C.c_int, [i32, vp, i32, vp, i32, vp, vp, i32, i32, i32, i32, i32, vp, C.c_size_t, vp]),
         "icz_gemm_workspace_floats": (C.c_size_t, [i32, i32]),

@@ -449,9 +449,15 @@ int icz_aoa_set_option(icz_aoa_t* h, const char* name, int32_t value) {
     ICZ_REQUIRE(h && name, "icz_aoa_set_option: null argument");
     Aoa* n = reinterpret_cast<Aoa*>(h);
     if (strcmp(name, "graphs") == 0) { n->use_graphs = value != 0; return ICZ_OK; }
-    if (strcmp(name, "early_out") == 0) { n->early_out = value != 0; n->gc.clear(); return ICZ_OK; }
-    if (strcmp(name, "refine_pair") == 0) { n->pair_refine = value != 0; n->gc.clear(); return ICZ_OK; }
-    if (strcmp(name, "mha_mfma") == 0) { n->mha_mfma = value != 0; n->gc.clear(); return ICZ_OK; }
+    const bool eo = strcmp(name, "early_out") == 0, rp = strcmp(name, "refine_pair") == 0, mm = strcmp(name, "mha_mfma") == 0;
+    if (eo || rp || mm) {
+        ICZ_CHECK_HIP(hipDeviceSynchronize());      // a replay of a graph about to be destroyed may still be in flight
+        n->gc.clear();
+        if (eo) n->early_out = value != 0;
+        if (rp) n->pair_refine = value != 0;
+        if (mm) n->mha_mfma = value != 0;
+        return ICZ_OK;
+    }
     set_error("icz_aoa_set_option: unknown option '%s'", name);
     return ICZ_ERR_INVALID;
 }

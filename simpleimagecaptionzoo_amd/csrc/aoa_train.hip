@@ -228,6 +228,7 @@ int Aoa::ensure_train(int Bq, int Tq) {
         for (void* p : tallocs) (void)hipFree(p);
         tallocs.clear();
         tcap_B = tcap_T = 0; mode = 0;
+        gc.clear();     // the captured rollout / backward graphs carry the freed addresses in their kernel arguments
     }
     struct Scope { bool& f; Scope(bool& x) : f(x) { f = true; } ~Scope() { f = false; } } scope(alloc_train);
     const size_t B = Bq, T = Tq, Hd = dims.Hd, E = dims.E, R = dims.R, NH = dims.NH;
@@ -429,7 +430,8 @@ int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* lo
     // with a DP callback the hook must fire on every call: eager launches (a replayed graph would not call it)
     if (!use_graphs || lens || grad_cb || aoa_explicit_rng(rng)) return sample_backward_impl(reward, *G, loss_out, msum_out, st);
     std::vector<uintptr_t> key = {2, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)msum_out, (uintptr_t)cur_B, (uintptr_t)cur_T, (uintptr_t)cur_R,
-                                  (uintptr_t)cur_seq, (uintptr_t)cur_logp};
+                                  (uintptr_t)cur_seq, (uintptr_t)cur_logp,
+                                  (uintptr_t)bank[0].refined, (uintptr_t)bank[0].Kd, (uintptr_t)bank[1].refined, (uintptr_t)bank[1].Kd, (uintptr_t)bank[1].Vd, (uintptr_t)cur_bank};      // paired-refine banks (rollouts) or the handle's own (sample)
     const float* const* gp = reinterpret_cast<const float* const*>(G);
     for (size_t i = 0; i < sizeof(icz_aoa_params) / sizeof(float*); ++i) key.push_back((uintptr_t)gp[i]);
     const icz_aoa_params Gc = *G;

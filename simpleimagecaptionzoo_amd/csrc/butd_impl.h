@@ -204,7 +204,7 @@ struct GraphCache {
     int run(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& fn) {
         ++tick;
         std::vector<uintptr_t> key = key_in;
-        key.push_back(gemm_prof_on() ? 1 : 0);
+        key.push_back((gemm_prof_on() ? 1 : 0) + 2 * (uintptr_t)(gemm_big_switch() + 2));      // the tile-configuration override changes the captured launches
         for (auto& e : graphs)
             if (e.key == key) {
                 e.last_use = tick;
@@ -242,7 +242,7 @@ int Butd::run_cached(const std::vector<uintptr_t>& key_in, hipStream_t st, F&& f
     ++tick;
     std::vector<uintptr_t> key = key_in;
     key.push_back((concurrent ? 1 : 0) + (early_out ? 2 : 0) + 4 * merge_small + (small_nt ? 256 : 0));          // flags that change the captured launch sequence
-    key.push_back(gemm_prof_on() ? 1 : 0);
+    key.push_back((gemm_prof_on() ? 1 : 0) + 2 * (uintptr_t)(gemm_big_switch() + 2));      // the tile-configuration override changes the captured launches
     for (auto& e : graphs)
         if (e.key == key) {
             e.last_use = tick;

@@ -302,7 +302,8 @@ int Butd::sample_backward(const float* reward, const icz_butd_params* G, float* 
     const bool explicit_rng = rng.uniforms || rng.emb_mask || rng.att_mask || rng.out_mask;
     if (explicit_rng || !use_graphs) return sample_backward_impl(reward, *G, loss_out, mask_sum_out, st);
     std::vector<uintptr_t> key = {3, (uintptr_t)reward, (uintptr_t)loss_out, (uintptr_t)mask_sum_out, (uintptr_t)cur_B, (uintptr_t)cur_T,
-                                  (uintptr_t)cur_feats, (uintptr_t)cur_seq, (uintptr_t)cur_logp};
+                                  (uintptr_t)cur_feats, (uintptr_t)cur_seq, (uintptr_t)cur_logp,
+                                  (uintptr_t)cur_rows, (uintptr_t)cur_row0};      // merged / unmerged rollouts share the caller's buffers: slot strides differ
     const float* const* gp = reinterpret_cast<const float* const*>(G);
     for (size_t i = 0; i < sizeof(icz_butd_params) / sizeof(float*); ++i) key.push_back((uintptr_t)gp[i]);
     const icz_butd_params Gc = *G;

@@ -407,10 +407,11 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
 //   NT 1280 x 10112 x 1024: 172 / 139 / 175    NT 2304 x 2048 x 2048: 146 / 139 (2) / 132 (4)   NT 2304 x 1024 x 1024: 47 / 58 (4) / 50 (4)
 //   NT 640 x 4096 x 4096 (beam step): 132 (3) / 142 (5) / 132 (3);  in beam search itself the three-per-CU kernel is 1 - 4 % slower
 int gemm_big_cfg(GemmLayout layout, const GemmArgs& a) {
+    for (int s = 0; s < a.nseg; ++s)
+        if (a.seg[s].K % BX_KS) return 0;          // also under a forced configuration: an ineligible shape falls back to the 128 x 128 kernel
+    if (layout == GEMM_TN && a.nseg != 1) return 0;
     const int sw = gemm_big_switch();
     if (sw >= 0) return sw;
-    for (int s = 0; s < a.nseg; ++s)
-        if (a.seg[s].K % BX_KS) return 0;
     const int t128 = cdiv(a.M, 128) * cdiv(a.N, 128), t256 = cdiv(a.M, 256) * cdiv(a.N, 256);
     const int rounds = cdiv(t256 * a.nsplit, 256);
     const double fill = (double)t256 * a.nsplit / (256.0 * rounds);

@@ -371,7 +371,7 @@ def test_bench_reads_its_committed_profiles_for_both_gemm_kernels():
     a = bench.aoa_roofline(64)
     assert "error" not in a and 0.2 < a["frac"] < 0.7 and 10 <= a["launches_per_step"] <= 30, a
     us, src = bench.trace_avg_us("gemm_resident_x3_kernel")
-    assert us and 10 < us < 30 and src.startswith("profiles/r05_")
+    assert us and 10 < us < 30 and src.startswith("profiles/r0")
 
 
 def test_routing_of_the_many_row_gemms_at_the_baseline_shapes():
@@ -389,3 +389,30 @@ def test_routing_of_the_many_row_gemms_at_the_baseline_shapes():
     assert f(NT, 1280, 10112, 1024, 1) == 1 and f(NT, 4608, 3072, 1024, 1) == 1
     assert f(NT, 2304, 2048, 2048, 1) == 4 and f(NT, 4608, 2048, 2048, 1) == 4 and f(NT, 2304, 1024, 1024, 1) == 0
     assert f(5, 1, 1, 1, 1) == -1
+
+
+def test_bench_parses_what_rccl_says_about_its_rings(tmp_path):
+    """bench.py --gpus N quotes rank 0's RCCL choices (NCCL_DEBUG=INFO into NCCL_DEBUG_FILE): channel count, algorithm / protocol per
+    all-reduce size, environment overrides.  The wording below is NCCL 2.2x's; unknown lines are ignored, a missing file is an error
+    entry -- never an exception (the headline must not depend on it)."""
+    import bench
+    log = tmp_path / "rccl.log"
+    log.write_text("\n".join([
+        "box:77:101 [0] NCCL INFO NCCL_DEBUG_SUBSYS set by environment to INIT,GRAPH,TUNING,ENV",
+        "box:77:101 [0] NCCL INFO RCCL version 2.22.3+hip7.0",
+        "box:77:101 [0] NCCL INFO Channel 00/16 :    0   1   2   3   4   5   6   7",
+        "box:77:101 [0] NCCL INFO Channel 15/16 :    0   7   6   5   4   3   2   1",
+        "box:77:101 [0] NCCL INFO Trees [0] 1/-1/-1->0->-1 [1] 1/-1/-1->0->-1",
+        "box:77:101 [0] NCCL INFO Connected all rings",
+        "box:77:101 [0] NCCL INFO 16 coll channels, 0 collnet channels, 0 nvls channels, 16 p2p channels, 2 p2p channels per peer",
+        "box:77:101 [0] NCCL INFO comm 0x55 rank 0 nranks 8 cudaDev 0 busId 5000 commId 0xabc - Init COMPLETE",
+        "box:77:101 [0] NCCL INFO AllReduce: 166395904 Bytes -> Algo 1 proto 2 time 1503.2",
+        "box:77:101 [0] NCCL INFO AllReduce: 4 Bytes -> Algo 0 proto 0 time 12.1",
+        "garbage that matches nothing",
+    ]))
+    r = bench.rccl_info(str(log))
+    assert r["channels"] == 16 and r["coll_channels"] == 16
+    assert r["algo_proto"] == {"AllReduce 166395904 B": "Ring / Simple", "AllReduce 4 B": "Tree / LL"}
+    assert len(r["env"]) == 1 and any("Init COMPLETE" in l for l in r["lines"]) and r["n_lines"] == 11
+    miss = bench.rccl_info(str(tmp_path / "nope.log"))
+    assert "error" in miss and miss["channels"] is None
