@@ -547,7 +547,7 @@ def cpu_baseline(eng, batch, words, df, rows):
               "reward_max_abs_err_on_equal_rows": float(np.abs(rew - g_rew)[same].max()) if same.any() else None,
               "loss_abs_err": abs(float(loss.item()) - g_loss), "all_rows_equal": bool(same.all()), "differing_sampled_rows": differing,
               "note": "device step vs CPU oracle on the same inputs and injected randomness; a row can differ where two logits / a "
-                      "CDF boundary are within fp32 rounding (tests/test_gpu_round2.py bounds and excuses those); the loss compares "
+                      "CDF boundary are within fp32 rounding (tests/test_gpu_butd_fullwidth.py bounds and excuses those); the loss compares "
                       "whole batches, so it carries any differing row"}
     torch.set_num_threads(default_threads)
     return {"value": rows / dt, "unit": "captions/s", "cores": best, "kind": "port",

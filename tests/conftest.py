@@ -11,6 +11,8 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "gpu_slow: GPU tests that start child processes with their own torch import (bench.py rehearsals, the 5-rank "
+                                       "Engine run): part of -m gpu; deselect with -m 'gpu and not gpu_slow' for a quick pass")
 
 
 @pytest.fixture(scope="session")

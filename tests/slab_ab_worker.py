@@ -1,4 +1,4 @@
-"""Child process of tests/test_gpu_round2.py::test_predict_slab_path_matches_the_unsplit_gemm: decodes 64 rows at full width
+"""Child process of tests/test_gpu_gemm.py::test_predict_slab_path_matches_the_unsplit_gemm: decodes 64 rows at full width
 with BUTD, AoA and NIC (greedy + Philox-seeded sampled rollout + REINFORCE gradients of the output layer) and writes the results to
 an .npz -- together with the explicit uniforms of the draws and the logits of a teacher-forced replay of the sampled rows (same
 Philox dropout streams), so that the parent can hold a differing draw to the CDF-edge criterion.  The parent runs it twice, with ICZ_PREDICT_SLABS=1 (default: the vocabulary projection leaves split-K slabs that

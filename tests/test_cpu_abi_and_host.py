@@ -348,7 +348,7 @@ def test_bench_launcher_reports_dead_ranks_instead_of_hanging():
     import sys
     import time
     if __import__("torch").cuda.is_available():
-        pytest.skip("needs a box without a GPU (the GPU variant is tests/test_gpu_round3.py::test_bench_launcher_kills_the_other_ranks_when_one_dies)")
+        pytest.skip("needs a box without a GPU (the GPU variant is tests/test_gpu_bench_ranks.py::test_bench_launcher_kills_the_other_ranks_when_one_dies)")
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["ICZ_BENCH_RANK_TIMEOUT"] = "120"

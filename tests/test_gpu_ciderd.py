@@ -233,3 +233,73 @@ def test_reward_scorer_at_coco_scale_document_frequency_table():
     want = oc.self_critical_reward(gen, greedy, refs, list(range(B)), dict(enumerate(words)), oc.DocFreq(df, 113287))
     assert np.array_equal(r.cpu().numpy(), want)
     assert np.abs(want).max() > 0
+
+
+# ---- at the benchmark width / handle behaviour (moved here from the per-round files in round 6)
+from _fullwidth import (V)  # noqa: E402
+
+
+def test_ciderd_at_bench_scale_bit_exact():
+    """64 images, V = 10102, the 2000-image document-frequency table of the bench (135 k n-gram keys): scores float64
+    bit-exact, reward float32 bit-exact.  Hypotheses are perturbed references (many n-gram matches, clipping, length
+    differences), empty / <pad> rows and pure noise."""
+    from oracle import ciderd as oc
+    from simpleimagecaptionzoo_amd.ciderd import CiderDReward
+    from simpleimagecaptionzoo_amd.synth import document_frequency, synthetic_references
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    B, T = 64, 20
+    vocab = synthetic_vocab(V)
+    words = [vocab.ix2word[i] for i in range(V)]
+    w2i = vocab.word2ix
+    dfd = document_frequency(synthetic_references(2000, words, seed=0))
+    assert len(dfd["document_frequency"]) > 50000
+    refs = synthetic_references(B, words, seed=77)
+    gts = {1000 + i: refs[i] for i in range(B)}
+    ids = list(gts.keys())
+    rs = np.random.RandomState(5)
+    gen = np.zeros((B, T), dtype=np.int64)
+    gre = np.zeros((B, T), dtype=np.int64)
+    for b in range(B):
+        for arr, is_greedy in ((gen, False), (gre, True)):
+            mode = rs.randint(0, 5)
+            base = [w2i[w] for w in refs[b][rs.randint(0, len(refs[b]))].split()]
+            if mode == 0:                     # a reference verbatim
+                row = base
+            elif mode == 1:                   # a reference with a few words replaced and a repeated tail
+                row = [x if rs.rand() > 0.25 else int(rs.randint(4, V)) for x in base] + base[-2:]
+            elif mode == 2:                   # two references spliced
+                other = [w2i[w] for w in refs[b][rs.randint(0, len(refs[b]))].split()]
+                row = base[:len(base) // 2] + other[len(other) // 2:]
+            elif mode == 3:                   # noise
+                row = rs.randint(4, V, size=rs.randint(1, T)).tolist()
+            else:                             # empty: sampled channel -> "<pad>" sentence, greedy channel -> ""
+                row = []
+            row = row[:T - 1]
+            arr[b, :len(row)] = row
+            if is_greedy and len(row) < T:
+                arr[b, len(row)] = 2
+    scorer = CiderDReward(dfd["document_frequency"], dfd["ref_len"], w2i, "cuda")
+    reward, scores = scorer.reward(torch.tensor(gen), torch.tensor(gre), gts, ids, return_scores=True)
+    docfreq = oc.DocFreq(dfd["document_frequency"], dfd["ref_len"])
+    ix2word = dict(enumerate(words))
+    hyps = [oc.sampled_sentence(gen[b], ix2word) for b in range(B)] + [oc.greedy_sentence(gre[b], ix2word) for b in range(B)]
+    want = oc.ciderd_scores(hyps, [gts[i] for i in ids] * 2, docfreq)
+    got = scores.cpu().numpy()
+    assert np.array_equal(got, np.asarray(want, dtype=np.float64)), np.abs(got - np.asarray(want)).max()
+    assert float(np.max(got)) > 1.0          # the cases do match references
+    w_reward = oc.self_critical_reward(gen, gre, gts, ids, ix2word, docfreq)
+    assert np.array_equal(reward.cpu().numpy(), w_reward)
+    # a second batch in another order, with images the store already holds and new ones: store rows, not batch positions
+    refs2 = synthetic_references(8, words, seed=78)
+    gts2 = dict(gts)
+    gts2.update({5000 + i: refs2[i] for i in range(8)})
+    ids2 = [ids[5], 5003, ids[0], 5000, ids[63], 5007]
+    sel = [5, 0, 63]
+    g2 = np.stack([gen[5], gen[1], gen[0], gen[2], gen[63], gen[3]])
+    r2 = np.stack([gre[5], gre[1], gre[0], gre[2], gre[63], gre[3]])
+    _, sc2 = scorer.reward(torch.tensor(g2), torch.tensor(r2), gts2, ids2, return_scores=True)
+    hyps2 = [oc.sampled_sentence(x, ix2word) for x in g2] + [oc.greedy_sentence(x, ix2word) for x in r2]
+    want2 = oc.ciderd_scores(hyps2, [gts2[i] for i in ids2] * 2, docfreq)
+    assert np.array_equal(sc2.cpu().numpy(), np.asarray(want2, dtype=np.float64))
+    assert sc2.cpu().numpy()[0] == got[sel[0]]
+    scorer.close()

@@ -12,7 +12,7 @@ import pytest
 pytestmark = pytest.mark.gpu
 
 
-@pytest.mark.parametrize("world", [2, 5])
+@pytest.mark.parametrize("world", [2, pytest.param(5, marks=pytest.mark.gpu_slow)])
 def test_ranks_reproduce_the_single_process_reference_steps(world):
     import socket
     here = os.path.dirname(os.path.abspath(__file__))

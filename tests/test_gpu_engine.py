@@ -313,3 +313,146 @@ def test_fused_adam_state_dict_roundtrip():
     ref = torch.optim.Adam([{"params": [torch.nn.Parameter(p.data.clone()) for p in b], "lr": 1e-3}], lr=1e-3)
     ref.load_state_dict(sd)                      # same key layout as torch's own
     assert ref.state_dict()["param_groups"][0]["params"] == [0, 1]
+
+
+# ---- at the benchmark width / handle behaviour (moved here from the per-round files in round 6)
+from _fullwidth import (feats_from_seed)  # noqa: E402
+
+
+def test_butdspatial_engine_xe_step_runs_and_matches_handle():
+    """BUTDSpatial_Eng (49 grid cells) through Engine.training_epoch: one XE step = the handle's gradients -> clamp 0.1 -> Adam."""
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import BUTDSpatial_Eng, init_optimizer
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    Vs, Hs, Ds = 203, 64, 128
+    eng = BUTDSpatial_Eng({"model_type": "BUTDSpatial", "atten_dim": Hs, "embed_dim": Hs, "hidden_dim": Hs, "enc_dim": Ds, "enc_img_size": 7},
+                          "SYN", synthetic_vocab(Vs), data_dir="/tmp/", device="cuda:0", max_batch=8)
+    assert eng.model.dims["R"] == 49
+    B = 6
+    torch.manual_seed(1)
+    feats = torch.relu(torch.randn(B, 49, Ds)).numpy()
+    rs = np.random.RandomState(2)
+    lens = sorted(rs.randint(5, 12, size=B).tolist(), reverse=True)
+    caps = torch.zeros(B, max(lens), dtype=torch.int64)
+    for b, n in enumerate(lens):
+        caps[b, 0] = 1
+        caps[b, 1:n - 1] = torch.from_numpy(rs.randint(4, Vs, size=n - 2))
+        caps[b, n - 1] = 2
+    supp = tuple({"bu_feat": feats[i], "bu_bbox": np.zeros((49, 4), np.float32)} for i in range(B))
+
+    class Crit:
+        smoothing = 0.1
+    before = {k: v.detach().clone() for k, v in eng.model.state_dict().items()}
+    # expected update from the handle's own gradients (same seed -> same Philox dropout)
+    hd = eng.model._handle()
+    vi = eng.modify_visual_inputs(None, supp)
+    hd.xe_forward(vi["bu_feats"], caps, [n - 1 for n in lens], make_rng(99), train=True)
+    grads = hd.new_grads()
+    hd.xe_backward(grads, 0.1)
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 4e-4}), 4e-4)
+    losses = eng.training_epoch([(tuple(range(B)), None, caps, lens, supp)], opt, Crit(), tqdm_visible=False, rngs=[make_rng(99)])
+    assert np.isfinite(losses[0].item())
+    after = eng.model.state_dict()
+    for k, g in grads.items():
+        gc = g.clamp(-0.1, 0.1)
+        # first Adam step: p -= lr * g / (|g| + eps)
+        want = before["decoder." + k] - 4e-4 * gc / (gc.abs() + 1e-8)
+        np.testing.assert_allclose(after["decoder." + k].cpu().numpy(), want.cpu().numpy(), atol=2e-6, err_msg=k)
+
+
+def test_scst_epoch_returns_one_loss_per_step(golden_dir):
+    """with graphs on, the handle's loss is one persistent buffer; the Engine must hand back per-step values."""
+    import test_gpu_engine as tge
+    from simpleimagecaptionzoo_amd.engine import init_optimizer
+    g, fx = tge._load(golden_dir)
+    eng, _ = tge._engine(g, fx)
+    B, R_, D_ = [int(x) for x in g["dims"][:3]]
+    from synth import feats_from_seed
+    opt = init_optimizer("Adam", eng.model.get_param_groups({"lr": 2e-5}), 2e-5)
+    batches = []
+    for s in range(2):
+        pre = "rl%d_" % s
+        feats = feats_from_seed(int(g[pre + "feats_seed"]), B, R_, D_)
+        ids = tuple(100 * s + int(i) for i in g[pre + "img_ids"])
+        gts = {100 * s + int(k): v for k, v in fx[pre + "gts"].items()}
+        batches.append((ids, None, gts, tge._supp(feats)))
+    losses = eng.SCST_training_epoch(batches * 2, opt, None, tqdm_visible=False)
+    vals = [l.item() for l in losses]
+    assert len(vals) == 4 and len({l.data_ptr() for l in losses}) == 4 and len(set(vals)) > 1
+
+
+def test_eval_test_image_returns_the_reference_attention_maps(golden_dir):
+    """Engine.py:325,339: eval_test_image -> (caption, [alphas]).  Greedy and beam-search alphas against what the reference's
+    sample / beam_search_sample returned (BUTD_Model.py:178-189, :309-317)."""
+    from test_gpu_butd import load, sd_of
+    from simpleimagecaptionzoo_amd.captioner import BUTDDetection_Captioner
+    from simpleimagecaptionzoo_amd.vocab import synthetic_vocab
+    g = load(golden_dir, "butd_dec_tiny")
+    B, R_, D_, H_, E_, A_, V_ = [int(x) for x in g["dims"]]
+    cap = BUTDDetection_Captioner(A_, E_, H_, V_, device="cuda:0", enc_dim=D_, num_regions=R_, max_batch=4).cuda()
+    cap.load_state_dict({"decoder." + k: torch.tensor(v) for k, v in sd_of(g).items()})
+    cap.eval()
+    vocab = synthetic_vocab(V_)
+    from oracle import butd as ob
+    ob_params = ob.to_params(sd_of(g))
+    for img in range(2):
+        vi = {"bu_feats": torch.tensor(g["feats"][img:img + 1], device="cuda"), "bu_bboxes": None, "bu_masks": None}
+        words, (alphas,) = cap.eval_test_image(vi, vocab, max_len=20, eval_beam_size=-1)
+        np.testing.assert_allclose(alphas.cpu().numpy()[0], g["greedy_alphas"][img], atol=1e-4)
+        ids = g["greedy_ids"][img].tolist()
+        want_words = [vocab.ix2word[i] for i in (ids[:ids.index(2)] if 2 in ids else ids) if i != 1]
+        assert words == want_words
+        # beam of one: the reference's bookkeeping is exact (no permutation happens) -> identical maps
+        words, (alphas,) = cap.eval_test_image(vi, vocab, max_len=20, eval_beam_size=1)
+        want = g["beam_nat_k1_i%d_alpha" % img]
+        assert tuple(alphas.shape) == want.shape, (alphas.shape, want.shape)
+        np.testing.assert_allclose(alphas.cpu().numpy(), want, atol=1e-4)
+        # wider beams: the reference appends every step's maps un-permuted (`alpha.unsqueeze(1)` is not indexed by
+        # prev_word_inds, BUTD_Model.py:282, and never compacted with incomplete_inds), so what it returns mixes the maps of
+        # different beams from the first re-ordering on; ours are the maps of the returned sentence itself (= the oracle's
+        # teacher-forced pass over it).  Same shape, same first step (nothing has been permuted yet), rows sum to one.
+        p_cpu = ob_params
+        for k in (3, 5):
+            words, (alphas,) = cap.eval_test_image(vi, vocab, max_len=20, eval_beam_size=k)
+            want = g["beam_nat_k%d_i%d_alpha" % (k, img)]
+            seq = g["beam_nat_k%d_i%d" % (k, img)].astype(np.int64)
+            assert tuple(alphas.shape) == want.shape, (alphas.shape, want.shape)
+            np.testing.assert_allclose(alphas.cpu().numpy()[0, 0], want[0, 0], atol=1e-4)
+            feats1 = torch.tensor(g["feats"][img:img + 1])
+            st, mean, tf = ob.zero_state(1, H_), feats1.mean(1), []
+            for t in range(seq.shape[1] - 1):
+                _, al, st = ob.step(feats1, mean, torch.tensor(seq[0, t:t + 1]), st, p_cpu)
+                tf.append(al)
+            np.testing.assert_allclose(alphas.cpu().numpy()[0], torch.cat(tf, 0).numpy(), atol=1e-4)
+            np.testing.assert_allclose(alphas.sum(-1).cpu().numpy(), 1.0, atol=1e-5)
+
+
+def test_optimizer_state_is_saved_next_to_the_checkpoint(golden_dir, tmp_path):
+    """Engine.save_checkpoint / load_from_checkpoint with the optimizer: a restart continues bit-identically."""
+    import test_gpu_engine as tge
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.engine import init_optimizer
+    from synth import feats_from_seed
+    g, fx = tge._load(golden_dir)
+    B, R_, D_ = [int(x) for x in g["dims"][:3]]
+    caps = torch.tensor(g["xe0_captions"])
+    lens = [int(x) for x in g["xe0_lengths"]]
+    feats = feats_from_seed(int(g["xe0_feats_seed"]), B, R_, D_)
+    batch = (tuple(range(B)), None, caps, lens, tge._supp(feats))
+
+    def run(eng, opt, seeds):
+        for s in seeds:
+            eng.training_epoch([batch], opt, tge._Crit(), tqdm_visible=False, rngs=[make_rng(s)])
+    a, _ = tge._engine(g, fx)
+    oa = init_optimizer("Adam", a.model.get_param_groups({"lr": 4e-4}), 4e-4)
+    run(a, oa, [1, 2])
+    a.save_checkpoint([1.0, 2.0], optimizer=oa, root=str(tmp_path))
+    assert os.path.exists(os.path.join(str(tmp_path), "cp", "Captioner_cp.pth")) and os.path.exists(os.path.join(str(tmp_path), "cp", "Optimizer_cp.pth"))
+    run(a, oa, [3])
+    b, _ = tge._engine(g, fx)
+    ob_ = init_optimizer("Adam", b.model.get_param_groups({"lr": 4e-4}), 4e-4)
+    his, start = b.load_from_checkpoint(optimizer=ob_, root=str(tmp_path))
+    assert his == [1.0, 2.0] and start == 3
+    run(b, ob_, [3])
+    for (k, x), (_, y) in zip(a.model.state_dict().items(), b.model.state_dict().items()):
+        assert torch.equal(x, y), k

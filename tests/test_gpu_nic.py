@@ -177,3 +177,91 @@ def test_nic_eval_test_image(golden_dir):
             words, extra = cap.eval_test_image(vi, vocab, max_len=20, eval_beam_size=beam)
             cut = ids[:ids.index(2)] if 2 in ids else ids
             assert extra == [] and words == [vocab.ix2word[i] for i in cut if i != 1]
+
+
+# ---- at the benchmark width / handle behaviour (moved here from the per-round files in round 6)
+from _fullwidth import (_excuse_greedy, _first_divergence)  # noqa: E402
+
+
+def test_nic_config1_size_matches_oracle():
+    """BASELINE config 1 at its own size: NIC decoder, Flickr8K-size vocabulary 2543, E = H = 512, batch 16, 20 steps, random-init
+    (un-sharpened) weights: greedy ids exact, sampled ids exact up to CDF-boundary draws, log-probs 1e-4, REINFORCE gradients
+    2e-4 (NIC_Model.py:100-151)."""
+    from oracle import butd as ob
+    from oracle import nic as onic
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.nic import NicHandle
+    from simpleimagecaptionzoo_amd.synth import random_nic_params
+    En, Hn, Vn, B, T = 512, 512, 2543, 16, 20
+    params = random_nic_params(En, Hn, Vn, "cuda", seed=7)
+    h = NicHandle(En, Hn, Vn, B, T)
+    h.bind(params)
+    g = torch.Generator(device="cpu")
+    g.manual_seed(11)
+    feats_c = torch.randn(B, En, generator=g)
+    feats = feats_c.cuda()
+    p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in params.items()}
+    ids = h.greedy(feats, T).cpu().numpy()
+    with torch.no_grad():
+        w_ids, w_glog = onic.greedy(feats_c, p, T)
+    _excuse_greedy(ids, w_ids, w_glog, 1)
+    rs = np.random.RandomState(12)
+    om = rs.rand(T, B, Hn) < 0.5
+    u = rs.rand(T, B).astype(np.float32)
+    rng = make_rng(0, torch.tensor(u, device="cuda"), None, None, torch.tensor(om.astype(np.uint8), device="cuda"))
+    seq, lp = h.sample(feats, T, rng)
+    seq, lp = seq.cpu().numpy(), lp.cpu().numpy()
+    w_seq, w_lp = onic.sample_rl(feats_c, p, u.astype(np.float64), om, T, early_exit=False)
+    sdiv = _first_divergence(seq, w_seq.numpy())
+    assert (sdiv >= 0).sum() <= 1
+    ok = sdiv < 0
+    np.testing.assert_allclose(lp[ok], w_lp.detach().numpy()[ok], atol=1e-4)
+    rw = (rs.randn(B, 1).astype(np.float32) * ok[:, None]).repeat(T, 1)
+    grads = h.new_grads()
+    loss, _ = h.sample_backward(torch.tensor(rw, device="cuda"), grads)
+    w_loss = ob.reward_criterion(w_lp, torch.from_numpy(np.where(ok[:, None], w_seq.numpy(), seq)), torch.from_numpy(rw))
+    w_loss.backward()
+    assert abs(loss.item() - w_loss.item()) < 1e-4
+    for k, gt in grads.items():
+        want = p[k].grad.numpy()
+        scale = max(1e-6, float(np.abs(want).max()))
+        assert np.abs(gt.cpu().numpy() - want).max() <= 2e-4 * scale + 1e-7, (k, float(np.abs(gt.cpu().numpy() - want).max()), scale)
+    h.close()
+
+
+@pytest.mark.parametrize("B", [5, 40])
+def test_nic_early_out_equals_running_every_step(B):
+    """NIC DecoderRNN.sample_rl's break (NIC_Model.py:150) on the device, against every step run (option early_out = 0, the form the
+    reference goldens in test_gpu_nic.py pin): sampled ids, log-probs, loss, decoder gradients and the gradient w.r.t. the image
+    embedding agree."""
+    from simpleimagecaptionzoo_amd._lib import check, lib
+    from simpleimagecaptionzoo_amd.butd import make_rng
+    from simpleimagecaptionzoo_amd.nic import NicHandle
+    from simpleimagecaptionzoo_amd.synth import random_nic_params
+    E_, H_, V_, T = 512, 512, 2543, 20
+    params = random_nic_params(E_, H_, V_, "cuda", seed=9)
+    params["predict.weight_g"][2] = 0.0
+    params["predict.bias"][2] = 8.0
+    gen = torch.Generator(device="cpu")
+    gen.manual_seed(B)
+    feats = torch.randn(B, E_, generator=gen).cuda()
+    out = {}
+    for eo in (0, 1):
+        h = NicHandle(E_, H_, V_, B, T)
+        h.bind(params)
+        check(lib().icz_nic_set_option(h._h, b"early_out", eo))
+        seq, lp = h.sample(feats, T, make_rng(31))
+        grads = h.new_grads()
+        rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
+        res = h.sample_backward(rew, grads, want_dfeats=True)
+        out[eo] = (seq.cpu().numpy(), lp.cpu().numpy(), res[0].item(), {k: v.cpu().numpy() for k, v in grads.items()},
+                   [res[1].cpu().numpy(), res[2].cpu().numpy()])
+        h.close()
+    a, b = out[1], out[0]
+    assert (b[0][:, -1] == 0).all() and (b[0][:, 0] != 0).any()          # every row ended before the last step
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    for k in a[3]:
+        scale = float(np.abs(b[3][k]).max()) + 1e-12
+        assert np.isfinite(a[3][k]).all() and float(np.abs(a[3][k] - b[3][k]).max()) <= 1e-5 * scale, k
+    for x, y in zip(a[4], b[4]):
+        assert np.allclose(x, y, rtol=0, atol=1e-5 * (float(np.abs(y).max()) + 1e-12))
