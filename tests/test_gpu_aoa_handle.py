@@ -175,7 +175,7 @@ def test_aoa_graphs_survive_training_buffers_that_regrow(golden_dir):
     feats = torch.relu(torch.randn(B, 36, D, device="cuda"))
     caps = torch.randint(4, V, (B, L), device="cuda")
     caps[:, 0] = 1
-    lengths = [L, L - 1, L - 3, 12, 9, 5]
+    lengths = [L - 1, L - 2, L - 4, 12, 9, 5]
     rew = torch.linspace(-1, 1, B, device="cuda").unsqueeze(1).repeat(1, T).contiguous()
 
     def scst(h, seed):

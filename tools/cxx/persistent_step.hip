@@ -15,7 +15,7 @@
 //   6 LM pointwise    256 x [ 0 |  69 |  7]   16 slabs
 //   7 predict GEMM    160 x [64 | 256 | 64]   K = 1024, N = 10112
 //   8 token choice    256 x [ 0 |  40 |  1]   four slabs of a quarter row (launch chain: 64 x 1024 threads x 160 KB as shipped)
-// = 223 MB per step (227.9 MB).
+// = 287 MB per step as moved (SURVEY 8d's algorithmic 227.9 MB + the split-K slabs written and read back).
 //
 // Variants: A  nine launches per step, 20 steps captured into one hipGraph (today's structure)
 //           B  one launch per 20 steps, 256 resident workgroups, an XCD-hierarchical grid barrier between phases
