@@ -30,15 +30,15 @@ def masked_mean(enc, bu_mask):
     return (enc * bu_mask.unsqueeze(-1)).sum(1) / bu_mask.unsqueeze(-1).sum(1)
 
 
-def aoa_block(query, kv, p, pre, att_mask=None, aoa_mask=None, aoa_p=0.3, bu_mask=None):
+def aoa_block(query, kv, p, pre, att_mask=None, aoa_mask=None, aoa_p=0.3, bu_mask=None, kv_proj=None):
     """AoABlock.forward, AoA_Model.py:90-120: 8-head dot-product attention (keys with bu_mask == 0 filled with -1e9
-    before the softmax, :63-64,108-110) + GLU gate."""
+    before the softmax, :63-64,108-110) + GLU gate.  kv_proj: (linear_K(kv), linear_V(kv)) computed by the caller (hoist_dec)."""
     B, nq, Hd = query.shape
     d = Hd // NH
     lin = lambda x, n: x @ p[pre + n + ".weight"].t() + p[pre + n + ".bias"]
     Q = lin(query, "linear_Q").view(B, -1, NH, d).transpose(1, 2)
-    K = lin(kv, "linear_K").view(B, -1, NH, d).transpose(1, 2)
-    V = lin(kv, "linear_V").view(B, -1, NH, d).transpose(1, 2)
+    K = (kv_proj[0] if kv_proj else lin(kv, "linear_K")).view(B, -1, NH, d).transpose(1, 2)
+    V = (kv_proj[1] if kv_proj else lin(kv, "linear_V")).view(B, -1, NH, d).transpose(1, 2)
     S = Q @ K.transpose(-2, -1) / math.sqrt(d)
     if bu_mask is not None:
         S = S.masked_fill(bu_mask[:, None, None, :] == 0, -1e9)
@@ -68,16 +68,25 @@ def refine(feats, p, masks=None, lens=None):
     return layer_norm(x, p["aoa_refine.norm.gain"], p["aoa_refine.norm.bias"])
 
 
-def dec_step(it, state, enc, meanf, p, masks=(None, None, None, None), bu_mask=None):
-    """One AoA_Decoder step, AoA_Model.py:319-336.  state = (h, m, ctx); masks = (emb, ctx, att, out)."""
+def hoist_dec(enc, p):
+    """What a decoder step recomputes although it does not change (AoA_Model.py:104-106 projects the refined regions onto keys and
+    values in every step; weight_norm rebuilds `predict` in every step), computed once -- as oracle.butd.hoist: forward values bitwise
+    those of the per-step form, gradients through one node instead of one per step.  For the full-width tests only."""
+    pre = "decoder.aoa_block."
+    lin = lambda n: enc @ p[pre + n + ".weight"].t() + p[pre + n + ".bias"]
+    return {"kv": (lin("linear_K"), lin("linear_V")), "w_pred": wn_weight(p, "decoder.predict")}
+
+
+def dec_step(it, state, enc, meanf, p, masks=(None, None, None, None), bu_mask=None, pre=None):
+    """One AoA_Decoder step, AoA_Model.py:319-336.  state = (h, m, ctx); masks = (emb, ctx, att, out).  pre: see hoist_dec()."""
     h, m, ctx = state
     emb = drop(torch.relu(p["decoder.embed.0.weight"][it]), masks[0], 0.5)
     u = meanf + drop(ctx, masks[1], 0.5)
     h, m = lstm_cell(torch.cat([emb, u], 1), h, m, p, "decoder.lstm")
     q = layer_norm(h, p["decoder.h_norm.gain"], p["decoder.h_norm.bias"]).unsqueeze(1)
-    ctx, alpha = aoa_block(q, enc, p, "decoder.aoa_block.", masks[2], None, bu_mask=bu_mask)
+    ctx, alpha = aoa_block(q, enc, p, "decoder.aoa_block.", masks[2], None, bu_mask=bu_mask, kv_proj=pre["kv"] if pre else None)
     ctx = ctx.squeeze(1)
-    logits = drop(ctx, masks[3], 0.5) @ wn_weight(p, "decoder.predict").t() + p["decoder.predict.bias"]
+    logits = drop(ctx, masks[3], 0.5) @ (pre["w_pred"] if pre else wn_weight(p, "decoder.predict")).t() + p["decoder.predict.bias"]
     return logits, alpha.squeeze(1), (h, m, ctx)
 
 
@@ -92,22 +101,23 @@ def _step_masks(masks, t, bt=None):
     return tuple(torch.as_tensor(cut(masks[k][t])) for k in ("emb", "ctx", "att", "out"))
 
 
-def greedy(feats, p, max_len=20, lens=None):
+def greedy(feats, p, max_len=20, lens=None, hoisted=False):
     enc = refine(feats, p, lens=lens)
     B, R, Hd = enc.shape
     bu = key_mask(lens, R)
     meanf, st = masked_mean(enc, bu), _zero(B, Hd)
     it = torch.full((B,), STA, dtype=torch.long)
     ids, lgs = [], []
+    pre = hoist_dec(enc, p) if hoisted else None
     for _ in range(max_len):
-        logits, _, st = dec_step(it, st, enc, meanf, p, bu_mask=bu)
+        logits, _, st = dec_step(it, st, enc, meanf, p, bu_mask=bu, pre=pre)
         it = logits.max(1)[1]
         ids.append(it)
         lgs.append(logits)
     return torch.stack(ids, 1), torch.stack(lgs, 1)
 
 
-def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True, lens=None):
+def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True, lens=None, hoisted=False):
     enc = refine(feats, p, masks, lens)
     B, R, Hd = enc.shape
     bu = key_mask(lens, R)
@@ -116,8 +126,9 @@ def sample_rl(feats, p, uniforms, masks, max_len=20, early_exit=True, lens=None)
     seq = torch.zeros(B, max_len, dtype=torch.long)
     lps = [torch.zeros(B) for _ in range(max_len)]
     unfinished = torch.ones(B, dtype=torch.bool)
+    pre = hoist_dec(enc, p) if hoisted else None
     for t in range(max_len):
-        logits, _, st = dec_step(it, st, enc, meanf, p, _step_masks(masks, t), bu)
+        logits, _, st = dec_step(it, st, enc, meanf, p, _step_masks(masks, t), bu, pre)
         logp = torch.log_softmax(logits, dim=1)
         draw = inverse_cdf_draw(torch.exp(logp.detach()), uniforms[t])
         lps[t] = logp.gather(1, draw.unsqueeze(1)).squeeze(1)

@@ -46,12 +46,24 @@ def drop(x, mask, p=0.5):
     return x * mask.to(x.dtype).reshape(x.shape) * (1.0 / (1.0 - p))
 
 
-def soft_attention(feats, h1, p, att_mask=None):
-    """SoftAttention.forward, BUTD_Model.py:49-62."""
-    enc_ctx = feats @ wn_weight(p, "atten.enc_att").t() + p["atten.enc_att.bias"]
-    dec_ctx = h1 @ wn_weight(p, "atten.dec_att").t() + p["atten.dec_att.bias"]
+def hoist(feats, p):
+    """What does not change from one decoder step to the next, computed ONCE: the four weight-normed matrices and enc_att(feats)
+    (BUTD_Model.py:57 recomputes the latter in every step, as step() / soft_attention() do by default).  Passing the result as
+    `pre` leaves every forward value bitwise as it was (the same operations on the same operands); a gradient reaches the parameters
+    through one graph node instead of one per step (the same sum in another association).  For the full-width tests, whose CPU
+    passes are otherwise 3/4 enc_att products; the golden checks (tests/test_oracle_golden.py) run the per-step form, and
+    tests/test_oracle_golden.py::test_hoisted_oracle_equals_the_per_step_form holds the two together."""
+    w = {n: wn_weight(p, n) for n in ("atten.enc_att", "atten.dec_att", "atten.affine", "predict")}
+    return {"w": w, "enc_ctx": None if feats is None else feats @ w["atten.enc_att"].t() + p["atten.enc_att.bias"]}
+
+
+def soft_attention(feats, h1, p, att_mask=None, pre=None):
+    """SoftAttention.forward, BUTD_Model.py:49-62.  pre: see hoist()."""
+    W = (lambda n: pre["w"][n]) if pre else (lambda n: wn_weight(p, n))
+    enc_ctx = pre["enc_ctx"] if pre and pre["enc_ctx"] is not None else feats @ W("atten.enc_att").t() + p["atten.enc_att.bias"]
+    dec_ctx = h1 @ W("atten.dec_att").t() + p["atten.dec_att.bias"]
     z = drop(torch.relu(enc_ctx + dec_ctx.unsqueeze(1)), att_mask)
-    score = (z @ wn_weight(p, "atten.affine").t()).squeeze(2) + p["atten.affine.bias"]
+    score = (z @ W("atten.affine").t()).squeeze(2) + p["atten.affine.bias"]
     alpha = torch.softmax(score, dim=1)
     return (feats * alpha.unsqueeze(2)).sum(1), alpha
 
@@ -61,14 +73,14 @@ def embed(it, p, emb_mask=None):
     return drop(torch.relu(p["embed.0.weight"][it]), emb_mask)
 
 
-def step(feats, mean, it, state, p, masks=(None, None, None)):
-    """One decoder step, BUTD_Model.py:172-182.  state = (h1, c1, h2, c2)."""
+def step(feats, mean, it, state, p, masks=(None, None, None), pre=None):
+    """One decoder step, BUTD_Model.py:172-182.  state = (h1, c1, h2, c2).  pre: see hoist()."""
     h1, c1, h2, c2 = state
     e = embed(it, p, masks[0])
     h1, c1 = lstm_cell(torch.cat([h2, mean, e], 1), h1, c1, p, "TD_atten")
-    ctx, alpha = soft_attention(feats, h1, p, masks[1])
+    ctx, alpha = soft_attention(feats, h1, p, masks[1], pre)
     h2, c2 = lstm_cell(torch.cat([ctx, h1], 1), h2, c2, p, "language_model")
-    logits = drop(h2, masks[2]) @ wn_weight(p, "predict").t() + p["predict.bias"]
+    logits = drop(h2, masks[2]) @ (pre["w"]["predict"] if pre else wn_weight(p, "predict")).t() + p["predict.bias"]
     return logits, alpha, (h1, c1, h2, c2)
 
 
@@ -76,15 +88,16 @@ def zero_state(B, H):
     return tuple(torch.zeros(B, H) for _ in range(4))
 
 
-def greedy(feats, p, max_len=20):
-    """DecoderRNN.sample, BUTD_Model.py:153-189 -> ids (B,max_len) int64, alphas, logits."""
+def greedy(feats, p, max_len=20, hoisted=False):
+    """DecoderRNN.sample, BUTD_Model.py:153-189 -> ids (B,max_len) int64, alphas, logits.  hoisted: see hoist()."""
     B = feats.shape[0]
     H = p["TD_atten.weight_hh"].shape[1]
     mean, st = feats.mean(1), zero_state(B, H)
     it = torch.full((B,), STA, dtype=torch.long)
     ids, als, lgs = [], [], []
+    pre = hoist(feats, p) if hoisted else None
     for _ in range(max_len):
-        logits, alpha, st = step(feats, mean, it, st, p)
+        logits, alpha, st = step(feats, mean, it, st, p, pre=pre)
         it = logits.max(1)[1]
         ids.append(it)
         als.append(alpha)
@@ -101,11 +114,11 @@ def inverse_cdf_draw(prob, u):
     return torch.searchsorted(c, tgt, right=True).clamp_(max=prob.shape[1] - 1).squeeze(1)
 
 
-def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, early_exit=True, trace=None):
+def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, early_exit=True, trace=None, hoisted=False):
     """DecoderRNN.sample_rl, BUTD_Model.py:191-234 with explicit uniforms/masks.
     Returns seq (B,T) int64 (0 at and after a sampled <end>), logprobs (B,T) (autograd-capable), logits.
     trace: optional dict; receives "h1" = the attention LSTM's hidden state of every step (detached), for tests that look at
-    the attention pre-activations behind a gradient."""
+    the attention pre-activations behind a gradient.  hoisted: see hoist()."""
     B = feats.shape[0]
     H = p["TD_atten.weight_hh"].shape[1]
     mean, st = feats.mean(1), zero_state(B, H)
@@ -114,11 +127,12 @@ def sample_rl(feats, p, uniforms, emb_masks, att_masks, out_masks, max_len=20, e
     lps = [torch.zeros(B) for _ in range(max_len)]
     lgs = []
     unfinished = torch.ones(B, dtype=torch.bool)
+    pre = hoist(feats, p) if hoisted else None
     for t in range(max_len):
         m = (None if emb_masks is None else torch.as_tensor(emb_masks[t]),
              None if att_masks is None else torch.as_tensor(att_masks[t]),
              None if out_masks is None else torch.as_tensor(out_masks[t]))
-        logits, _, st = step(feats, mean, it, st, p, m)
+        logits, _, st = step(feats, mean, it, st, p, m, pre)
         if trace is not None:
             trace.setdefault("h1", []).append(st[0].detach())
         logp = torch.log_softmax(logits, dim=1)
@@ -145,8 +159,9 @@ def beam_search(feats1, p, k, max_steps=50):
     seqs = prev.view(k, 1)
     run = torch.zeros(k, 1)
     done, done_scores = [], []
+    pre = hoist(None, p)          # the weight-normed matrices once (bitwise the per-step values); enc_att(feats) stays per step: the rows shrink
     for stp in range(1, max_steps + 1):
-        logits, _, st = step(feats, mean, prev, st, p)
+        logits, _, st = step(feats, mean, prev, st, p, pre=pre)
         sc = run.expand(-1, V) + torch.log_softmax(logits, dim=1)
         top, idx = (sc[0] if stp == 1 else sc.reshape(-1)).topk(k, 0, True, True)
         src, nxt = torch.div(idx, V, rounding_mode="floor"), idx % V

@@ -140,13 +140,13 @@ def _butd_scst_case(B, T, seed, sharpen=6.0, options=None, with_reward=False):
         try:
             p = {k: v.detach().cpu().to(dt).requires_grad_(True) for k, v in params.items()}
             trace = {}
-            w_seq, w_lp, w_slog = ob.sample_rl(feats_c.to(dt), p, u.astype(np.float64), em, am, om, T, early_exit=False, trace=trace)
+            w_seq, w_lp, w_slog = ob.sample_rl(feats_c.to(dt), p, u.astype(np.float64), em, am, om, T, early_exit=False, trace=trace, hoisted=True)
             out[name] = (p, w_seq, w_lp, w_slog, trace)
         finally:
             torch.set_default_dtype(torch.float32)
     p32 = out["f32"][0]
     with torch.no_grad():
-        w_greedy, _, w_glog = ob.greedy(feats_c, {k: v.detach() for k, v in p32.items()}, T)
+        w_greedy, _, w_glog = ob.greedy(feats_c, {k: v.detach() for k, v in p32.items()}, T, hoisted=True)
     limit = max(1, B // 32)
     _excuse_greedy(greedy, w_greedy, w_glog, limit)
     ok = _excuse_sampled(seq, out["f32"][1], out["f32"][3], u, limit)

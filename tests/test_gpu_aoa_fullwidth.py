@@ -84,12 +84,12 @@ def test_fullsize_aoa_scst_step_64x20_matches_oracle():
         torch.set_default_dtype(dt)
         try:
             pp = {k: v.detach().cpu().to(dt).requires_grad_(k.startswith("decoder.")) for k, v in cap.state_dict().items()}
-            runs[name] = (pp,) + tuple(oa.sample_rl(feats_c.to(dt), pp, u.astype(np.float64), masks, T, early_exit=False))
+            runs[name] = (pp,) + tuple(oa.sample_rl(feats_c.to(dt), pp, u.astype(np.float64), masks, T, early_exit=False, hoisted=True))
         finally:
             torch.set_default_dtype(torch.float32)
     p, w_seq, w_lp = runs["f32"]
     with torch.no_grad():
-        w_greedy, w_glog = oa.greedy(feats_c, p, T)
+        w_greedy, w_glog = oa.greedy(feats_c, p, T, hoisted=True)
     div = _first_divergence(greedy, w_greedy.numpy())
     excused = 0
     for b in np.nonzero(div >= 0)[0]:
@@ -228,7 +228,7 @@ def test_aoaspatial_49_regions_gradients_match_oracle():
     rng = make_aoa_rng(0, torch.tensor(u, device="cuda"), {k: torch.tensor(v.astype(np.uint8), device="cuda") for k, v in masks.items()})
     seq, lp = h.sample(feats, T, rng)
     p = fresh()
-    w_seq, w_lp = oa.sample_rl(feats_c, p, u.astype(np.float64), masks, T, early_exit=False)
+    w_seq, w_lp = oa.sample_rl(feats_c, p, u.astype(np.float64), masks, T, early_exit=False, hoisted=True)
     assert np.array_equal(seq.cpu().numpy(), w_seq.numpy())
     np.testing.assert_allclose(lp.cpu().numpy(), w_lp.detach().numpy(), atol=1e-4)
     rw = rs.randn(B, 1).astype(np.float32).repeat(T, 1)

@@ -189,7 +189,7 @@ def test_greedy_at_128_rows_matches_oracle_and_the_64_row_path():
     p = {k: v.detach().cpu() for k, v in params.items()}
     rows = [0, 63, 64, 99, 127]
     with torch.no_grad():
-        want, _, logits = ob.greedy(feats[rows].cpu(), p, 20)
+        want, _, logits = ob.greedy(feats[rows].cpu(), p, 20, hoisted=True)
     top2 = torch.topk(logits, 2, dim=2).values
     clear = ((top2[..., 0] - top2[..., 1]) > 1e-3).numpy()                # steps whose argmax no fp32 reordering can flip
     for j, r in enumerate(rows):

@@ -51,7 +51,7 @@ def test_fullsize_rollout_with_early_break_matches_oracle_and_autograd():
     if all((r == 2).any() for r in g_full):
         assert max(ends) < T - 1 and (g_roll[:, max(ends) + 1:] == 0).all()
     p = {k: v.detach().cpu().clone().requires_grad_(True) for k, v in params.items()}
-    w_seq, w_lp, w_logits = ob.sample_rl(feats.cpu(), p, u.astype(np.float64), em, am, om, T, early_exit=True)
+    w_seq, w_lp, w_logits = ob.sample_rl(feats.cpu(), p, u.astype(np.float64), em, am, om, T, early_exit=True, hoisted=True)
     steps_run = w_logits.shape[1]
     assert 4 <= steps_run <= 16, steps_run                    # the regime does what it is for: the reference broke out early
     same = (w_seq.numpy() == seq_h).all(1)

@@ -507,3 +507,55 @@ def test_aoa_oracle_two_steps_at_full_width(golden_dir):
     packed = packed[0] if isinstance(packed, tuple) else packed
     np.testing.assert_allclose(packed.numpy(), g["packed_logits"], atol=1e-4, rtol=1e-5)
     assert np.array_equal(packed.argmax(1).numpy(), g["argmax"])
+
+
+def test_hoisted_oracle_equals_the_per_step_form():
+    """oracle.butd.hoist / oracle.aoa.hoist_dec (round 6: what a step recomputes although it does not change -- enc_att(feats), the
+    weight-normed matrices, AoA's key / value projections -- computed once, for the full-width GPU tests whose CPU passes are otherwise
+    mostly those products): forward values bitwise those of the per-step form the golden checks above pin, gradients equal up to the
+    association of one sum."""
+    from oracle import aoa as oa
+    from oracle import butd as ob
+    torch.manual_seed(5)
+    B, R, D, H, E, A, V, T = 5, 7, 24, 16, 12, 20, 37, 6
+    g = lambda *s: torch.randn(*s) * 0.3
+    p = {"embed.0.weight": g(V, E), "TD_atten.weight_ih": g(4 * H, H + D + E), "TD_atten.weight_hh": g(4 * H, H), "TD_atten.bias_ih": g(4 * H),
+         "TD_atten.bias_hh": g(4 * H), "language_model.weight_ih": g(4 * H, D + H), "language_model.weight_hh": g(4 * H, H),
+         "language_model.bias_ih": g(4 * H), "language_model.bias_hh": g(4 * H)}
+    for n, shape in (("atten.enc_att", (A, D)), ("atten.dec_att", (A, H)), ("atten.affine", (1, A)), ("predict", (V, H))):
+        p[n + ".weight_v"], p[n + ".weight_g"], p[n + ".bias"] = g(*shape), torch.rand(shape[0], 1) + 0.5, g(shape[0])
+    feats = torch.relu(torch.randn(B, R, D))
+    rs = np.random.RandomState(1)
+    u = rs.rand(T, B)
+    em, am, om = rs.rand(T, B, E) < 0.5, rs.rand(T, B, R, A) < 0.5, rs.rand(T, B, H) < 0.5
+    out = {}
+    for hz in (False, True):
+        q = {k: v.clone().requires_grad_(True) for k, v in p.items()}
+        ids, al, lg = ob.greedy(feats, {k: v.detach() for k, v in q.items()}, T, hoisted=hz)
+        seq, lp, slg = ob.sample_rl(feats, q, u, em, am, om, T, early_exit=False, hoisted=hz)
+        lp.sum().backward()
+        out[hz] = (ids, al, lg, seq, lp.detach(), slg.detach(), {k: v.grad for k, v in q.items()})
+    a, b = out[False], out[True]
+    for i in range(6):
+        assert torch.equal(a[i], b[i]), i
+    for k in a[6]:
+        assert (a[6][k] - b[6][k]).abs().max() <= 1e-6 * (1 + a[6][k].abs().max()), k
+    # AoA: the decoder's key / value projections and `predict`
+    gd = dict(np.load(os.path.join(os.path.dirname(__file__), "golden", "aoa_tiny.npz")))
+    sd = {k[3:]: torch.tensor(np.asarray(v), dtype=torch.float32) for k, v in gd.items() if k.startswith("sd.")}
+    _, Rr, Dd, Hd, Ee, Vv, NH = [int(x) for x in gd["dims"]]
+    fa = torch.relu(torch.randn(4, Rr, Dd))
+    ua = rs.rand(T, 4)
+    res = {}
+    for hz in (False, True):
+        q = {k: v.clone().requires_grad_(k.startswith("decoder.")) for k, v in sd.items()}
+        with torch.no_grad():
+            ids, lg = oa.greedy(fa, q, T, hoisted=hz)
+        seq, lp = oa.sample_rl(fa, q, ua, None, T, early_exit=False, hoisted=hz)
+        lp.sum().backward()
+        res[hz] = (ids, lg, seq, lp.detach(), {k: v.grad for k, v in q.items() if v.grad is not None})
+    a, b = res[False], res[True]
+    for i in range(4):
+        assert torch.equal(a[i], b[i]), i
+    for k in a[4]:
+        assert (a[4][k] - b[4][k]).abs().max() <= 1e-6 * (1 + a[4][k].abs().max()), k
