@@ -112,7 +112,7 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
 // ICZ_GEMM_RESIDENT_M128 (0: 65..128 rows go to the 128 x 128-tile kernel instead of the 128-row resident kernel),
 // ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch),
 // ICZ_GEMM_BIG (unset / -1: gemm_big_cfg's choice per shape; 0: the 128 x 128 two-barrier kernel everywhere; 1..5: that large-tile configuration everywhere).
-struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs, resident_narrow; unsigned prof_every; int big_cfg; };
+struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs; unsigned prof_every; int big_cfg; };
 const GemmSwitches& gemm_switches();
 
 }  // namespace icz

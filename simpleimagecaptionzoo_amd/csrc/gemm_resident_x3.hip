@@ -592,22 +592,18 @@ static bool rs_shape_ok(const GemmArgs& a) {
 bool gemm_resident_x3_fits(const GemmArgs& a) { return a.N >= 2048 && rs_shape_ok(a); }
 int gemm_resident_x3_nsplit(const GemmArgs& a) { return rs_total_stages(a) / gemm_resident_x3_stages(a); }
 
-template <int NSR, int TPW, bool STAMPS>
+template <int NSR, bool STAMPS>
 static int rs_launch(const GemmArgs& a, hipStream_t stream) {
     constexpr size_t lds = rs_lds_bytes<4, NSR>();
     static bool attr = false;
     if (!attr) {
-        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, NSR, TPW, 3, STAMPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, NSR, 2, 3, STAMPS>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, NSR, TPW, 3, STAMPS>), dim3(cdiv(a.N, 128 * TPW) * a.nsplit), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, NSR, 2, 3, STAMPS>), dim3(cdiv(a.N, 256) * a.nsplit), dim3(256), lds, stream, a);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
-// (round 6) a product whose (k ranges x 256-column groups) fill at most half of the chip -- AoA's 2048 x 2048 linear: 8 x 8 = 64
-// workgroups, NIC's LSTM gates -- runs ONE 128-column tile per workgroup instead of two: twice the workgroups of [64 KB activations |
-// 128 KB weights | 32 KB slab], the same k ranges, slabs and sums (bitwise the same results)
-static bool rs_narrow(const GemmArgs& a) { return gemm_switches().resident_narrow && a.M <= 64 && cdiv(a.N, 256) * a.nsplit <= 128; }
 
 template <bool STAMPS>
 static int rs_launch_m128(const GemmArgs& a, hipStream_t stream) {
@@ -637,11 +633,10 @@ int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
     if (rs_dev_env("ICZ_DEV_STAMPS")) {
         if (!g_sk_stamps) ICZ_CHECK_HIP(hipMalloc((void**)&g_sk_stamps, sizeof(unsigned long long) * 32 * 4096));
         a.bias = reinterpret_cast<const float*>(g_sk_stamps);
-        return a.M > 64 ? rs_launch_m128<true>(a, stream) : rs_launch<4, 2, true>(a, stream);
+        return a.M > 64 ? rs_launch_m128<true>(a, stream) : rs_launch<4, true>(a, stream);
     }
 #endif
-    if (rs_narrow(a)) return rs_launch<4, 1, false>(a, stream);
-    return a.M > 64 ? rs_launch_m128<false>(a, stream) : rs_launch<4, 2, false>(a, stream);
+    return a.M > 64 ? rs_launch_m128<false>(a, stream) : rs_launch<4, false>(a, stream);
 }
 
 // the pair launch: both problems in the kernel's decomposition with four stages per k range, slabs out (nsplit > 1)

@@ -39,11 +39,11 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(scaling):
 
 
 @pytest.mark.gpu_slow
-@pytest.mark.parametrize("n,extra", [(2, ["--scaling", "weak"]), (5, ["--scaling", "strong", "--batch", "40"])])
+@pytest.mark.parametrize("n,extra", [(2, ["--scaling", "weak"]), (4, ["--scaling", "strong", "--batch", "32"])])
 def test_bench_starts_its_own_ranks(n, extra):
     """`python bench.py --gpus N` with no launcher and no WORLD_SIZE (the form the driver uses at N = 1): bench.py must start the N
     ranks itself -- fresh child processes, the parent stays off the GPU -- and relay ONE line with n_gpus = ranks_seen = N
-    (rehearsal mode: all ranks on the one GPU of the box over gloo).  Five ranks x 8 rows: uneven launch timing, the <= 32-row
+    (rehearsal mode: all ranks on the one GPU of the box over gloo; five ranks through the Engine itself: test_gpu_dist_two_ranks.py).  Four ranks x 8 rows: uneven launch timing, the <= 32-row
     decoder path, four gradient slices reduced from the library's callback under graph replay at ranks >= 2."""
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
     env["ICZ_REHEARSE_ONE_GPU"] = "1"
@@ -54,7 +54,7 @@ def test_bench_starts_its_own_ranks(n, extra):
     assert len(line) == 1, r.stdout[-2000:]
     j = json.loads(line[0])
     assert j["n_gpus"] == n and j["ranks_seen"] == n and j["config"]["parallelism"] == "dp%d" % n
-    assert j["config"]["global_batch"] == (128 if n == 2 else 40) and j["value"] > 0 and "grad_allreduce_ms" in j
+    assert j["config"]["global_batch"] == (128 if n == 2 else 32) and j["value"] > 0 and "grad_allreduce_ms" in j
     _check_dp_fields(j)
 
 
