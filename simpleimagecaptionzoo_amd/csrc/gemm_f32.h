@@ -75,7 +75,7 @@ int gemm_fit_split(GemmLayout layout, const GemmArgs& a, int nsplit, size_t capa
 // gemm_resident_x3.hip: NT at 33..64 rows (and, as one merged decode chain, 65..128 rows) with split-precision operands and the activations of a workgroup's k range resident in
 // LDS (LSTM gates, vocabulary projection, per-step dgrad on transposed weights): fixed decomposition, nsplit = stages / stages per range
 bool gemm_resident_x3_fits(const GemmArgs& a);
-int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup: 4 (a 256-deep k range), 0 = shape not taken
+int gemm_resident_x3_stages(const GemmArgs& a);      // 64-deep stages per workgroup: 8 (a 512-deep k range on one column tile, <= 64 rows, round 6) or 4 (256 deep, two tiles), 0 = shape not taken
 int gemm_resident_x3_nsplit(const GemmArgs& a);
 int gemm_resident_x3(const GemmArgs& a, hipStream_t stream);
 // two independent problems (each in the kernel's four-stage decomposition, N >= 512) as ONE launch; slabs [nsplit][M][N] go to each
@@ -112,7 +112,7 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
 // ICZ_GEMM_RESIDENT_M128 (0: 65..128 rows go to the 128 x 128-tile kernel instead of the 128-row resident kernel),
 // ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch),
 // ICZ_GEMM_BIG (unset / -1: gemm_big_cfg's choice per shape; 0: the 128 x 128 two-barrier kernel everywhere; 1..5: that large-tile configuration everywhere).
-struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs; unsigned prof_every; int big_cfg; };
+struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs, resident_k512; unsigned prof_every; int big_cfg; };
 const GemmSwitches& gemm_switches();
 
 }  // namespace icz

@@ -928,6 +928,7 @@ const GemmSwitches& gemm_switches() {
         GemmSwitches s;
         s.tn_x3 = on("ICZ_GEMM_TN_X3"); s.nn_x3 = on("ICZ_GEMM_NN_X3"); s.nt_x3big = on("ICZ_GEMM_NT_X3BIG");
         s.resident_x3 = on("ICZ_GEMM_RESIDENT_X3"); s.resident_m128 = on("ICZ_GEMM_RESIDENT_M128"); s.predict_slabs = on("ICZ_PREDICT_SLABS");
+        s.resident_k512 = on("ICZ_GEMM_RESIDENT_K512");
         const char* e = getenv("ICZ_PROF_EVERY");
         s.prof_every = e && atoi(e) > 1 ? (unsigned)atoi(e) : 1u;
         const char* b = getenv("ICZ_GEMM_BIG");

@@ -85,10 +85,14 @@ template <int MT, int NSR>
 constexpr size_t rs_lds_bytes() { return (size_t)3 * (16 * MT) * rs_pb(NSR) * 2 + (size_t)4 * (16 * MT) * 32 * 4; }
 
 // one workgroup's work: pair = its index among the (k range, column group) pairs of the problem `a`
-template <int MT, int NSR, int TPW, int D, bool STAMPS>
+// HS = stages whose planes are resident at a time.  HS == NSR: the whole k range (rounds 2 - 5).  NSR == 2 HS, TPW == 1 (round 6): a
+// 512-deep k range on ONE column tile, its planes in two halves -- the second half's activations are loaded into registers behind the
+// barrier, wait there during the first half's steps and are cut into the same LDS planes between two barriers; the accumulators stay
+// live across the halves.  Half the split-K slabs of the 256-deep decomposition for the same 256 KB of weights per workgroup.
+template <int MT, int NSR, int TPW, int D, bool STAMPS, int HS = NSR>
 __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pair) {
-    static_assert(NSR >= 2 && NSR <= 4, "two to four 64-deep stages per k range");
-    constexpr int RS_PB = rs_pb(NSR);
+    static_assert(HS >= 2 && HS <= 4 && (NSR == HS || (NSR == 2 * HS && TPW == 1)), "two to four resident 64-deep stages; two halves only on one tile");
+    constexpr int RS_PB = rs_pb(HS);
     unsigned long long* const stamps = STAMPS ? reinterpret_cast<unsigned long long*>(const_cast<float*>(a.bias)) + 32 * (size_t)blockIdx.x : nullptr;
     auto stamp = [&](int i) __attribute__((always_inline)) {
         if constexpr (STAMPS) {
@@ -159,8 +163,8 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
     // ---- phase A: the activations of the whole k range -> three bf16 planes in LDS (k order permuted inside 32-blocks)
     {
         // a wave-wide load covers four rows x 256 contiguous bytes (whole 128-byte lines: lanes 0..15 = the 16 float4 of a row's stage)
-        f32x4 xr[NSR][XL];
-        sk_static_for<0, NSR>([&](auto sc) {
+        f32x4 xr[HS][XL];
+        sk_static_for<0, HS>([&](auto sc) {
             constexpr int st = decltype(sc)::value;
             const Cur c = seek(c_begin + st);
             const GemmSeg& g = a.seg[c.seg];
@@ -186,7 +190,7 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
             stamp(22);
             __builtin_amdgcn_sched_barrier(0);
         }
-        sk_static_for<0, NSR>([&](auto sc) {
+        sk_static_for<0, HS>([&](auto sc) {
             constexpr int st = decltype(sc)::value;
             sk_static_for<0, XL>([&](auto jc) {
                 constexpr int j = decltype(jc)::value;
@@ -202,6 +206,8 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
             });
         });
     }
+    // second half of a 512-deep range: its activations wait in registers until the first half's steps are done with the planes
+    f32x4 xr2[HS][XL];
 
     __builtin_amdgcn_sched_barrier(0);
     sk_static_for<1, D - 1>([&](auto ic) {
@@ -210,8 +216,21 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
     });
     __builtin_amdgcn_sched_barrier(0);
     stamp(1);
-    __syncthreads();                        // the planes are complete (the only barrier of the kernel)
+    __syncthreads();                        // the planes are complete (HS == NSR: the only barrier of the kernel)
     stamp(2);
+    if constexpr (NSR != HS) {
+        sk_static_for<0, HS>([&](auto sc) {
+            constexpr int st = decltype(sc)::value;
+            const Cur c = seek(c_begin + HS + st);
+            const GemmSeg& g = a.seg[c.seg];
+            sk_static_for<0, XL>([&](auto jc) {
+                constexpr int j = decltype(jc)::value;
+                const int f = tid + 256 * j, row = f >> 4, c4 = f & 15;
+                xr2[st][j] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(row < a.M ? row : a.M - 1) * g.lda + c.k0 + 4 * c4);
+            });
+        });
+        __builtin_amdgcn_sched_barrier(0);
+    }
     sk_static_for<0, WP>([&](auto pc) { w_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 0>{}); });
 
     sk_static_for<0, NT>([&](auto stepc) {
@@ -223,8 +242,29 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
 #pragma unroll
                 for (int c = 0; c < NCT; ++c) acc[t][c] = (f32x4){0.f, 0.f, 0.f, 0.f};
         }
+        if constexpr (NSR != HS && i == HS) {
+            // ---- the first half is done with the planes: cut the second half into them (two barriers; the weight ring runs on)
+            __builtin_amdgcn_sched_barrier(0);
+            __syncthreads();
+            sk_static_for<0, HS>([&](auto sc) {
+                constexpr int s2 = decltype(sc)::value;
+                sk_static_for<0, XL>([&](auto jc) {
+                    constexpr int j = decltype(jc)::value;
+                    const int f = tid + 256 * j, row = f >> 4, c4 = f & 15, kq = c4 & 7;
+                    unsigned short* o = planes + (size_t)row * RS_PB + 64 * s2 + 32 * (c4 >> 3) + 8 * (kq & 3) + 4 * (kq >> 2);
+                    uint32_t a0, a1, a2, b0, b1, b2;
+                    sk_split3(xr2[s2][j][0], xr2[s2][j][1], a0, a1, a2);
+                    sk_split3(xr2[s2][j][2], xr2[s2][j][3], b0, b1, b2);
+                    *reinterpret_cast<sk_u32x2*>(o) = (sk_u32x2){a0, b0};
+                    *reinterpret_cast<sk_u32x2*>(o + PLANE) = (sk_u32x2){a1, b1};
+                    *reinterpret_cast<sk_u32x2*>(o + 2 * PLANE) = (sk_u32x2){a2, b2};
+                });
+            });
+            __syncthreads();
+            __builtin_amdgcn_sched_barrier(0);
+        }
         if constexpr (HAS_LOAD) point_w(std::integral_constant<int, i + D - 1>{});
-        const unsigned short* abase = planes + (size_t)li * RS_PB + 64 * st + 8 * lq;
+        const unsigned short* abase = planes + (size_t)li * RS_PB + 64 * (st % HS) + 8 * lq;
         sk_bf16x8 af[2][3];
         sk_static_for<0, 3>([&](auto pp) { af[0][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(abase + decltype(pp)::value * PLANE); });
         sk_static_for<0, G>([&](auto gc) {
@@ -301,17 +341,17 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
     stamp(31);
 }
 
-template <int MT, int NSR, int TPW, int D, bool STAMPS = false>
+template <int MT, int NSR, int TPW, int D, bool STAMPS = false, int HS = NSR>
 __global__ __launch_bounds__(256) void gemm_resident_x3_kernel(GemmArgs a) {
-    resident_x3_body<MT, NSR, TPW, D, STAMPS>(a, blockIdx.x);
+    resident_x3_body<MT, NSR, TPW, D, STAMPS, HS>(a, blockIdx.x);
 }
 // Two independent problems in one launch (the two recurrent dgrad products of a BPTT step, d h2 and d h1: 128 + 64 workgroups --
 // alone neither fills the chip, and every launch pays the same fixed prologue): workgroups [0, first) take `a`, the rest `b`.
 struct GemmPair { GemmArgs a, b; int first; };
-template <int MT, int NSR, int TPW, int D>
+template <int MT, int NSR, int TPW, int D, int HS = NSR>
 __global__ __launch_bounds__(256) void gemm_resident_x3_pair_kernel(GemmPair g) {
-    if ((int)blockIdx.x < g.first) resident_x3_body<MT, NSR, TPW, D, false>(g.a, blockIdx.x);
-    else resident_x3_body<MT, NSR, TPW, D, false>(g.b, blockIdx.x - g.first);
+    if ((int)blockIdx.x < g.first) resident_x3_body<MT, NSR, TPW, D, false, HS>(g.a, blockIdx.x);
+    else resident_x3_body<MT, NSR, TPW, D, false, HS>(g.b, blockIdx.x - g.first);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -579,7 +619,13 @@ static int rs_total_stages(const GemmArgs& a) {
     for (int s = 0; s < a.nseg; ++s) tot += a.seg[s].K / SK_BK;
     return tot;
 }
-int gemm_resident_x3_stages(const GemmArgs& a) { return rs_total_stages(a) % 4 == 0 ? 4 : 0; }
+// (round 6) <= 64 rows, whole 512-deep ranges: eight stages on ONE column tile (192 / 256 / 158 workgroups for the TD gates, the LM gates
+// and the vocabulary projection -- as before -- with half the split-K slabs: 6 / 8 / 2)
+int gemm_resident_x3_stages(const GemmArgs& a) {
+    const int tot = rs_total_stages(a);
+    if (gemm_switches().resident_k512 && a.M <= 64 && tot % 8 == 0) return 8;
+    return tot % 4 == 0 ? 4 : 0;
+}
 // shapes the kernel can take: 33..64 rows, N a multiple of 4, whole 64-deep stages that split into ranges
 static bool rs_shape_ok(const GemmArgs& a) {
     if (!gemm_switches().resident_x3 || a.M <= 32 || a.M > (gemm_switches().resident_m128 ? 128 : 64) || a.N % 4 || a.accumulate) return false;
@@ -601,6 +647,19 @@ static int rs_launch(const GemmArgs& a, hipStream_t stream) {
         attr = true;
     }
     hipLaunchKernelGGL((gemm_resident_x3_kernel<4, NSR, 2, 3, STAMPS>), dim3(cdiv(a.N, 256) * a.nsplit), dim3(256), lds, stream, a);
+    ICZ_CHECK_HIP(hipGetLastError());
+    return ICZ_OK;
+}
+
+template <bool STAMPS>
+static int rs_launch_k512(const GemmArgs& a, hipStream_t stream) {
+    constexpr size_t lds = rs_lds_bytes<4, 4>();
+    static bool attr = false;
+    if (!attr) {
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, 8, 1, 3, STAMPS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        attr = true;
+    }
+    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, 8, 1, 3, STAMPS, 4>), dim3(cdiv(a.N, 128) * a.nsplit), dim3(256), lds, stream, a);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -633,34 +692,38 @@ int gemm_resident_x3(const GemmArgs& a_in, hipStream_t stream) {
     if (rs_dev_env("ICZ_DEV_STAMPS")) {
         if (!g_sk_stamps) ICZ_CHECK_HIP(hipMalloc((void**)&g_sk_stamps, sizeof(unsigned long long) * 32 * 4096));
         a.bias = reinterpret_cast<const float*>(g_sk_stamps);
-        return a.M > 64 ? rs_launch_m128<true>(a, stream) : rs_launch<4, true>(a, stream);
+        return a.M > 64 ? rs_launch_m128<true>(a, stream) : (nsr == 8 ? rs_launch_k512<true>(a, stream) : rs_launch<4, true>(a, stream));
     }
 #endif
-    return a.M > 64 ? rs_launch_m128<false>(a, stream) : rs_launch<4, false>(a, stream);
+    return a.M > 64 ? rs_launch_m128<false>(a, stream) : (nsr == 8 ? rs_launch_k512<false>(a, stream) : rs_launch<4, false>(a, stream));
 }
 
 // the pair launch: both problems in the kernel's decomposition with four stages per k range, slabs out (nsplit > 1)
 bool gemm_resident_x3_pair_fits(const GemmArgs& a, const GemmArgs& b) {
-    return a.M <= 64 && b.M <= 64 && rs_shape_ok(a) && rs_shape_ok(b) && gemm_resident_x3_stages(a) == 4 && gemm_resident_x3_stages(b) == 4 && a.N >= 512 && b.N >= 512;
+    return a.M <= 64 && b.M <= 64 && rs_shape_ok(a) && rs_shape_ok(b) && gemm_resident_x3_stages(a) == gemm_resident_x3_stages(b) && a.N >= 512 && b.N >= 512;
 }
 int gemm_resident_x3_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_t stream) {
     ICZ_REQUIRE(gemm_resident_x3_pair_fits(a_in, b_in), "gemm_resident_x3_pair: shapes outside the kernel's decomposition");
     GemmPair g;
     g.a = a_in; g.b = b_in;
+    const int nsr = gemm_resident_x3_stages(g.a), tilew = nsr == 8 ? 128 : 256;
     for (GemmArgs* p : {&g.a, &g.b}) {
         p->nsplit = gemm_resident_x3_nsplit(*p);
-        p->chunks_per_split = 4;
+        p->chunks_per_split = nsr;
         p->bias = nullptr;
         ICZ_REQUIRE(p->out && p->nsplit > 1, "gemm_resident_x3_pair: slab output expected");
     }
-    g.first = cdiv(g.a.N, 256) * g.a.nsplit;
+    g.first = cdiv(g.a.N, tilew) * g.a.nsplit;
     constexpr size_t lds = rs_lds_bytes<4, 4>();
     static bool attr = false;
     if (!attr) {
         ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 8, 1, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 4, 2, 3>), dim3(g.first + cdiv(g.b.N, 256) * g.b.nsplit), dim3(256), lds, stream, g);
+    const dim3 grid(g.first + cdiv(g.b.N, tilew) * g.b.nsplit);
+    if (nsr == 8) hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 8, 1, 3, 4>), grid, dim3(256), lds, stream, g);
+    else hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 4, 2, 3>), grid, dim3(256), lds, stream, g);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }

@@ -30,12 +30,15 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 struct Phase { int jobs; int shared_f4, priv_f4, out_f4; int shared_mod; };     // per job, in float4 per THREAD (256 threads)
 // KB per job / (256 threads x 16 B = 4 KB per float4-per-thread)
-__constant__ Phase PH[9] = {
+__constant__ Phase PH[9];
+static Phase PH_HOST[9] = {
     {192, 16, 64, 16, 12}, {256, 0, 13, 2, 1}, {64, 8, 16, 8, 8}, {192, 8, 12, 1, 64}, {256, 0, 18, 1, 1},
     {256, 16, 64, 16, 16}, {256, 0, 17, 2, 1}, {160, 16, 64, 16, 4}, {256, 0, 10, 1, 1}};
-static const Phase PH_HOST[9] = {
-    {192, 16, 64, 16, 12}, {256, 0, 13, 2, 1}, {64, 8, 16, 8, 8}, {192, 8, 12, 1, 64}, {256, 0, 18, 1, 1},
-    {256, 16, 64, 16, 16}, {256, 0, 17, 2, 1}, {160, 16, 64, 16, 4}, {256, 0, 10, 1, 1}};
+// `persistent_step half`: the gate GEMMs on 512-deep k ranges x ONE 128-column tile per workgroup (half the slabs: 6 / 8 instead of 12 / 16;
+// twice the activation block per workgroup) and the pointwise phases over half the slab bytes -- EXPERIMENTS round 6 section 2
+static const Phase PH_HALF[9] = {
+    {192, 32, 64, 8, 6}, {256, 0, 7, 2, 1}, {64, 8, 16, 8, 8}, {192, 8, 12, 1, 64}, {256, 0, 18, 1, 1},
+    {256, 32, 64, 8, 8}, {256, 0, 9, 2, 1}, {160, 16, 64, 16, 4}, {256, 0, 10, 1, 1}};
 
 struct Bufs {
     const f32x4* priv[9];      // private streams, job j at + j * priv_f4 * 256
@@ -148,7 +151,9 @@ __global__ __launch_bounds__(256) void persistent_kernel(Bufs B, Bar* bar, int s
         }
 }
 
-int main() {
+int main(int argc, char** argv) {
+    if (argc > 1 && argv[1][0] == 'h') { for (int i = 0; i < 9; ++i) PH_HOST[i] = PH_HALF[i]; printf("table: gate GEMMs on 512-deep k ranges x one tile (half the slabs)\n"); }
+    CK(hipMemcpyToSymbol(HIP_SYMBOL(PH), PH_HOST, sizeof(PH_HOST)));
     int cus = 0;
     CK(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, 0));
     printf("%d CUs\n", cus);
