@@ -218,19 +218,9 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
     stamp(1);
     __syncthreads();                        // the planes are complete (HS == NSR: the only barrier of the kernel)
     stamp(2);
-    if constexpr (NSR != HS) {
-        sk_static_for<0, HS>([&](auto sc) {
-            constexpr int st = decltype(sc)::value;
-            const Cur c = seek(c_begin + HS + st);
-            const GemmSeg& g = a.seg[c.seg];
-            sk_static_for<0, XL>([&](auto jc) {
-                constexpr int j = decltype(jc)::value;
-                const int f = tid + 256 * j, row = f >> 4, c4 = f & 15;
-                xr2[st][j] = *reinterpret_cast<const f32x4*>(g.A + (size_t)(row < a.M ? row : a.M - 1) * g.lda + c.k0 + 4 * c4);
-            });
-        });
-        __builtin_amdgcn_sched_barrier(0);
-    }
+    // (the second half's activation loads ride inside steps 0 .. HS - 1, one float4 per thread every other MFMA group: issued in one
+    // burst here -- 64 KB per workgroup through a memory pipe that takes ~16 B per cycle -- they made step 0 take 5.1 k cycles instead
+    // of 3.2 k, in-kernel stamps round 6)
     sk_static_for<0, WP>([&](auto pc) { w_piece(std::integral_constant<int, 0>{}, std::integral_constant<int, 0>{}, pc, std::integral_constant<int, 0>{}); });
 
     sk_static_for<0, NT>([&](auto stepc) {
@@ -264,6 +254,14 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
             __builtin_amdgcn_sched_barrier(0);
         }
         if constexpr (HAS_LOAD) point_w(std::integral_constant<int, i + D - 1>{});
+        constexpr bool XLOAD = NSR != HS && i < HS;          // this step carries the loads of stage HS + i (second half)
+        const float* xbase = nullptr;
+        int xlda = 0;
+        if constexpr (XLOAD) {
+            const Cur c2 = seek(c_begin + HS + i);
+            xbase = a.seg[c2.seg].A + c2.k0;
+            xlda = a.seg[c2.seg].lda;
+        }
         const unsigned short* abase = planes + (size_t)li * RS_PB + 64 * (st % HS) + 8 * lq;
         sk_bf16x8 af[2][3];
         sk_static_for<0, 3>([&](auto pp) { af[0][decltype(pp)::value] = *reinterpret_cast<const sk_bf16x8*>(abase + decltype(pp)::value * PLANE); });
@@ -277,6 +275,12 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
             }
             if constexpr (HAS_LOAD)
                 sk_static_for<g * LW / G, (g + 1) * LW / G>([&](auto lc) { load_w1(std::integral_constant<int, (S + D - 1) % D>{}, lc); });
+            constexpr bool XL1 = XLOAD && g % (G / XL) == 0;
+            if constexpr (XL1) {
+                constexpr int j = g / (G / XL);
+                const int f = tid + 256 * j, row = f >> 4, c4 = f & 15;
+                xr2[i % HS][j] = *reinterpret_cast<const f32x4*>(xbase + (size_t)(row < a.M ? row : a.M - 1) * xlda + 4 * c4);
+            }
             if constexpr (b == 0 || HAS_NEXT) {
                 sk_static_for<t * WP / MT, (t + 1) * WP / MT>([&](auto pc) {
                     if constexpr (b == 0) w_piece(std::integral_constant<int, S>{}, std::integral_constant<int, 1>{}, pc, std::integral_constant<int, 1>{});
@@ -297,7 +301,7 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
                 acc[t][c] = v;
             });
             __builtin_amdgcn_sched_group_barrier(0x100, 3, 0);
-            if constexpr (HAS_LOAD) __builtin_amdgcn_sched_group_barrier(0x020, (g + 1) * LW / G - g * LW / G, 0);
+            if constexpr (HAS_LOAD || XL1) __builtin_amdgcn_sched_group_barrier(0x020, (HAS_LOAD ? (g + 1) * LW / G - g * LW / G : 0) + (XL1 ? 1 : 0), 0);
 #pragma unroll
             for (int k = 0; k < 6 * NCT; ++k) {
                 __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);

@@ -113,7 +113,7 @@ def test_predict_slab_path_matches_the_unsplit_gemm(tmp_path):
         np.testing.assert_allclose(got_lp[live], a[fam + "_lp"][live], atol=1e-4, err_msg=fam + ": replay")
         first = _first_divergence(sa, sb)
         rows = np.where(first >= 0)[0]
-        assert len(rows) <= 2, (fam, rows)
+        assert len(rows) <= 4, (fam, rows)      # (each of them must sit on a CDF edge, below; 2 with 256-deep k ranges, 3 with the 512-deep ones of round 6)
         for r_ in rows:
             t = first[r_]
             c = torch.cumsum(torch.softmax(lg[t, r_], 0), 0)
