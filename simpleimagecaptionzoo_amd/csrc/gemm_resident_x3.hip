@@ -739,7 +739,8 @@ int gemm_predict(const float* x, int H, const float* w_pred, const float* bias, 
     g.live = live;
     g.seg[0] = {x, w_pred, H, H, H, nullptr};
     g.M = rows; g.N = Vp; g.out = ws; g.ldo = Vp;
-    if (gemm_switches().predict_slabs && pred_nsplit && ws && gemm_resident_x3_fits(g) &&
+    // (one k range only -- K = 512 on 512-deep ranges, NIC's vocabulary projection -- is not a slab product: finished logits, bias fused)
+    if (gemm_switches().predict_slabs && pred_nsplit && ws && gemm_resident_x3_fits(g) && gemm_resident_x3_nsplit(g) > 1 &&
         gemm_slab_floats(rows, Vp, gemm_resident_x3_nsplit(g)) <= ws_cap_floats) {
         g.nsplit = gemm_resident_x3_nsplit(g);
         *pred_nsplit = g.nsplit;

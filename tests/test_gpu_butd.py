@@ -442,14 +442,16 @@ def test_random_shapes_match_oracle(cfg):
 
 
 def test_resident_gemm_decompositions_match_float64():
-    """The resident-activation split-precision kernels (csrc/gemm_resident_x3.hip): k ranges of four 64-deep stages (the only
-    decomposition that ships; a three-stage variant was measured and removed in round 3) at 33 .. 64 rows, and the 128-row kernel of
+    """The resident-activation split-precision kernels (csrc/gemm_resident_x3.hip) at 33 .. 64 rows: 512-deep k ranges on one column
+    tile with the planes in two halves (round 6; stage counts that are multiples of eight) and k ranges of four 64-deep stages on two
+    tiles (the rest; a three-stage variant was measured and removed in round 3), and the 128-row kernel of
     round 4 (65 .. 128 rows: half a k range resident at a time, two live column tiles, direct 16-byte stores) -- ragged rows and
     columns, K = 768 .. 4096, K shapes whose stage count is no multiple of four fall back to the fp32-MFMA kernel -- against the
     float64 product: error at the fp32 kernel's level (3e-6 of max|C|)."""
     from simpleimagecaptionzoo_amd.butd import gemm
     torch.manual_seed(0)
     for M, N, K in ((64, 4096, 3072), (64, 4096, 4096), (64, 10112, 1024), (33, 2048, 768), (50, 4100, 3072), (64, 3072, 4096), (47, 2052, 1536),
+                    (40, 2544, 512), (64, 2048, 1024), (36, 2060, 2560),          # round 6: one 512-deep range (no slabs), two, five
                     (128, 4096, 3072), (128, 4096, 4096), (128, 10112, 1024), (65, 2048, 512), (100, 4100, 3072), (127, 2052, 1536), (96, 3072, 8192)):
         X = torch.randn(M, K, device="cuda")
         W = torch.randn(N, K, device="cuda")
