@@ -16,7 +16,7 @@ features / references / random-init weights (no network), already resident in HB
     ... bench.py --gpus N --scaling strong     # global batch 64 split over the ranks (64 / N images per GPU) instead of 64 per GPU
 
 Rank 0 prints ONE JSON line (see the keys below).  `roofline` is measured live with HIP events around every launch of
-the dominant kernel (gemm_resident_x3_kernel<4,4,2,3>: the LSTM-gate and vocabulary-projection GEMMs of every decoder step
+the dominant kernel (gemm_resident_x3_kernel<4,8,1,3,.,4>: 512-deep k ranges on one column tile since round 6; the LSTM-gate and vocabulary-projection GEMMs of every decoder step
 and, on transposed weights, the per-step dgrad GEMMs of BPTT) in an eager re-run of bench steps right after the timed region;
 `cpu_baseline` times the CPU oracle (our port of the reference path, oracle/) on a bounded sample on rank 0.
 """
@@ -40,6 +40,8 @@ MFMA_F32_PEAK_TFLOPS = 157.3
 # cores of the survey / build container: 9.98 s per step.  The reference publishes no throughput; this is the only number for the metric.
 REFERENCE_IN_CONTAINER = {"captions_per_s": 6.4, "s_per_step": 9.98, "cores": 8, "source": "BASELINE.md section 2 (measured in the survey container, not on the GPU box)"}
 RESIDENT_X3 = os.environ.get("ICZ_GEMM_RESIDENT_X3", "1") not in ("", "0")     # the library's default: on
+K512 = os.environ.get("ICZ_GEMM_RESIDENT_K512", "1") not in ("", "0")           # round 6 default: 512-deep k ranges (half the split-K slabs)
+PRED_SLABS, GATE_SLABS = (2, 7) if K512 else (4, 14)                             # slabs the select / pointwise kernels sum (gates: mean of TD 6 | 12 and LM 8 | 16)
 
 
 def build_engine(device, B):
@@ -979,12 +981,12 @@ def small_kernel_rooflines(small, empty_pair, B):
     entry("attention", "dec_att GEMM (%d x 1024 x 1024) + att_scores_kernel + att_ctx_kernel: w_dec 4.2 MB + enc_ctx %d x 36 x 1024 + "
                        "features %d x 36 x 2048 + h1 / dec_ctx / ctx rows, fp32" % (B, B, B),
           4.0 * (A * H + A) + B * 4.0 * (R * A + R * D + H + 2 * A + D))
-    entry("greedy_select", "greedy_select_kernel: the four split-K slabs of the vocabulary projection (%d x 10112 fp32 each) + the next "
-                           "embedding row" % B, B * 4.0 * (4 * 10112 + V + E))
+    entry("greedy_select", "greedy_select_kernel: the two split-K slabs of the vocabulary projection (%d x 10112 fp32 each; four before round 6) + the next "
+                           "embedding row" % B, B * 4.0 * (PRED_SLABS * 10112 + V + E))
     entry("sample_select", "sample_select_kernel: the same slabs + the finished logits row written for backward + the next embedding row",
-          B * 4.0 * (4 * 10112 + 10112 + V + E))
+          B * 4.0 * (PRED_SLABS * 10112 + 10112 + V + E))
     entry("lstm_point", "lstm_point_gw_kernel: 12 - 16 split-K slabs of %d x 4096 gates + biases + cell state in / out + gates out" % B,
-          B * 4.0 * (14 * 4 * H + 4 * H + 3 * H + 4 * H))
+          B * 4.0 * (GATE_SLABS * 4 * H + 4 * H + 3 * H + 4 * H))
     return out
 
 
@@ -1011,11 +1013,11 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
         nt = [v for k, v in pmc["kernels"].items() if want in k]
         traffic = max(nt, key=lambda v: v["launches"])["hbm_bytes_per_launch"]
         src = ("profiles/" + os.path.basename(pmc_path) + ": rocprofv3 --pmc passes of this command at the committed code, NOT this run (PMC counters "
-               "cannot be read in-process); above the algorithmic bytes by the split-K slabs the kernel writes (12 - 16 slabs of "
-               "rows x N floats per gate GEMM, 4 per vocabulary projection), which its consumers sum")
+               "cannot be read in-process); above the algorithmic bytes by the split-K slabs the kernel writes (6 - 8 slabs of "
+               "rows x N floats per gate GEMM, 2 per vocabulary projection since round 6; twice that before), which its consumers sum")
     except Exception:
         pass
-    roof = {"kernel": ("gemm_resident_x3_kernel<4,4,2,3> (split precision, activations resident in LDS): the LSTM-gate GEMMs and the "
+    roof = {"kernel": ("gemm_resident_x3_kernel<4,8,1,3,false,4> (split precision, activations resident in LDS, 512-deep k ranges on one column tile): the LSTM-gate GEMMs and the "
                        "vocabulary projection of every decoder step at 64 rows" if x3 else
                        "decoder-step forward GEMMs at 64 rows: gemm_nt_kernel<4,1,false,128,4,true> (fp32-input MFMA)")}
     # `achieved` / `frac` / `avg_launch_us` are THIS run's (live HIP-event pairs around every launch of the kernel, minus what a pair
@@ -1039,8 +1041,8 @@ def roofline_entry(pair, empty_pair, bytes_pl, flops_pl, launches):
                  "launches": launches, "bytes_per_launch": bytes_pl, "flops_per_launch": flops_pl,
                  "roofline_us_per_launch": {"hbm": t_hbm * 1e6, "mfma": t_mfma * 1e6},
                  "bytes_note": "algorithmic bytes per launch = (M K + N K + M N) x 4: activations, weights and output once each "
-                               "(DESIGN.md section 4); what a compute unit actually pulls in is 1.5x that: every workgroup re-reads its "
-                               "64 x 256 activation block from L2 and writes a 64 x 256 slab (gemm_resident_x3.hip, MEASURED)",
+                               "(DESIGN.md section 4); what a compute unit actually pulls in is 1.6x that: every workgroup re-reads its "
+                               "64 x 512 activation block from L2 (128 KB per 256 KB of weights) and writes a 64 x 128 slab (gemm_resident_x3.hip, MEASURED)",
                  "hbm_gbs": gbs, "hbm_frac": gbs / HBM_PEAK_GBS, "fp32_equiv_tflops": tf, "mfma_f32_frac": tf / MFMA_F32_PEAK_TFLOPS})
     return roof
 

@@ -27,6 +27,21 @@
 // Everything is compile-time (steps, ring slots, tile boundaries): no branch with a vector-memory operation in it.
 // Launch: 1-D grid of (column groups) x (k ranges) workgroups, every one with exactly NSR stages (the launcher checks).
 //
+// Round 6 -- what ships at <= 64 rows wherever the stage count is a multiple of eight (every product of the BASELINE models): a workgroup
+// owns a 512-deep k range (NSR = 8) and ONE column tile, i.e. the same 256 KB of weights as before, twice the activation block (128 KB,
+// an L2 hit) and HALF the slab (32 KB): 6 / 8 / 2 split-K slabs instead of 12 / 16 / 4 for the TD gates, the LM gates and the vocabulary
+// projection, on the same 192 / 256 / 158 workgroups.  The planes hold half a range (HS = 4 stages, 98 KB) at a time; the second half's
+// activations are loaded into registers during the first half's steps (one float4 per thread every other MFMA group), wait there, and
+// are cut into the same planes between two barriers in front of step 4; the accumulators stay live across the halves, one epilogue.
+// MEASURED (profiles/r06_resident_k512_stamps.txt, median cycles per workgroup, LM gates 64 x 4096 x 4096): steps 3.5 k, 3 x 2.8 k,
+// 5.2 k (the re-split: +3 k), 2.2 k, 1.9 k, 2.1 k + one epilogue 2.0 k = 35.6 k against 34.8 k for the 256-deep form -- the GEMM itself
+// is 2 - 5 % SLOWER, and the step around it faster: the pointwise / select / BPTT kernels sum half the slabs and the launch edge
+// behind the GEMM has half the dirty bytes to write back.  Same box, three alternations (profiles/r06_resident_k512_ab.log): SCST step
+// 5.69 -> 5.50 ms, rollouts 2.79 -> 2.70, backward 2.49 -> 2.40.  (First version, the second half's loads in one burst behind the
+// barrier: step 0 took 5.1 k cycles instead of 3.5 k, SCST step 5.79 -> 5.67 ms.)  The data-movement emulation had predicted the
+// direction (tools/cxx/persistent_step.hip `half`: 72.9 -> 67.9 us per greedy step, profiles/r06_persistent_step_half_slabs.txt).
+// ICZ_GEMM_RESIDENT_K512=0 selects the 256-deep form everywhere.
+//
 // MEASURED (MI355X, in-kernel clock stamps under -DICZ_DEV, tools/perf_skinny_stamps.py; rocprofv3 for whole launches):
 //   * round 2: per workgroup ~9.5-11.5 k cycles from entry to the barrier, ~2.1-3.2 k per pipeline step (32 KB of weights),
 //     ~1.7-2.1 k per tile epilogue; the main loop runs at the chip's HBM rate (256 KB per CU in ~19 k cycles), the fixed part
@@ -655,15 +670,18 @@ static int rs_launch(const GemmArgs& a, hipStream_t stream) {
     return ICZ_OK;
 }
 
+#ifndef RS_K512_D
+#define RS_K512_D 3          // depth of the weight ring of the 512-deep form (pipeline steps in flight + 1); 4 measured: +5 - 8 % cycles per workgroup (a longer prologue), profiles/r06_resident_k512_stamps.txt
+#endif
 template <bool STAMPS>
 static int rs_launch_k512(const GemmArgs& a, hipStream_t stream) {
     constexpr size_t lds = rs_lds_bytes<4, 4>();
     static bool attr = false;
     if (!attr) {
-        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, 8, 1, 3, STAMPS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_kernel<4, 8, 1, RS_K512_D, STAMPS, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
-    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, 8, 1, 3, STAMPS, 4>), dim3(cdiv(a.N, 128) * a.nsplit), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((gemm_resident_x3_kernel<4, 8, 1, RS_K512_D, STAMPS, 4>), dim3(cdiv(a.N, 128) * a.nsplit), dim3(256), lds, stream, a);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
@@ -722,11 +740,11 @@ int gemm_resident_x3_pair(const GemmArgs& a_in, const GemmArgs& b_in, hipStream_
     static bool attr = false;
     if (!attr) {
         ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 4, 2, 3>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 8, 1, 3, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        ICZ_CHECK_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(gemm_resident_x3_pair_kernel<4, 8, 1, RS_K512_D, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     const dim3 grid(g.first + cdiv(g.b.N, tilew) * g.b.nsplit);
-    if (nsr == 8) hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 8, 1, 3, 4>), grid, dim3(256), lds, stream, g);
+    if (nsr == 8) hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 8, 1, RS_K512_D, 4>), grid, dim3(256), lds, stream, g);
     else hipLaunchKernelGGL((gemm_resident_x3_pair_kernel<4, 4, 2, 3>), grid, dim3(256), lds, stream, g);
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
