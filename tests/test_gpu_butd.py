@@ -397,6 +397,9 @@ def test_edge_cases_single_row_single_step_and_argument_errors(golden_dir):
     (2, 49, 100, 36, 20, 28, 57, 6),
     (9, 12, 64, 256, 64, 64, 130, 3),
     (64, 36, 32, 32, 32, 32, 41, 3),
+    # 40 rows x 4 H = 2560 gate columns reach the resident GEMM; K segments of 10 | 4 | 10 (TD) and 4 | 10 | 10 (LM) 64-deep stages:
+    # the 512-deep k ranges of round 6 (and their halves) cross segment boundaries
+    (40, 12, 256, 640, 256, 64, 300, 3),
 ])
 def test_random_shapes_match_oracle(cfg):
     """Randomly initialised decoders of assorted sizes: greedy ids / alphas, sampled log-probs and every REINFORCE gradient
