@@ -56,6 +56,7 @@ struct TrainBuf {
     float *dc1[2] = {nullptr, nullptr}, *dc2[2] = {nullptr, nullptr};
     float* X[4] = {nullptr, nullptr, nullptr, nullptr}; size_t xfloats = 0;
     float *dWp = nullptr, *dWenc = nullptr, *dWdec = nullptr, *dWaff = nullptr, *scalars = nullptr;
+    float* wslab = nullptr; size_t wslab_floats = 0;      // split-K slabs of the two attention weight gradients (gemm_tn_split, round 6)
     int* scalars_i = nullptr; int scalars_i_cap = 0;
 };
 

@@ -99,6 +99,12 @@ int Butd::ensure_train(int B, int T) {
     ICZ_TRY(zalloc((void**)&tb.dWp, sizeof(float) * Vp * H));
     ICZ_TRY(zalloc((void**)&tb.dWenc, sizeof(float) * A * D));
     ICZ_TRY(zalloc((void**)&tb.dWdec, sizeof(float) * A * H));
+    {   // slabs of the two attention weight gradients (A x H over T B rows, A x D over B R rows), one buffer: they run one after the other
+        const size_t n1 = (size_t)gemm_tn_split_pick((int)A, (int)H, (int)TB) * A * H, n2 = (size_t)gemm_tn_split_pick((int)A, (int)D, (int)(B * R)) * A * D;
+        tb.wslab_floats = n1 > n2 ? n1 : n2;
+        if (tb.wslab_floats > A * (H > D ? H : D)) ICZ_TRY(zalloc((void**)&tb.wslab, sizeof(float) * tb.wslab_floats));
+        else tb.wslab_floats = 0;
+    }
     ICZ_TRY(zalloc((void**)&tb.dWaff, sizeof(float) * A));
     ICZ_TRY(zalloc((void**)&tb.scalars, sizeof(float) * 16));
     ICZ_TRY(zalloc((void**)&tb.scalars_i, sizeof(int) * 2 * T));
@@ -515,6 +521,17 @@ int Butd::gemm_auto(GemmLayout layout, GemmArgs& g, float* slab, size_t slab_flo
 
 // C (ldc) = A^T B over K rows, written directly (no split): weight gradients
 int Butd::wgrad(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, float* out, int ldo, hipStream_t st, const int* rows_live) {
+    // too few 128 x 128 tiles to fill the chip (the attention projections): split K on the large-tile split-precision kernel, sum the slabs
+    if (tb.wslab && ldo == N) {
+        const int ns = gemm_tn_split_pick(M, N, K);
+        if (ns > 1 && (size_t)ns * M * N <= tb.wslab_floats && ((size_t)M * N) % 4 == 0) {
+            ICZ_TRY(gemm_tn_split(dY, ldy, M, X, ldx, N, K, ns, tb.wslab, rows_live, st));
+            const size_t MN = (size_t)M * N;
+            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, (const float*)tb.wslab, ns, MN, N, (const float*)nullptr, out);
+            ICZ_CHECK_HIP(hipGetLastError());
+            return ICZ_OK;
+        }
+    }
     GemmArgs g = {};
     g.nseg = 1;
     g.rows_live = rows_live;

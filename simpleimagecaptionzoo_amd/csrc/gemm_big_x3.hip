@@ -366,6 +366,31 @@ int gemm_big_x3(GemmLayout layout, const GemmArgs& a, int cfg, hipStream_t st) {
     return launch_cfg<false, false>(a, cfg, cg, st);
 }
 
+int gemm_tn_split_pick(int M, int N, int K) {
+    static const bool on = [] { const char* e = getenv("ICZ_GEMM_TN_SPLIT"); return e ? atoi(e) != 0 : true; }();      // A/B switch (read once)
+    if (!on) return 1;
+    if (!gemm_switches().tn_x3 || gemm_big_switch() == 0 || M < 128 || N < 128 || M % 4 || N % 4 || K % BX_KS || K < 512) return 1;
+    const int tiles = cdiv(M, 128) * cdiv(N, 128), chunks = cdiv(K, 128);
+    if (tiles >= 256) return 1;                       // the plain route takes it
+    int s = 448 / tiles;                              // about two workgroups per CU
+    if (s > chunks / 2) s = chunks / 2;               // at least two chunks (256 rows of K) per split
+    if (s < 2) return 1;
+    return cdiv(chunks, cdiv(chunks, s));             // no empty splits
+}
+
+int gemm_tn_split(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, int nsplit, float* slabs, const int* rows_live, hipStream_t st) {
+    ICZ_REQUIRE(dY && X && slabs && nsplit > 1 && nsplit == gemm_tn_split_pick(M, N, K), "gemm_tn_split: shape / split not taken (M %d N %d K %d, %d splits)", M, N, K, nsplit);
+    ICZ_REQUIRE(ldy % 4 == 0 && ldx % 4 == 0 && ((uintptr_t)dY & 15) == 0 && ((uintptr_t)X & 15) == 0 && ((uintptr_t)slabs & 15) == 0, "gemm_tn_split: operand alignment");
+    GemmArgs a = {};
+    a.nseg = 1;
+    a.seg[0] = {dY, X, ldy, ldx, K, nullptr};
+    a.M = M; a.N = N; a.out = slabs; a.ldo = N; a.nsplit = nsplit; a.chunks_per_split = cdiv(cdiv(K, 128), nsplit);
+    a.rows_live = rows_live;
+    ICZ_TRY(big_check(a, 4));
+    BxGroups cg = {};
+    return launch_cfg<false, false>(a, 4, cg, st);
+}
+
 bool gemm_tn_grouped_fits(int M, int K, const GemmColGroup* groups, int ngroups) {
     if (!gemm_switches().tn_x3 || gemm_big_switch() == 0 || ngroups < 1 || ngroups > GEMM_MAX_COLGROUPS || M % 4 || K % 32 || K < 64) return false;
     int N = 0;

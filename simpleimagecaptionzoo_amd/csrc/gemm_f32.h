@@ -112,6 +112,12 @@ int gemm_tn_grouped(const float* dY, int ldy, int M, int K, const GemmColGroup* 
 // ICZ_GEMM_RESIDENT_M128 (0: 65..128 rows go to the 128 x 128-tile kernel instead of the 128-row resident kernel),
 // ICZ_PREDICT_SLABS (0: un-split vocabulary projection -- the slab A/B test), ICZ_PROF_EVERY (event pairs on every n-th launch),
 // ICZ_GEMM_BIG (unset / -1: gemm_big_cfg's choice per shape; 0: the 128 x 128 two-barrier kernel everywhere; 1..5: that large-tile configuration everywhere).
+// (round 6) TN products too small to fill the chip on 128 x 128 tiles (fewer than 256 of them: the weight gradients of the two attention
+// projections, 1024 x 1024 over 1280 rows and 1024 x 2048 over 2304) on the large-tile split-precision kernel with split-K slabs
+// [nsplit][M][N] (the caller sums them: slab_reduce_kernel) instead of the fp32-MFMA 64 x 64 kernel.  gemm_tn_split_pick: the split (1 =
+// shape not taken); gemm_tn_split: the launch (K a multiple of 16, splits on 128-deep chunk boundaries, rows_live as in gemm_tn_grouped).
+int gemm_tn_split_pick(int M, int N, int K);
+int gemm_tn_split(const float* dY, int ldy, int M, const float* X, int ldx, int N, int K, int nsplit, float* slabs, const int* rows_live, hipStream_t st);
 struct GemmSwitches { bool tn_x3, nn_x3, nt_x3big, resident_x3, resident_m128, predict_slabs, resident_k512; unsigned prof_every; int big_cfg; };
 const GemmSwitches& gemm_switches();
 
