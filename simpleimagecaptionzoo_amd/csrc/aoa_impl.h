@@ -102,7 +102,6 @@ struct Aoa {
     int64_t* tok = nullptr;
     float *th = nullptr, *tm = nullptr, *tctx = nullptr, *temb = nullptr, *tu = nullptr, *tg = nullptr, *tstats = nullptr, *tqn = nullptr,
           *tQp = nullptr, *tP = nullptr, *tPd = nullptr, *tdS = nullptr, *tdX = nullptr, *txatt = nullptr, *tz = nullptr, *tcd = nullptr, *tlogit = nullptr;
-    float* wslab = nullptr; size_t wslab_floats = 0;      // split-K slabs of the small weight gradients (q / k / v projections; gemm_tn_split, round 6)
     float *dCd = nullptr, *dZ = nullptr, *dQp = nullptr, *dQn = nullptr, *dHln = nullptr, *dG = nullptr, *dEmb = nullptr, *dKd = nullptr,
           *dVd = nullptr, *dcb[2] = {nullptr, nullptr}, *X = nullptr, *X2 = nullptr, *dWp = nullptr, *prod = nullptr;
     float *coef = nullptr, *lse = nullptr, *loss_rows = nullptr;

@@ -259,13 +259,6 @@ int Aoa::ensure_train(int Bq, int Tq) {
     ICZ_TRY(alloc((void**)&dKd, sizeof(float) * B * R * Hd));
     ICZ_TRY(alloc((void**)&dVd, sizeof(float) * B * R * Hd));
     ICZ_TRY(alloc((void**)&dHln, sizeof(float) * B * Hd));
-    {   // slabs of the Hd x Hd weight gradients over T B rows (query projection) and over the batch's region rows (key / value projections)
-        const int s1 = gemm_tn_split_pick((int)Hd, (int)Hd, (int)TB), s2 = gemm_tn_split_pick((int)Hd, (int)Hd, (int)(B * R));
-        wslab_floats = (size_t)(s1 > s2 ? s1 : s2) * Hd * Hd;
-        wslab = nullptr;
-        if (wslab_floats > Hd * Hd) ICZ_TRY(alloc((void**)&wslab, sizeof(float) * wslab_floats));
-        else wslab_floats = 0;
-    }
     ICZ_TRY(alloc((void**)&dcb[0], sizeof(float) * B * Hd));
     ICZ_TRY(alloc((void**)&dcb[1], sizeof(float) * B * Hd));
     xfloats = (size_t)TARGET_WGS * 4096 * 2 + TB * (Hd > E ? Hd : E) + B * 4 * Hd;
@@ -558,17 +551,6 @@ int Aoa::nn(const float* A, int lda, int M, int K, const float* Bm, int ldb, int
 
 int Aoa::tn(const float* dY, int ldy, int M, const float* Xm, int ldx, int N, int K, float* out, int ldo, int accumulate, hipStream_t st,
             const int* rows_live) {
-    // too few 128 x 128 tiles to fill the chip (the Hd x Hd projections): split K on the large-tile split-precision kernel, sum the slabs
-    if (wslab && ldo == N && !accumulate) {
-        const int ns = gemm_tn_split_pick(M, N, K);
-        if (ns > 1 && (size_t)ns * M * N <= wslab_floats && ((size_t)M * N) % 4 == 0) {
-            ICZ_TRY(gemm_tn_split(dY, ldy, M, Xm, ldx, N, K, ns, wslab, rows_live, st));
-            const size_t MN = (size_t)M * N;
-            hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, (const float*)wslab, ns, MN, N, (const float*)nullptr, out);
-            ICZ_CHECK_HIP(hipGetLastError());
-            return ICZ_OK;
-        }
-    }
     GemmArgs g = {};
     g.nseg = 1;
     g.rows_live = rows_live;
