@@ -582,7 +582,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
-        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork4, hipEventDisableTiming));
     }
     hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
     if (phases & 1) {
@@ -775,15 +774,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     const bool tail_side = phases == 0xF && !grad_cb && concurrent;
     if (tail_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork3, st));
     bool tail_forked = false;
-    static const bool side_more_on = [] { const char* e = getenv("ICZ_TAIL_SIDE_MORE"); return e ? atoi(e) != 0 : true; }();      // A/B switch
-    const bool side_more = tail_side && side_more_on;
-    // the mean-feature columns of the TD input weights: sum of d gates over time (the mean is the same in every step) x mean -- 10 + 35 us
-    // of kernels that depend on the loop only; round 6: with the tail on the side branch they run there, off the chain of big weight-gradient
-    // GEMMs that clamp + Adam waits for (eager timeline: profiles/r06_backward_eager_timeline_*.txt)
-    auto mean_wgrad = [&](hipStream_t s) -> int {
-        hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)Bs * 4 * H / 4), 256)), dim3(256), 0, s, tb.dGtd, T, (size_t)Bs * 4 * H, tb.dGsum);
-        return wgrad(tb.dGsum + (size_t)roff * 4 * H, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, H + D + E, s);      // mean features
-    };
     hipStream_t const main_st = st;
     auto behind_loop = [&]() -> int {
     if (phases & 2) {
@@ -800,9 +790,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, E, (const float*)nullptr, tb.dEmb);
         }
         // inactive (t,b) rows have dG = 0 -> dEmb = 0; their token ids are whatever the buffer held (valid ids)
-        // (round 6: with the tail on the side branch the ordered scatter -- 40 us on a fraction of the chip -- goes there too, behind an event)
-        if (side_more) ICZ_CHECK_HIP(hipEventRecord(ev_fork4, st));
-        else ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
+        ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
     // (round 5) the three products over all (t, b) share d gates: one launch over the column groups [h2 | emb | h1] (4096 x 3072 at the
@@ -813,7 +801,8 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     const bool td_grouped = gemm_tn_grouped_fits(4 * H, TB, td_groups, 3);
     if (td_grouped) ICZ_TRY(gemm_tn_grouped(tb.dGtd, 4 * H, 4 * H, TB, td_groups, 3, rl, st));
     else ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h2, H, H, TB, G.td_w_ih, ldtd, st, rl));
-    if (!side_more) ICZ_TRY(mean_wgrad(st));      // (tail on the side branch: issued there, see below)
+    hipLaunchKernelGGL(timesum_kernel, dim3(cdiv((int)((size_t)Bs * 4 * H / 4), 256)), dim3(256), 0, st, tb.dGtd, T, (size_t)Bs * 4 * H, tb.dGsum);
+    ICZ_TRY(wgrad(tb.dGsum + (size_t)roff * 4 * H, 4 * H, 4 * H, mean, D, D, B, G.td_w_ih + H, ldtd, st));      // mean features
     if (!td_grouped) {
         ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.emb, E, E, TB, G.td_w_ih + H + D, ldtd, st, rl));
         ICZ_TRY(wgrad(tb.dGtd, 4 * H, 4 * H, tb.h1, H, H, TB, G.td_w_hh, H, st, rl));
@@ -837,11 +826,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     if (tail_side) {
         ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork3, 0));
         tail_forked = true;
-        if (side_more) {
-            ICZ_TRY(mean_wgrad(low_st));
-            ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork4, 0));
-            ICZ_CHECK_HIP(embed_grad_launch(low_st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
-        }
         st = low_st;
     }
     ICZ_TRY(wgrad(tb.dDec, A, A, tb.h1 + sH, H, H, TB, tb.dWdec, H, st));
