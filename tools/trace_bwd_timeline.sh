@@ -9,4 +9,5 @@ PD=$(mktemp -d /tmp/prof_XXXXXX)
 rocprofv3 --kernel-trace --output-format csv -d $PD -- python3 $ROOT/tools/perf_headline.py 6 > $ROOT/gpurun_out/${tag}_bwd_trace.log 2>&1
 f=$(find $PD -name "*kernel_trace.csv" | head -1)
 python3 $ROOT/tools/trace_timeline.py $f > $ROOT/gpurun_out/${tag}_bwd_timeline.txt 2>&1
+python3 $ROOT/tools/trace_timeline.py $f rollouts > $ROOT/gpurun_out/${tag}_rollouts_timeline.txt 2>&1
 tail -3 $ROOT/gpurun_out/${tag}_bwd_trace.log
