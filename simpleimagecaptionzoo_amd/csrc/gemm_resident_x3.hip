@@ -82,6 +82,14 @@ __device__ __forceinline__ uint32_t sk_cvt_pk_bf16(float lo, float hi) {
     asm("v_cvt_pk_bf16_f32 %0, %1, %2" : "=v"(r) : "v"(lo), "v"(hi));
     return r;
 }
+// the same instruction through the conversion builtin: one the machine scheduler knows as a VALU instruction.  Used where the cut stands
+// alone (the activation planes: prologue and re-split, -0.4 k cycles each); inside the main loop the hand-placed scheduling groups were
+// tuned around the INLINEASM nodes and the builtin makes steps 1 - 7 slower (stamps: profiles/r06_resident_k512_stamps.txt)
+__device__ __forceinline__ uint32_t sk_cvt_pk_bf16_b(float lo, float hi) {
+    typedef __bf16 sk_bf16x2_ __attribute__((ext_vector_type(2)));
+    typedef float sk_f32x2_ __attribute__((ext_vector_type(2)));
+    return __builtin_bit_cast(uint32_t, __builtin_convertvector((sk_f32x2_){lo, hi}, sk_bf16x2_));
+}
 // (a, b) -> three packed bf16 pairs (a in the low half): p0 + p1 + p2 == the fp32 values up to 2^-24 relative
 __device__ __forceinline__ void sk_split3(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
     p0 = sk_cvt_pk_bf16(a, b);
@@ -90,6 +98,15 @@ __device__ __forceinline__ void sk_split3(float a, float b, uint32_t& p0, uint32
     ra -= __uint_as_float(p1 << 16);
     rb -= __uint_as_float(p1 & 0xffff0000u);
     p2 = sk_cvt_pk_bf16(ra, rb);
+}
+
+__device__ __forceinline__ void sk_split3_b(float a, float b, uint32_t& p0, uint32_t& p1, uint32_t& p2) {
+    p0 = sk_cvt_pk_bf16_b(a, b);
+    float ra = a - __uint_as_float(p0 << 16), rb = b - __uint_as_float(p0 & 0xffff0000u);
+    p1 = sk_cvt_pk_bf16_b(ra, rb);
+    ra -= __uint_as_float(p1 << 16);
+    rb -= __uint_as_float(p1 & 0xffff0000u);
+    p2 = sk_cvt_pk_bf16_b(ra, rb);
 }
 
 constexpr int SK_BK = 64;                 // k per pipeline stage (two MFMA k blocks of 32)
@@ -213,8 +230,8 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
                 // float4 kq of a 32-block holds k = 4 kq .. 4 kq + 3: fragment position 8 (kq & 3) + 4 (kq >> 2) (see the header)
                 unsigned short* o = planes + (size_t)row * RS_PB + 64 * st + 32 * (c4 >> 3) + 8 * (kq & 3) + 4 * (kq >> 2);
                 uint32_t a0, a1, a2, b0, b1, b2;
-                sk_split3(xr[st][j][0], xr[st][j][1], a0, a1, a2);
-                sk_split3(xr[st][j][2], xr[st][j][3], b0, b1, b2);
+                sk_split3_b(xr[st][j][0], xr[st][j][1], a0, a1, a2);
+                sk_split3_b(xr[st][j][2], xr[st][j][3], b0, b1, b2);
                 *reinterpret_cast<sk_u32x2*>(o) = (sk_u32x2){a0, b0};
                 *reinterpret_cast<sk_u32x2*>(o + PLANE) = (sk_u32x2){a1, b1};
                 *reinterpret_cast<sk_u32x2*>(o + 2 * PLANE) = (sk_u32x2){a2, b2};
@@ -258,8 +275,8 @@ __device__ __forceinline__ void resident_x3_body(const GemmArgs& a, const int pa
                     const int f = tid + 256 * j, row = f >> 4, c4 = f & 15, kq = c4 & 7;
                     unsigned short* o = planes + (size_t)row * RS_PB + 64 * s2 + 32 * (c4 >> 3) + 8 * (kq & 3) + 4 * (kq >> 2);
                     uint32_t a0, a1, a2, b0, b1, b2;
-                    sk_split3(xr2[s2][j][0], xr2[s2][j][1], a0, a1, a2);
-                    sk_split3(xr2[s2][j][2], xr2[s2][j][3], b0, b1, b2);
+                    sk_split3_b(xr2[s2][j][0], xr2[s2][j][1], a0, a1, a2);
+                    sk_split3_b(xr2[s2][j][2], xr2[s2][j][3], b0, b1, b2);
                     *reinterpret_cast<sk_u32x2*>(o) = (sk_u32x2){a0, b0};
                     *reinterpret_cast<sk_u32x2*>(o + PLANE) = (sk_u32x2){a1, b1};
                     *reinterpret_cast<sk_u32x2*>(o + 2 * PLANE) = (sk_u32x2){a2, b2};
