@@ -26,7 +26,7 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(scaling):
     port = 29500 + (os.getpid() % 400) + (0 if scaling == "weak" else 1)
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--headline-only",
-           "--scaling", scaling]
+           "--scaling", scaling] + (["--dp-pieces", "1"] if scaling == "strong" else [])      # round 6: the timed region with ONE all-reduce behind the backward pass
     r = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-3000:]
     line = [l for l in r.stdout.splitlines() if l.startswith("{")]
@@ -35,6 +35,7 @@ def test_bench_two_rank_rehearsal_prints_the_contract_line(scaling):
     assert j["n_gpus"] == 2 and j["ranks_seen"] == 2 and j["scaling"] == scaling and j["steps"] == 2 and j["warmup"] == 1
     assert j["config"]["global_batch"] == (128 if scaling == "weak" else 64) and j["config"]["parallelism"] == "dp2"
     assert j["value"] > 0 and j["unit"] == "captions/s" and j["higher_is_better"] is True and "grad_allreduce_ms" in j
+    assert j["dp_pieces"] == (1 if scaling == "strong" else 4) and j["config"]["dp_pieces"] == j["dp_pieces"]
     _check_dp_fields(j)
 
 
