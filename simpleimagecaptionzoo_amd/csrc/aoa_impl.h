@@ -84,6 +84,7 @@ struct Aoa {
     hipEvent_t ev_fork = nullptr, ev_join = nullptr;
     hipStream_t low_st = nullptr;                         // backward: the predict layer's weight gradient beside the reverse-time loop (plain priority)
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
+    hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;      // (round 6) the attention block's small products beside the weight-gradient GEMMs of bptt's tail
     float *xa = nullptr, *xb = nullptr, *ln = nullptr, *qkv = nullptr, *o = nullptr, *od = nullptr, *nd = nullptr,
           *z = nullptr, *refined = nullptr, *meanf = nullptr, *Kd = nullptr, *Vd = nullptr;
     // decoder state + scratch
@@ -139,6 +140,8 @@ struct Aoa {
         if (low_st) (void)hipStreamDestroy(low_st);
         if (ev_fork2) (void)hipEventDestroy(ev_fork2);
         if (ev_join2) (void)hipEventDestroy(ev_join2);
+        if (ev_fork3) (void)hipEventDestroy(ev_fork3);
+        if (ev_join3) (void)hipEventDestroy(ev_join3);
         if (ev_fork) (void)hipEventDestroy(ev_fork);
         if (ev_join) (void)hipEventDestroy(ev_join);
         if (bm.n_live_host) (void)hipHostFree(bm.n_live_host);

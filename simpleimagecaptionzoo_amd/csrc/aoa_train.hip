@@ -426,6 +426,8 @@ int Aoa::sample_backward(const float* reward, const icz_aoa_params* G, float* lo
         ICZ_CHECK_HIP(hipStreamCreateWithFlags(&low_st, hipStreamNonBlocking));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming));
+        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
     }
     // with a DP callback the hook must fire on every call: eager launches (a replayed graph would not call it)
     if (!use_graphs || lens || grad_cb || aoa_explicit_rng(rng)) return sample_backward_impl(reward, *G, loss_out, msum_out, st);
@@ -587,6 +589,8 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
             ICZ_CHECK_HIP(hipStreamCreateWithFlags(&low_st, hipStreamNonBlocking));
             ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork2, hipEventDisableTiming));
             ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
+            ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming));
+            ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
         }
         ICZ_CHECK_HIP(hipEventRecord(ev_fork2, st));
         ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork2, 0));
@@ -650,6 +654,9 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
     const int s_loop = loop();
     if (side) ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join2, 0));      // the predict branch has long finished beside the loop
     if (s_loop != ICZ_OK) return s_loop;
+    static const bool tail_side_on = [] { const char* e = getenv("ICZ_AOA_TAIL_SIDE"); return e ? atoi(e) != 0 : true; }();      // A/B switch (read once)
+    const bool tail_side = side && tail_side_on;
+    if (tail_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork3, st));
     // ---- embedding gradient
     ICZ_TRY(nn(dG, 4 * Hd, TB, 4 * Hd, P.lstm_w_ih, E + Hd, E, X, xfloats, &ns, TARGET_WGS, st, nullptr, rl));
     {
@@ -678,25 +685,39 @@ int Aoa::bptt(const icz_aoa_params& G, hipStream_t st) {
         ICZ_TRY(tn(dZ, 2 * Hd, 2 * Hd, tqn, Hd, Hd, TB, G.dec.aoa_w + Hd, 2 * Hd, 0, st, rl));
     }
     ICZ_TRY(colsum(dZ, TB, 2 * Hd, 2 * Hd, G.dec.aoa_b, st));
-    ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, st, rl));
-    ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, st));
+    // ---- the attention block's small products (three Hd x Hd weight gradients, d K / d V, seven column sums: 240 us of kernels that fill a
+    //      fraction of the chip, eager timeline round 6) depend on the loop only: without a DP callback they run on the side stream beside
+    //      the embedding / LSTM / AoA-linear gradients above -- forked at the loop's end, ISSUED last, joined here (as Butd::bptt's tail)
+    hipStream_t ts = tail_side ? low_st : st;
+    auto tail = [&]() -> int {
+    ICZ_TRY(tn(dQp, Hd, Hd, tqn, Hd, Hd, TB, G.dec.q_w, Hd, 0, ts, rl));
+    ICZ_TRY(colsum(dQp, TB, Hd, Hd, G.dec.q_b, ts));
     {
         const int tc_fit = (int)(48 * 1024 / (sizeof(float) * 2 * (R + dh))), tc = T < tc_fit ? T : tc_fit;
-        hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)tc * 2 * (R + dh), st, tdS, tPd, tQp, tdX, dKd, dVd, B, T,
+        hipLaunchKernelGGL(aoa_dkv_kernel, dim3(B, NH), dim3(256), sizeof(float) * (size_t)tc * 2 * (R + dh), ts, tdS, tPd, tQp, tdX, dKd, dVd, B, T,
                            tc, R, Hd, NH, region_rows());
     }
     const int rrows = (int)region_row_count(B);      // region rows of the batch (packed valid rows with per-image counts)
-    ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.k_w, Hd, 0, st));
-    ICZ_TRY(colsum(dKd, rrows, Hd, Hd, G.dec.k_b, st));
-    ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.v_w, Hd, 0, st));
-    ICZ_TRY(colsum(dVd, rrows, Hd, Hd, G.dec.v_b, st));
+    ICZ_TRY(tn(dKd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.k_w, Hd, 0, ts));
+    ICZ_TRY(colsum(dKd, rrows, Hd, Hd, G.dec.k_b, ts));
+    ICZ_TRY(tn(dVd, Hd, Hd, refined, Hd, Hd, rrows, G.dec.v_w, Hd, 0, ts));
+    ICZ_TRY(colsum(dVd, rrows, Hd, Hd, G.dec.v_b, ts));
     // ---- h_norm gain / bias
     {
         const size_t n = (size_t)TB * Hd;
-        hipLaunchKernelGGL(aoa_ln_prod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, dQn, th + sH, tstats, prod, (size_t)TB, Hd);
-        ICZ_TRY(colsum(prod, TB, Hd, Hd, G.dec.ln_g, st));
-        ICZ_TRY(colsum(dQn, TB, Hd, Hd, G.dec.ln_b, st));
+        hipLaunchKernelGGL(aoa_ln_prod_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, ts, dQn, th + sH, tstats, prod, (size_t)TB, Hd);
+        ICZ_TRY(colsum(prod, TB, Hd, Hd, G.dec.ln_g, ts));
+        ICZ_TRY(colsum(dQn, TB, Hd, Hd, G.dec.ln_b, ts));
     }
+    return ICZ_OK;
+    };
+    if (tail_side) ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork3, 0));
+    const int s_tail = tail();
+    if (tail_side) {       // joined also on an error (inside a capture an unjoined side stream would hide it behind a capture failure)
+        ICZ_CHECK_HIP(hipEventRecord(ev_join3, low_st));
+        ICZ_CHECK_HIP(hipStreamWaitEvent(st, ev_join3, 0));
+    }
+    if (s_tail != ICZ_OK) return s_tail;
     ICZ_CHECK_HIP(hipGetLastError());
     return ICZ_OK;
 }
