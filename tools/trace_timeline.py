@@ -8,10 +8,15 @@ for r in rows:
 rows.sort(key=lambda r: r["s"])
 starts = [i for i, r in enumerate(rows) if "reinforce_loss_kernel" in r["Kernel_Name"]]
 i0 = starts[-1]
+STEP = len(sys.argv) > 2 and sys.argv[2] == "step"            # everything between the previous step's Adam and the last loss kernel (the rollouts), unwindowed
 if ROLL:
     i1 = i0
     i0 = max(i for i in range(i1) if "mean_feats_kernel" in rows[i]["Kernel_Name"])
-if not ROLL:
+if STEP:
+    i1 = i0
+    i0 = max(i for i in range(i1) if "adam_clamp_multi" in rows[i]["Kernel_Name"]) + 1
+    ROLL = False
+if not ROLL and not STEP:
     i1 = next(i for i in range(i0, len(rows)) if "adam_clamp_multi" in rows[i]["Kernel_Name"])
 t0 = rows[i0]["s"]
 qs = {}
