@@ -89,7 +89,6 @@ Butd::~Butd() {
     if (ev_join2) (void)hipEventDestroy(ev_join2);
     if (ev_fork3) (void)hipEventDestroy(ev_fork3);
     if (ev_join3) (void)hipEventDestroy(ev_join3);
-    if (ev_fork4) (void)hipEventDestroy(ev_fork4);
     if (ev_fork) (void)hipEventDestroy(ev_fork);
     if (ev_join) (void)hipEventDestroy(ev_join);
     clear_graphs();

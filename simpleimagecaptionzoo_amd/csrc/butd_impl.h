@@ -137,7 +137,6 @@ struct Butd {
     hipStream_t low_st = nullptr;        // lowest-priority stream for work overlapped with the BPTT chain
     hipEvent_t ev_fork2 = nullptr, ev_join2 = nullptr;
     hipEvent_t ev_fork3 = nullptr, ev_join3 = nullptr;   // the attention block's tail beside the LSTM weight gradients (bptt)
-    hipEvent_t ev_fork4 = nullptr;                       // ... d Emb complete: the embedding scatter ends that side branch (round 6)
     icz_grad_ready_cb grad_cb = nullptr; void* grad_cb_user = nullptr;   // DP overlap hook (icz_butd_set_grad_callback)
     int sample_backward_impl(const float* reward, const icz_butd_params& G, float* loss_out, float* mask_sum_out, hipStream_t st,
                              int phases = 0xF, bool fire_cb = true);

@@ -582,7 +582,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join2, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork3, hipEventDisableTiming));
         ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_join3, hipEventDisableTiming));
-        ICZ_CHECK_HIP(hipEventCreateWithFlags(&ev_fork4, hipEventDisableTiming));
     }
     hipEvent_t ev_fork = ev_fork2, ev_join = ev_join2;
     if (phases & 1) {
@@ -775,11 +774,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
     const bool tail_side = phases == 0xF && !grad_cb && concurrent;
     if (tail_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork3, st));
     bool tail_forked = false;
-    // (round 6) the ordered embedding scatter lasts as long as its most frequent token (36 us in an SCST step, 95 us in an XE batch) on a
-    // handful of workgroups, in the chain of big weight-gradient GEMMs clamp + Adam waits for: with the tail on the side branch it runs at
-    // the END of that branch (which has the slack), behind an event recorded where d Emb is complete
-    static const bool scatter_side_on = [] { const char* e = getenv("ICZ_EMBED_GRAD_SIDE"); return e ? atoi(e) != 0 : true; }();      // A/B switch
-    const bool scatter_side = tail_side && scatter_side_on;
     hipStream_t const main_st = st;
     auto behind_loop = [&]() -> int {
     if (phases & 2) {
@@ -796,8 +790,7 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
             hipLaunchKernelGGL(slab_reduce_kernel, dim3(cdiv((int)(MN / 4), 256)), dim3(256), 0, st, ws, ns, MN, E, (const float*)nullptr, tb.dEmb);
         }
         // inactive (t,b) rows have dG = 0 -> dEmb = 0; their token ids are whatever the buffer held (valid ids)
-        if (scatter_side) ICZ_CHECK_HIP(hipEventRecord(ev_fork4, st));
-        else ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
+        ICZ_CHECK_HIP(embed_grad_launch(st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     }
     // ---- weight gradients: one TN GEMM each over all (t, b)
     // (round 5) the three products over all (t, b) share d gates: one launch over the column groups [h2 | emb | h1] (4096 x 3072 at the
@@ -868,10 +861,6 @@ int Butd::bptt(const icz_butd_params& G, hipStream_t st, int phases, bool fire_c
         add(tb.dWdec, H, P.dec_att_v, P.dec_att_g, n_dec, G.dec_att_v, G.dec_att_g, A, H);
         add(tb.dWaff, A, P.affine_v, P.affine_g, n_aff, G.affine_v, G.affine_g, 1, A);
         hipLaunchKernelGGL(weight_norm_bwd_multi_kernel, dim3(nb), dim3(256), 0, st, wt);
-    }
-    if (scatter_side && tail_forked) {      // st == low_st here
-        ICZ_CHECK_HIP(hipStreamWaitEvent(low_st, ev_fork4, 0));
-        ICZ_CHECK_HIP(embed_grad_launch(low_st, tb.tok, TB, tb.dEmb, 1, (size_t)0, tb.emb, cur_train ? 2.0f : 1.0f, E, G.embed_weight, V, 1, rl));
     }
     }   // phase 3
     return ICZ_OK;

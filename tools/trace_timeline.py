@@ -6,9 +6,7 @@ rows = list(csv.DictReader(open(sys.argv[1])))
 for r in rows:
     r["s"], r["e"] = int(r["Start_Timestamp"]), int(r["End_Timestamp"])
 rows.sort(key=lambda r: r["s"])
-import os
-ANCHOR = os.environ.get("TL_ANCHOR", "reinforce_loss_kernel")      # the kernel that starts a backward pass (XE: xe_loss_dlogits_kernel)
-starts = [i for i, r in enumerate(rows) if ANCHOR in r["Kernel_Name"]]
+starts = [i for i, r in enumerate(rows) if "reinforce_loss_kernel" in r["Kernel_Name"]]
 i0 = starts[-1]
 STEP = len(sys.argv) > 2 and sys.argv[2] == "step"            # everything between the previous step's Adam and the last loss kernel (the rollouts), unwindowed
 if ROLL:
